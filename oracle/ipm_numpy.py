@@ -1,0 +1,484 @@
+"""Reference implementation (numpy, one instance at a time) of the solver algorithm that
+the HIP kernels and the C port (oracle/mmpc_oracle.c) run.
+
+TEST INFRASTRUCTURE ONLY (see oracle/nlp.py header).  Slow and explicit on purpose.
+
+The reference hands the NLP of controllers/mpc_wholebody_qref.py:142-285 to IPOPT
+(primal-dual interior point, exact Hessian, :280-285).  This file states the build's
+own solver for the same NLP:
+
+  * primal-dual interior point on the inequality rows, one slack t_i>0 and one
+    multiplier z_i>0 per row (h_i(w) + t_i = 0), monotone barrier schedule
+    (mu <- max(tol/10, min(0.2 mu, mu^1.5)), subproblem tolerance 10 mu) - the
+    Fiacco-McCormick schedule IPOPT uses by default;
+  * exact Lagrangian Hessian (cost + dynamics curvature + row curvature), the row
+    blocks condensed stage-wise; the per-stage scalar slack s_k is removed by a
+    rank-one Schur complement (quirk Q1 handled: terminal self-collision rows are
+    bound to s_{N-1});
+  * the Newton system is the block-tridiagonal KKT system of the multiple-shooting
+    QP; it is factorised stage by stage (Riccati recursion = block LDL^T of the KKT
+    matrix), with on-the-fly diagonal regularisation of a stage's input Hessian
+    when its Cholesky pivot is not positive;
+  * fraction-to-boundary rule + backtracking line search on an l1 merit function.
+"""
+from __future__ import annotations
+
+import numpy as np
+from . import nlp
+
+
+class Options:
+    tol = 1e-8
+    mu_init = 0.1
+    max_iter = 200
+    kappa_eps = 10.0
+    kappa_mu = 0.2
+    theta_mu = 1.5
+    tau_min = 0.99
+    t_init_min = 1e-2
+    eta = 1e-4
+    max_ls = 25
+    reg0 = 1e-6
+    exact_hessian = True
+    curv_dyn = True
+    curv_circ = True
+    curv_self = True
+    piv_frac = 0.0
+    nu_lam = 0.0
+    filter = True
+
+
+def _rows_for_stage(prob, k):
+    """Static description of the inequality rows of stage k in the solver's own order.
+
+    u rows (k<N): merged box  max(ulim_lo, u_last+dulim_lo) <= u <= min(ulim_hi, u_last+dulim_hi)
+    (mpc_wholebody_qref.py:203,205 - both are simple bounds on the same variable);
+    x rows (k>=1; x_0 is data, :244); circle rows (:208-209,:248-249); self rows (:219-222,:261-265).
+    Returns list of tuples (kind, index, sign/bound...).
+    """
+    p = prob.par
+    rows = []
+    if k < p.N:
+        lo = np.maximum(p.ulim[0], prob.u_last[k] + p.dulim[0])
+        hi = np.minimum(p.ulim[1], prob.u_last[k] + p.dulim[1])
+        for j in range(p.nu):
+            if np.isfinite(lo[j]):
+                rows.append(("ulo", j, lo[j]))
+            if np.isfinite(hi[j]):
+                rows.append(("uhi", j, hi[j]))
+    if k >= 1:
+        for j in range(p.nx):
+            if np.isfinite(p.xlim[0, j]):
+                rows.append(("xlo", j, p.xlim[0, j]))
+            if np.isfinite(p.xlim[1, j]):
+                rows.append(("xhi", j, p.xlim[1, j]))
+    for m, o in enumerate(prob.obs_at(k)):
+        rows.append(("circ", m, o))
+    if p.kind == "wholebody":
+        for i in range(4):
+            rows.append(("self", i, None))
+    return rows
+
+
+def _eval_row(prob, k, row, X, U, s, order):
+    """h (<=0 form), and sparse derivative pieces: (h, jx, ju, js_index, Hxx)."""
+    p = prob.par
+    kind, j, b = row
+    nx, nu = p.nx, p.nu
+    if kind == "ulo":
+        ju = np.zeros(nu); ju[j] = -1
+        return b - U[k, j], None, ju, None, None
+    if kind == "uhi":
+        ju = np.zeros(nu); ju[j] = 1
+        return U[k, j] - b, None, ju, None, None
+    if kind == "xlo":
+        jx = np.zeros(nx); jx[j] = -1
+        return b - X[k, j], jx, None, None, None
+    if kind == "xhi":
+        jx = np.zeros(nx); jx[j] = 1
+        return X[k, j] - b, jx, None, None, None
+    if kind == "circ":
+        if order == 0:
+            return nlp.circle_row(X[k], b, nx, 0) - s[k], None, None, k, None
+        g, jx, H = nlp.circle_row(X[k], b, nx, 2)
+        return g - s[k], jx, None, k, H
+    if kind == "self":
+        ks = nlp.slack_index(p, k)
+        if order == 0:
+            return nlp.selfcol_row(X[k], j, 0) - s[ks], None, None, ks, None
+        h, jx, H = nlp.selfcol_row(X[k], j, 2)
+        return h - s[ks], jx, None, ks, H
+    raise ValueError(kind)
+
+
+class State:
+    pass
+
+
+def _eval_all(prob, rows, X, U, s, order):
+    out = []
+    for k in range(prob.par.N + 1):
+        out.append([_eval_row(prob, k, r, X, U, s, order) for r in rows[k]])
+    return out
+
+
+def _defects(prob, X, U):
+    p = prob.par
+    return np.array([nlp.f_dyn(p.kind, X[k], U[k], p.dt) - X[k + 1] for k in range(p.N)])
+
+
+def _merit_parts(prob, rows, X, U, s, t, mu):
+    """returns (barrier objective, l1 infeasibility)"""
+    p = prob.par
+    f = nlp.cost(prob, X, U, s)
+    c = _defects(prob, X, U)
+    th = np.abs(c).sum() + np.abs(X[0] - prob.x_init).sum()
+    bar = 0.0
+    for k in range(p.N + 1):
+        for i, r in enumerate(rows[k]):
+            h = _eval_row(prob, k, r, X, U, s, 0)[0]
+            th += abs(h + t[k][i])
+            bar -= mu * np.log(t[k][i])
+    return f + bar, th
+
+
+def solve(prob: nlp.Problem, U0=None, X0=None, opt: Options = None, verbose=False, history=None):
+    """Solve one instance.  Initial point per the reference protocol
+    (mpc_wholebody_qref.py:302-304): X = tile(x_init), U = u_latest, s = 0.
+    Returns dict(X,U,s,status,iters,cost,kkt)."""
+    opt = opt or Options()
+    p = prob.par
+    N, nx, nu = p.N, p.nx, p.nu
+    X = np.tile(prob.x_init, (N + 1, 1)) if X0 is None else np.array(X0, float)
+    X[0] = prob.x_init
+    U = np.zeros((N, nu)) if U0 is None else np.array(U0, float)
+    s = np.zeros(N + 1)
+    lam = np.zeros((N + 1, nx))      # lam[k+1]: multiplier of x_{k+1} - f(x_k,u_k) = 0
+    rows = [_rows_for_stage(prob, k) for k in range(N + 1)]
+    mu = opt.mu_init
+    # slacks / multipliers
+    ev = _eval_all(prob, rows, X, U, s, 0)
+    t = [np.array([max(-e[0], opt.t_init_min) for e in ev[k]]) for k in range(N + 1)]
+    z = [mu / t[k] for k in range(N + 1)]
+    nrows = sum(len(r) for r in rows)
+    Q2 = p.Q + p.Q.T
+    P2 = p.P + p.P.T
+    RW2 = (p.R + p.R.T) + (p.W + p.W.T)
+    status = 1
+    nu_merit = 1.0
+    filt = None
+    nfail = 0
+    it = 0
+    for it in range(opt.max_iter + 1):
+        # ---------------- evaluation ------------------------------------
+        ev = _eval_all(prob, rows, X, U, s, 2)
+        gX, gU, gs = nlp.cost_grad(prob, X, U, s)
+        c = _defects(prob, X, U)
+        AB = [nlp.f_jac(p.kind, X[k], U[k], p.dt) for k in range(N)]
+        # ---------------- KKT error at current point ---------------------
+        rdx = gX.copy(); rdu = gU.copy(); rds = gs.copy()
+        for k in range(N + 1):
+            for i, (h, jx, ju, ks, H) in enumerate(ev[k]):
+                if jx is not None: rdx[k] += jx * z[k][i]
+                if ju is not None: rdu[k] += ju * z[k][i]
+                if ks is not None: rds[ks] -= z[k][i]
+        # equality multipliers: L = f + sum lam[k+1]^T (x_{k+1} - f(x_k,u_k)) + lam0^T(x0 - xinit)
+        for k in range(N):
+            A, B = AB[k]
+            rdx[k + 1] += lam[k + 1]
+            rdx[k] -= A.T @ lam[k + 1]
+            rdu[k] -= B.T @ lam[k + 1]
+        rdx[0] = 0.0   # x_0 is fixed data; its multiplier absorbs the residual
+        rh = [np.array([e[0] for e in ev[k]]) + t[k] for k in range(N + 1)]
+        err_d = max(np.abs(rdx).max(), np.abs(rdu).max(), np.abs(rds).max())
+        err_p = max(np.abs(c).max() if N else 0.0, max(np.abs(r).max() for r in rh))
+        comp0 = max((t[k] * z[k]).max() for k in range(N + 1))
+        compmu = max(np.abs(t[k] * z[k] - mu).max() for k in range(N + 1))
+        zsum = sum(z[k].sum() for k in range(N + 1)) + np.abs(lam).sum()
+        sd = max(100.0, zsum / (nrows + lam.size)) / 100.0
+        E0 = max(err_d / sd, err_p, comp0 / sd)
+        Emu = max(err_d / sd, err_p, compmu / sd)
+        if history is not None:
+            history.append(dict(it=it, mu=mu, E0=E0, Emu=Emu, err_d=err_d, err_p=err_p,
+                                cost=nlp.cost(prob, X, U, s)))
+        if verbose:
+            print(f"it {it:3d} mu {mu:8.2e} E0 {E0:9.3e} Emu {Emu:9.3e} d {err_d:9.3e} p {err_p:9.3e} "
+                  f"f {nlp.cost(prob, X, U, s):12.6f}")
+        if E0 <= opt.tol:
+            status = 0
+            break
+        if it == opt.max_iter:
+            break
+        changed = False
+        while Emu <= opt.kappa_eps * mu and mu > opt.tol / 10:
+            mu = max(opt.tol / 10, min(opt.kappa_mu * mu, mu ** opt.theta_mu))
+            compmu = max(np.abs(t[k] * z[k] - mu).max() for k in range(N + 1))
+            Emu = max(err_d / sd, err_p, compmu / sd)
+            changed = True
+        if changed:
+            nu_merit = 1.0
+            filt = None
+        # ---------------- stage QP assembly + Riccati ----------------------
+        def factor(use_exact):
+            Hxx = []; Hux = []; Huu = []; qx = []; qu = []
+            hss = 2 * p.S * np.ones(N + 1)
+            gss = gs.copy()
+            vx = np.zeros((N + 1, nx))        # sum_i w_i J_i,x for rows bound to s_k from stage k
+            vxN = np.zeros(nx)                # Q1: stage-N self rows bound to s_{N-1}
+            for k in range(N + 1):
+                H = (Q2 if k < N else P2).copy()
+                Hu = RW2.copy() if k < N else None
+                Hc = np.zeros((nu, nx)) if k < N else None
+                g = gX[k].copy()
+                gu = gU[k].copy() if k < N else None
+                if k < N and use_exact and opt.curv_dyn:
+                    fxx, fux, fuu = nlp.f_hess_contract(p.kind, X[k], U[k], p.dt, lam[k + 1])
+                    H -= fxx; Hc -= fux; Hu -= fuu
+                for i, (h, jx, ju, ks, Hr) in enumerate(ev[k]):
+                    w = z[k][i] / t[k][i]
+                    zh = mu / t[k][i] + w * rh[k][i]
+                    if jx is not None:
+                        H += w * np.outer(jx, jx)
+                        g += jx * zh
+                    if ju is not None:
+                        Hu += w * np.outer(ju, ju)
+                        gu += ju * zh
+                    if Hr is not None and use_exact:
+                        if (rows[k][i][0] == "circ" and opt.curv_circ) or (rows[k][i][0] == "self" and opt.curv_self):
+                            H += z[k][i] * Hr
+                    if ks is not None:
+                        hss[ks] += w
+                        gss[ks] -= zh
+                        if ks == k:
+                            vx[k] += w * jx
+                        else:
+                            vxN += w * jx
+                Hxx.append(H); Hux.append(Hc); Huu.append(Hu); qx.append(g); qu.append(gu)
+            # Schur complement of s_k  (cross term H_xs = -v)
+            for k in range(N + 1):
+                if k == N - 1:
+                    A, B = AB[k]
+                    a = vx[k] + A.T @ vxN
+                    b = B.T @ vxN
+                    gam = gss[k] - vxN @ c[k]
+                    Hxx[k] -= np.outer(a, a) / hss[k]
+                    Hux[k] -= np.outer(b, a) / hss[k]
+                    Huu[k] -= np.outer(b, b) / hss[k]
+                    qx[k] += a * gam / hss[k]
+                    qu[k] += b * gam / hss[k]
+                else:
+                    a = vx[k]
+                    Hxx[k] -= np.outer(a, a) / hss[k]
+                    qx[k] += a * gss[k] / hss[k]
+            Pm = [None] * (N + 1); pv = [None] * (N + 1)
+            K = [None] * N; kf = [None] * N
+            Pm[N] = Hxx[N]; pv[N] = qx[N]
+            for k in range(N - 1, -1, -1):
+                A, B = AB[k]
+                PA = Pm[k + 1] @ A
+                PB = Pm[k + 1] @ B
+                pc = pv[k + 1] + Pm[k + 1] @ c[k]
+                F = Hxx[k] + A.T @ PA
+                G = Hux[k] + B.T @ PA
+                Hh = Huu[k] + B.T @ PB
+                gx_ = qx[k] + A.T @ pc
+                gu_ = qu[k] + B.T @ pc
+                L = _chol_checked(Hh, np.diag(Huu[k]) if use_exact else None, opt.piv_frac)
+                if L is None:
+                    return None
+                K[k] = -_cho_solve(L, G)
+                kf[k] = -_cho_solve(L, gu_)
+                Pm[k] = F + G.T @ K[k]
+                Pm[k] = 0.5 * (Pm[k] + Pm[k].T)
+                pv[k] = gx_ + G.T @ kf[k]
+            return Pm, pv, K, kf, hss, gss, vx, vxN
+        fac = factor(opt.exact_hessian) if opt.exact_hessian else None
+        nreg = 0
+        if fac is None:
+            nreg = 1 if opt.exact_hessian else 0
+            fac = factor(False)
+        Pm, pv, K, kf, hss, gss, vx, vxN = fac
+        dX = np.zeros_like(X); dU = np.zeros_like(U)
+        dX[0] = prob.x_init - X[0]
+        for k in range(N):
+            A, B = AB[k]
+            dU[k] = K[k] @ dX[k] + kf[k]
+            dX[k + 1] = A @ dX[k] + B @ dU[k] + c[k]
+        lam_new = np.zeros_like(lam)
+        for k in range(1, N + 1):
+            lam_new[k] = -(Pm[k] @ dX[k] + pv[k])
+        # ---------------- recover ds, dt, dz ------------------------------
+        ds = np.zeros(N + 1)
+        for k in range(N + 1):
+            vdx = vx[k] @ dX[k]
+            if k == N - 1:
+                vdx += vxN @ dX[N]
+            ds[k] = -(gss[k] - vdx) / hss[k]
+        if getattr(opt, "dense_check", False):
+            _dense_check(prob, rows, ev, X, U, s, t, z, lam, mu, c, AB, gX, gU, gs, rh, dX, dU, ds, lam_new, opt,
+                         Q2, P2, RW2)
+        dt = [None] * (N + 1); dz = [None] * (N + 1)
+        for k in range(N + 1):
+            dtk = np.zeros(len(rows[k])); dzk = np.zeros(len(rows[k]))
+            for i, (h, jx, ju, ks, Hr) in enumerate(ev[k]):
+                jd = 0.0
+                if jx is not None: jd += jx @ dX[k]
+                if ju is not None: jd += ju @ dU[k]
+                if ks is not None: jd -= ds[ks]
+                dtk[i] = -rh[k][i] - jd
+                w = z[k][i] / t[k][i]
+                dzk[i] = mu / t[k][i] - z[k][i] - w * dtk[i]
+            dt[k] = dtk; dz[k] = dzk
+        # ---------------- step lengths ------------------------------------
+        tau = max(opt.tau_min, 1 - mu)
+        ap = 1.0; ad = 1.0
+        for k in range(N + 1):
+            neg = dt[k] < 0
+            if neg.any():
+                ap = min(ap, (-tau * t[k][neg] / dt[k][neg]).min())
+            neg = dz[k] < 0
+            if neg.any():
+                ad = min(ad, (-tau * z[k][neg] / dz[k][neg]).min())
+        # ---------------- line search -------------------------------------
+        phi0, th0 = _merit_parts(prob, rows, X, U, s, t, mu)
+        dphi = (gX * dX).sum() + (gU * dU).sum() + gs @ ds
+        for k in range(N + 1):
+            dphi -= mu * (dt[k] / t[k]).sum()
+        alpha = ap
+        accepted = False
+        if opt.filter:
+            if filt is None:
+                filt = []
+                th_max = 1e4 * max(1.0, th0)
+                th_min = 1e-4 * max(1.0, th0)
+            for ls in range(opt.max_ls):
+                Xn = X + alpha * dX; Un = U + alpha * dU; sn = s + alpha * ds
+                tn = [t[k] + alpha * dt[k] for k in range(N + 1)]
+                phi, th = _merit_parts(prob, rows, Xn, Un, sn, tn, mu)
+                ok_f = th < th_max and all(not (th >= fj[0] and phi >= fj[1]) for fj in filt)
+                ftype = (dphi < 0 and th0 <= th_min and alpha * (-dphi) ** 2.3 > th0 ** 1.1)
+                if ok_f:
+                    if ftype:
+                        if phi <= phi0 + 1e-8 * alpha * dphi + 1e-14 * abs(phi0):
+                            accepted = True
+                            break
+                    elif th <= (1 - 1e-5) * th0 or phi <= phi0 - 1e-5 * th0:
+                        accepted = True
+                        filt.append(((1 - 1e-5) * th0, phi0 - 1e-5 * th0))
+                        break
+                alpha *= 0.5
+            dm = dphi
+        else:
+            if th0 > 1e-14:
+                need = dphi / (0.9 * th0)
+                if need > nu_merit:
+                    nu_merit = need + 1.0
+            if opt.nu_lam:
+                nu_merit = max(nu_merit, opt.nu_lam * np.abs(lam_new).max())
+            dm = dphi - nu_merit * th0
+            for ls in range(opt.max_ls):
+                Xn = X + alpha * dX; Un = U + alpha * dU; sn = s + alpha * ds
+                tn = [t[k] + alpha * dt[k] for k in range(N + 1)]
+                phi, th = _merit_parts(prob, rows, Xn, Un, sn, tn, mu)
+                if phi + nu_merit * th <= phi0 + nu_merit * th0 + opt.eta * alpha * dm + 1e-13 * abs(phi0):
+                    accepted = True
+                    break
+                alpha *= 0.5
+        nfail += (not accepted)
+        if verbose:
+            print(f"      ap {ap:.3f} ad {ad:.3f} alpha {alpha:.4f} ls {ls} nreg {nreg} nu {nu_merit:.2e} dm {dm:.3e}")
+        X = X + alpha * dX; U = U + alpha * dU; s = s + alpha * ds
+        X[0] = prob.x_init
+        for k in range(N + 1):
+            t[k] = t[k] + alpha * dt[k]
+            z[k] = z[k] + ad * dz[k]
+        lam = lam + alpha * (lam_new - lam)
+    return dict(X=X, U=U, s=s, status=status, iters=it, cost=nlp.cost(prob, X, U, s), E0=E0,
+                lam=lam, mu=mu, nfail=nfail)
+
+
+def _chol_reg(H, reg0):
+    """Cholesky of a small SPD block; if a pivot is <= 0 add delta*I (delta = reg0, x10...)."""
+    delta = 0.0
+    n = 0
+    while True:
+        try:
+            L = np.linalg.cholesky(H + delta * np.eye(H.shape[0]))
+            return L, n
+        except np.linalg.LinAlgError:
+            delta = reg0 if delta == 0.0 else delta * 10
+            n += 1
+
+
+def _chol_checked(H, ref_diag, frac):
+    """Cholesky; returns None if a pivot is not safely positive (exact-Hessian attempt)."""
+    n = H.shape[0]
+    L = np.zeros_like(H)
+    for j in range(n):
+        d = H[j, j] - L[j, :j] @ L[j, :j]
+        lim = 0.0 if ref_diag is None else frac * ref_diag[j]
+        if not (d > lim) or not np.isfinite(d):
+            if ref_diag is None:
+                raise FloatingPointError("GN Hessian not PD: %r" % d)
+            return None
+        L[j, j] = np.sqrt(d)
+        for i in range(j + 1, n):
+            L[i, j] = (H[i, j] - L[i, :j] @ L[j, :j]) / L[j, j]
+    return L
+
+
+def _cho_solve(L, B):
+    y = np.linalg.solve(L, B)
+    return np.linalg.solve(L.T, y)
+
+
+def _dense_check(prob, rows, ev, X, U, s, t, z, lam, mu, c, AB, gX, gU, gs, rh, dX, dU, ds, lam_new, opt,
+                 Q2, P2, RW2):
+    """Debug: assemble the full (un-condensed) Newton KKT system densely and compare."""
+    p = prob.par
+    N, nx, nu = p.N, p.nx, p.nu
+    nvar = (N + 1) * nx + N * nu + N + 1
+    offU = (N + 1) * nx
+    offS = offU + N * nu
+    H = np.zeros((nvar, nvar)); g = np.zeros(nvar)
+    for k in range(N + 1):
+        xs = slice(k * nx, (k + 1) * nx)
+        H[xs, xs] += Q2 if k < N else P2
+        g[xs] += gX[k]
+        H[offS + k, offS + k] += 2 * p.S
+        g[offS + k] += gs[k]
+        if k < N:
+            us = slice(offU + k * nu, offU + (k + 1) * nu)
+            H[us, us] += RW2
+            g[us] += gU[k]
+            if opt.exact_hessian:
+                fxx, fux, fuu = nlp.f_hess_contract(p.kind, X[k], U[k], p.dt, lam[k + 1])
+                H[xs, xs] -= fxx; H[us, xs] -= fux; H[xs, us] -= fux.T; H[us, us] -= fuu
+        for i, (h, jx, ju, ks, Hr) in enumerate(ev[k]):
+            J = np.zeros(nvar)
+            if jx is not None: J[xs] = jx
+            if ju is not None: J[offU + k * nu: offU + (k + 1) * nu] = ju
+            if ks is not None: J[offS + ks] = -1
+            w = z[k][i] / t[k][i]
+            zh = mu / t[k][i] + w * rh[k][i]
+            H += w * np.outer(J, J)
+            g += J * zh
+            if Hr is not None and opt.exact_hessian:
+                H[xs, xs] += z[k][i] * Hr
+    neq = (N + 1) * nx
+    Jc = np.zeros((neq, nvar)); rc = np.zeros(neq)
+    Jc[:nx, :nx] = np.eye(nx); rc[:nx] = X[0] - prob.x_init
+    for k in range(N):
+        A, B = AB[k]
+        r = slice((k + 1) * nx, (k + 2) * nx)
+        Jc[r, (k + 1) * nx:(k + 2) * nx] = np.eye(nx)
+        Jc[r, k * nx:(k + 1) * nx] = -A
+        Jc[r, offU + k * nu:offU + (k + 1) * nu] = -B
+        rc[r] = -c[k]
+    KKT = np.block([[H, Jc.T], [Jc, np.zeros((neq, neq))]])
+    sol = np.linalg.solve(KKT, -np.concatenate([g, rc]))
+    dw = sol[:nvar]; lamd = sol[nvar:].reshape(N + 1, nx)
+    dXd, dUd, dsd = nlp.unpack(p, dw)
+    print("   dense-check: dX %.2e dU %.2e ds %.2e lam %.2e  (|dU| %.2e, |lam| %.2e)" % (
+        np.abs(dXd - dX).max(), np.abs(dUd - dU).max(), np.abs(dsd - ds).max(),
+        np.abs(lamd[1:] - lam_new[1:]).max(), np.abs(dUd).max(), np.abs(lamd).max()))
