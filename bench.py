@@ -1,0 +1,198 @@
+"""MPC solves/sec, whole-body N=20, batch 8192 (BASELINE.json metric) on 1/2/4/8 MI355X.
+
+One "step" = one pass of the hot path (MPCWholeBody.solve for every instance of the batch,
+controllers/mpc_wholebody_qref.py:287-331) over a fixed synthetic batch whose inputs are already
+resident in HBM.  N ranks: the global batch is sharded contiguously over ranks (no data-path
+collective), followed by the one all-gather of the solved trajectories the metric's config names.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+_ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, _ROOT)
+
+FP64_PEAK_TFLOPS = 78.6      # MI355X FP64 vector = FP64 matrix peak (spec), SURVEY §7
+HBM_PEAK_GBS = 8000.0
+
+
+def riccati_flops_per_iter(N, nx, nu, M, nself):
+    """Algorithmic flops of ONE interior-point iteration of the stage-wise (Riccati) KKT
+    factorisation, dense-block convention: per stage
+    P[A B] 2nx^2(nx+nu) + [A B]^T(.) 2(nx+nu)^2 nx + chol nu^3/3 + solves 2nu^2(nx+1) + P update 2nx^2 nu,
+    plus ~ (60 M + 250 nself + 8 (nx+nu)) per stage for row evaluation / barrier terms, twice
+    (direction + one line-search trial)."""
+    nv = nx + nu
+    ric = 2 * nx * nx * nv + 2 * nv * nv * nx + nu ** 3 / 3.0 + 2 * nu * nu * (nx + 1) + 2 * nx * nx * nu
+    rows = 2 * (60 * M + 250 * nself + 8 * nv)
+    return N * ric + (N + 1) * rows
+
+
+def algorithmic_bytes_per_solve(N, nx, nu, M):
+    """compulsory fp64 read-once/write-once traffic per solve."""
+    return 8 * (nx + nx * (N + 1) + nu * N + nu * N + 3 * M) + 8 * (nx * (N + 1) + nu * N + (N + 1))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8192, help="GLOBAL batch (BASELINE metric: 8192)")
+    ap.add_argument("--horizon", type=int, default=20)
+    ap.add_argument("--obstacles", type=int, default=5)
+    ap.add_argument("--cpu-sample", type=int, default=2048, help="instances timed on the host cores (rank 0, N=1)")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import mmpc_loader
+    mm = mmpc_loader.load()
+    from oracle import synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    N, M, Bg = args.horizon, args.obstacles, args.batch
+    nx, nu = 9, 5
+    lo = rank * Bg // world
+    hi = (rank + 1) * Bg // world
+    Bl = hi - lo
+    # identical seeded inputs on every rank; each rank keeps its contiguous slice
+    d = synth.make_batch(Bg, N=N, M=M)
+    robot = mm.MobileManipulator(0.1)
+    ctrl = mm.MPCWholeBody(robot, [], [], N=N, max_batch=Bl, device=local_rank, n_obstacles=M)
+    eng = ctrl._engine
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a[lo:hi])).to(dev)
+    x_init = t(np.clip(d["x_init"], ctrl.xlim[0], ctrl.xlim[1]))
+    traj, uref, obs = t(d["traj_ref"]), t(d["u_ref"]), t(d["obs"])
+    ulast = torch.zeros((Bl, N, nu), dtype=torch.float64, device=dev)   # cold start: u_latest = 0 (:298-299)
+    out = eng.solve_batch_device(x_init, traj, uref, ulast, obs)
+    gathered = None
+    if world > 1:
+        rec = 310 if (N, nx, nu) == (20, 9, 5) else (N + 1) * nx + N * nu + N + 1
+        packed = torch.empty((Bl, rec), dtype=torch.float64, device=dev)
+        gathered = torch.empty((Bg, rec), dtype=torch.float64, device=dev)
+
+    def step():
+        eng.solve_batch_device(x_init, traj, uref, ulast, obs, out=out)
+        if world > 1:
+            # the one collective of the path: all-gather of the solved (X,U,s) over xGMI (RCCL)
+            packed[:, :(N + 1) * nx] = out["X"].reshape(Bl, -1)
+            packed[:, (N + 1) * nx:(N + 1) * nx + N * nu] = out["U"].reshape(Bl, -1)
+            packed[:, (N + 1) * nx + N * nu:] = out["s"]
+            dist.all_gather_into_tensor(gathered, packed)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    kernel_ms = 0.0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ev0.record()
+        eng.solve_batch_device(x_init, traj, uref, ulast, obs, out=out)
+        ev1.record()
+        if world > 1:
+            packed[:, :(N + 1) * nx] = out["X"].reshape(Bl, -1)
+            packed[:, (N + 1) * nx:(N + 1) * nx + N * nu] = out["U"].reshape(Bl, -1)
+            packed[:, (N + 1) * nx + N * nu:] = out["s"]
+            dist.all_gather_into_tensor(gathered, packed)
+        ev1.synchronize()
+        kernel_ms += ev0.elapsed_time(ev1)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+    status = out["status"].cpu().numpy()
+    iters = out["iters"].cpu().numpy()
+    err = out["err"].cpu().numpy()
+    stats = torch.tensor([float((status == 0).sum()), float(iters.sum()), float(iters.max()), float(err.max())],
+                         dtype=torch.float64, device=dev)
+    if world > 1:
+        parts = [torch.zeros_like(stats) for _ in range(world)]
+        dist.all_gather(parts, stats)
+        n_conv = sum(float(p[0]) for p in parts); it_sum = sum(float(p[1]) for p in parts)
+        it_max = max(float(p[2]) for p in parts); err_max = max(float(p[3]) for p in parts)
+    else:
+        n_conv, it_sum, it_max, err_max = [float(v) for v in stats.tolist()]
+
+    if rank == 0:
+        ms_per_step = el / args.steps * 1e3
+        value = Bg * args.steps / el
+        mean_iters = it_sum / Bg
+        k_ms = kernel_ms / args.steps                      # this rank's solve kernel, HIP events on its stream
+        fl = riccati_flops_per_iter(N, nx, nu, M, 4) * mean_iters * Bl
+        achieved_tf = fl / (k_ms * 1e-3) / 1e12
+        by = algorithmic_bytes_per_solve(N, nx, nu, M) * Bl
+        res = {
+            "metric": "MPC solves/sec, whole-body N=%d batch=%d" % (N, Bg),
+            "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "whole-body MPC solve, N=%d, M=%d static circle obstacles, global batch %d, "
+                                   "cold start (u_latest=0), seeded synthetic (x_init, traj_ref, obstacles)" % (N, M, Bg),
+                       "batch_per_gpu": Bl, "parallelism": "batch-sharded x%d%s" % (world, " + all-gather(X,U,s)" if world > 1 else "")},
+            "solver": {"converged_frac": n_conv / Bg, "mean_iters": mean_iters, "max_iters": it_max,
+                       "max_scaled_kkt": err_max, "lds_bytes_per_problem": eng.lds_bytes},
+            "roofline": {"bound": "mfma", "kernel": "mmpc_solve_kernel<0>", "achieved": achieved_tf,
+                         "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tf / FP64_PEAK_TFLOPS,
+                         "traffic": None, "kernel_ms": k_ms,
+                         "flops_per_iter": riccati_flops_per_iter(N, nx, nu, M, 4),
+                         "hbm_achieved_GBs": by / (k_ms * 1e-3) / 1e9, "hbm_frac": by / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+        }
+        if world == 1 and not args.no_cpu:
+            from oracle import coracle, nlp
+            cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            ns = min(args.cpu_sample, Bg)
+            par = nlp.WholeBodyParams(N=N)
+            xi = np.clip(d["x_init"][:ns], par.xlim[0], par.xlim[1])
+            coracle.lib()
+            c0 = time.perf_counter()
+            o = coracle.solve_batch(par, xi, d["traj_ref"][:ns], d["u_ref"][:ns], np.zeros((ns, N, nu)), d["obs"][:ns],
+                                    nthreads=cores)
+            ct = time.perf_counter() - c0
+            gX = out["X"][:ns].cpu().numpy()
+            res["cpu_baseline"] = {"value": ns / ct, "unit": "solves/s", "cores": cores, "kind": "port",
+                                   "sample": "first %d instances of the same batch, oracle/mmpc_oracle.c (OpenMP), %.1f s" % (ns, ct),
+                                   "max_abs_dX_vs_gpu": float(np.abs(gX - o["X"]).max()),
+                                   "casadi": "CasADi/IPOPT baseline unavailable on this host" if not _has_casadi() else "importable"}
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def _has_casadi():
+    try:
+        import casadi  # noqa: F401
+        return True
+    except Exception:
+        return False
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,106 @@
+/*
+ * mmpc.h - C ABI of the MI355X batched MPC solve engine (libmmpc.so).
+ *
+ * The reference (HsinyuG/mobile-manipulator-mpc) is pure Python: its hot path has no FFI.  The
+ * boundary this library replaces is the Python controller object the closed-loop driver calls
+ * (interface_wholebody_qref.py:134  `self.controller.solve(current_state, local_traj_ref,
+ * local_u_ref)`), i.e. the public surface of controllers/mpc_wholebody_qref.py:6-331 and
+ * controllers/mpc_base.py:6-226.  Each entry point below names the reference interface it
+ * stands in for.  Plain pointers and sizes only; nothing throws across the ABI; every function
+ * returns 0 on success or a negative MMPC_E_* code (text via mmpc_last_error()).
+ *
+ * Array conventions are the reference's: float64, C order, one record per problem instance:
+ *   x_init[B][nx]  traj_ref[B][N+1][nx]  u_ref[B][N][nu]  obs[B][M][3] = (x, y, radius)
+ *   (or obs[B][N+1][M][3] when cfg.obs_per_stage: per-stage centres for moving obstacles)
+ *   X[B][N+1][nx]  U[B][N][nu]  s[B][N+1]
+ * whole-body kind: nx=9 [x,y,psi,dx,dy,dpsi,q1,q2,q3], nu=5 [dV,dw,dq1,dq2,dq3]
+ * (robot_models/mobile_manipulator.py:22,62-65); base kind: nx=6, nu=2 (robot_models/base.py:26).
+ */
+#ifndef MMPC_H
+#define MMPC_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMPC_KIND_WHOLEBODY 0 /* controllers/mpc_wholebody_qref.py:MPCWholeBody */
+#define MMPC_KIND_BASE 1      /* controllers/mpc_base.py:MPCBase */
+
+#define MMPC_OK 0
+#define MMPC_E_ARG (-1)         /* bad argument / unsupported size */
+#define MMPC_E_HIP (-2)         /* HIP runtime error */
+#define MMPC_E_NODEVICE (-3)    /* no gfx950 device visible */
+#define MMPC_E_UNSUPPORTED (-4) /* feature not implemented */
+
+/* per-instance solver status written to status[B] */
+#define MMPC_STATUS_CONVERGED 0 /* scaled KKT error <= tol */
+#define MMPC_STATUS_MAXITER 1
+#define MMPC_STATUS_NUMERIC 2   /* NaN / non-PD even with the Gauss-Newton Hessian */
+
+/* Build-time structure of the NLP = constructor arguments of MPCWholeBody.__init__
+ * (mpc_wholebody_qref.py:7-23: N, ulim, xlim, dulim, robot.dt) / MPCBase.__init__
+ * (mpc_base.py:7-17).  +-INFINITY marks an absent bound (the reference uses ca.inf). */
+typedef struct mmpc_config {
+    int kind;          /* MMPC_KIND_* */
+    int N;             /* horizon, 1 <= N <= 63 */
+    int M;             /* circle obstacles per instance, 0 <= M <= 16 (len(obstacle_list)) */
+    int obs_per_stage; /* 0: obs[B][M][3]; 1: obs[B][N+1][M][3] */
+    int max_batch;     /* capacity of the device-side warm-start buffers */
+    int device;        /* HIP device ordinal */
+    int max_iter;      /* interior-point iteration cap (reference passes ipopt.max_iter 2000, :280) */
+    double dt;         /* robot.dt (demo_wholebody_qref.py:10) */
+    double tol;        /* scaled KKT tolerance (ipopt tol / acceptable_tol 1e-8, :283) */
+    double mu_init;    /* initial barrier parameter */
+    double ulim[2][5]; /* [lo|hi][nu] */
+    double xlim[2][9]; /* [lo|hi][nx]; psi entry +-INFINITY (mpc_base.py:16 stores 5 columns) */
+    double dulim[2][5];
+} mmpc_config;
+
+typedef struct mmpc_handle_s *mmpc_handle;
+
+/* MPCWholeBody.__init__ / MPCBase.__init__ + reset() (mpc_wholebody_qref.py:25-46,142-285):
+ * allocates device state, uploads the structure.  Weights start at the reference defaults
+ * (:12-16 / mpc_base.py:11-14). */
+int mmpc_create(const mmpc_config *cfg, mmpc_handle *out);
+int mmpc_destroy(mmpc_handle h);
+
+/* setWeight(Q,R,P,S,W) (mpc_wholebody_qref.py:119-139; mpc_base.py:96-112 where S is `M`):
+ * row-major nx*nx / nu*nu matrices; a NULL pointer keeps the current value; S<0 keeps S. */
+int mmpc_set_weights(mmpc_handle h, const double *Q, const double *R, const double *P, double S, const double *W);
+
+/* The hard terminal equality the driver injects through controller.opti
+ * (interface_wholebody_qref.py:166-167: X[N,:2] == X_ref[N,:2]). */
+int mmpc_set_terminal_xy_equality(mmpc_handle h, int on);
+
+/* reset(): clears the warm start (u_latest / x_guess = None, mpc_wholebody_qref.py:164-165). */
+int mmpc_reset(mmpc_handle h);
+
+/* solve(x_init, traj_ref, u_ref) for B instances (mpc_wholebody_qref.py:287-331, mpc_base.py:191-226).
+ * Host pointers.  Uses and then replaces the handle's warm start (u_latest, and x_guess for the base
+ * kind) for instances 0..B-1.  x_init of the whole-body kind is clipped to xlim (:290-291) inside.
+ * Any out_* may be NULL except out_u0.  out_u0[B][nu] = U*[0] (the reference's return value). */
+int mmpc_solve_batch(mmpc_handle h, int B, const double *x_init, const double *traj_ref, const double *u_ref,
+                     const double *obs, double *out_u0, double *out_X, double *out_U, double *out_s, int *out_status,
+                     int *out_iters, double *out_cost);
+
+/* Same solve on DEVICE pointers (inputs already resident in HBM), asynchronous on `stream`
+ * (a hipStream_t, passed as void*; NULL = default stream).  Stateless: u_last is the explicit
+ * U_last parameter / U initial guess (:303,:310), x_guess the X initial guess for the base kind
+ * (mpc_base.py:200; NULL = tile(x_init), :302).  status/iters are int32 arrays, cost/err float64. */
+int mmpc_solve_batch_device(mmpc_handle h, int B, const double *d_x_init, const double *d_traj_ref,
+                            const double *d_u_ref, const double *d_u_last, const double *d_x_guess,
+                            const double *d_obs, double *d_X, double *d_U, double *d_s, int *d_status, int *d_iters,
+                            double *d_cost, double *d_err, void *stream);
+
+/* warm start access (self.u_latest, mpc_wholebody_qref.py:165,330): host <-> device copies */
+int mmpc_get_u_latest(mmpc_handle h, int B, double *u_latest);
+int mmpc_set_u_latest(mmpc_handle h, int B, const double *u_latest);
+
+/* bytes of LDS one problem instance occupies (one 64-lane workgroup) */
+int mmpc_lds_bytes(mmpc_handle h);
+const char *mmpc_last_error(mmpc_handle h);
+const char *mmpc_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

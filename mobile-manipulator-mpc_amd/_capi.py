@@ -1,0 +1,187 @@
+"""ctypes binding of the C ABI in include/mmpc.h (csrc/libmmpc.so).  No fallback of any kind:
+a missing library or a failing call raises."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmmpc.so")
+
+KIND_WHOLEBODY, KIND_BASE = 0, 1
+STATUS_CONVERGED, STATUS_MAXITER, STATUS_NUMERIC = 0, 1, 2
+
+
+class MmpcConfig(C.Structure):
+    _fields_ = [("kind", C.c_int), ("N", C.c_int), ("M", C.c_int), ("obs_per_stage", C.c_int),
+                ("max_batch", C.c_int), ("device", C.c_int), ("max_iter", C.c_int),
+                ("dt", C.c_double), ("tol", C.c_double), ("mu_init", C.c_double),
+                ("ulim", (C.c_double * 5) * 2), ("xlim", (C.c_double * 9) * 2), ("dulim", (C.c_double * 5) * 2)]
+
+
+EXPORTS = ["mmpc_create", "mmpc_destroy", "mmpc_set_weights", "mmpc_set_terminal_xy_equality", "mmpc_reset",
+           "mmpc_solve_batch", "mmpc_solve_batch_device", "mmpc_get_u_latest", "mmpc_set_u_latest",
+           "mmpc_lds_bytes", "mmpc_last_error", "mmpc_version"]
+
+_lib = None
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+
+def lib():
+    """Loads libmmpc.so; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "HIP extension %s is missing - build it with __graft_entry__.build() "
+                "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.mmpc_create.argtypes = [C.POINTER(MmpcConfig), C.POINTER(C.c_void_p)]
+        L.mmpc_destroy.argtypes = [C.c_void_p]
+        L.mmpc_set_weights.argtypes = [C.c_void_p, _dp, _dp, _dp, C.c_double, _dp]
+        L.mmpc_set_terminal_xy_equality.argtypes = [C.c_void_p, C.c_int]
+        L.mmpc_reset.argtypes = [C.c_void_p]
+        L.mmpc_solve_batch.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _ip, _ip, _dp]
+        L.mmpc_solve_batch_device.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 13 + [C.c_void_p]
+        L.mmpc_get_u_latest.argtypes = [C.c_void_p, C.c_int, _dp]
+        L.mmpc_set_u_latest.argtypes = [C.c_void_p, C.c_int, _dp]
+        L.mmpc_lds_bytes.argtypes = [C.c_void_p]
+        L.mmpc_last_error.argtypes = [C.c_void_p]
+        L.mmpc_last_error.restype = C.c_char_p
+        L.mmpc_version.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp) if a is not None else None
+
+
+def _i(a):
+    return a.ctypes.data_as(_ip) if a is not None else None
+
+
+class Engine:
+    """Owns one mmpc_handle (one controller's NLP structure on one GPU)."""
+
+    def __init__(self, kind, N, M, dt, ulim, xlim, dulim, max_batch=1, device=0, obs_per_stage=False,
+                 tol=1e-8, mu_init=1.0, max_iter=200):
+        self.kind, self.N, self.M = kind, int(N), int(M)
+        self.nx, self.nu = (9, 5) if kind == KIND_WHOLEBODY else (6, 2)
+        self.max_batch, self.device, self.obs_per_stage = int(max_batch), int(device), bool(obs_per_stage)
+        cfg = MmpcConfig()
+        cfg.kind, cfg.N, cfg.M, cfg.obs_per_stage = kind, self.N, self.M, int(self.obs_per_stage)
+        cfg.max_batch, cfg.device, cfg.max_iter = self.max_batch, self.device, int(max_iter)
+        cfg.dt, cfg.tol, cfg.mu_init = float(dt), float(tol), float(mu_init)
+        ulim = np.asarray(ulim, float); xlim = np.asarray(xlim, float); dulim = np.asarray(dulim, float)
+        for r in range(2):
+            for j in range(5):
+                cfg.ulim[r][j] = ulim[r, j] if j < self.nu else 0.0
+                cfg.dulim[r][j] = dulim[r, j] if j < self.nu else 0.0
+            for j in range(9):
+                cfg.xlim[r][j] = xlim[r, j] if j < self.nx else 0.0
+        self._h = C.c_void_p()
+        rc = lib().mmpc_create(C.byref(cfg), C.byref(self._h))
+        if rc != 0:
+            msg = lib().mmpc_last_error(self._h).decode() if self._h else ""
+            if self._h:
+                lib().mmpc_destroy(self._h)
+                self._h = C.c_void_p()
+            raise RuntimeError("mmpc_create failed (%d) %s" % (rc, msg))
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("%s failed (%d): %s" % (what, rc, lib().mmpc_last_error(self._h).decode()))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().mmpc_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def lds_bytes(self):
+        return lib().mmpc_lds_bytes(self._h)
+
+    def set_weights(self, Q=None, R=None, P=None, S=None, W=None):
+        def m(a, n):
+            if a is None:
+                return None
+            a = np.ascontiguousarray(a, float)
+            if a.shape != (n, n):
+                raise ValueError("weight matrix must be %dx%d" % (n, n))
+            return a
+        Q, P, R, W = m(Q, self.nx), m(P, self.nx), m(R, self.nu), m(W, self.nu)
+        Sv = -1.0 if S is None else float(np.ravel(S)[0])
+        self._chk(lib().mmpc_set_weights(self._h, _d(Q), _d(R), _d(P), Sv, _d(W)), "mmpc_set_weights")
+
+    def set_terminal_xy_equality(self, on):
+        self._chk(lib().mmpc_set_terminal_xy_equality(self._h, int(bool(on))), "mmpc_set_terminal_xy_equality")
+
+    def reset(self):
+        self._chk(lib().mmpc_reset(self._h), "mmpc_reset")
+
+    def obs_shape(self, B):
+        return (B, self.N + 1, self.M, 3) if self.obs_per_stage else (B, self.M, 3)
+
+    def solve_batch(self, x_init, traj_ref, u_ref, obs):
+        """Host arrays in, host arrays out (dict).  Updates the handle's warm start."""
+        N, nx, nu = self.N, self.nx, self.nu
+        x_init = np.ascontiguousarray(x_init, float)
+        B = x_init.shape[0]
+        traj_ref = np.ascontiguousarray(traj_ref, float)
+        u_ref = np.ascontiguousarray(u_ref, float)
+        obs = np.ascontiguousarray(obs, float)
+        if x_init.shape != (B, nx) or traj_ref.shape != (B, N + 1, nx) or u_ref.shape != (B, N, nu):
+            raise ValueError("shape mismatch: x_init %s traj_ref %s u_ref %s" % (x_init.shape, traj_ref.shape, u_ref.shape))
+        if obs.shape != self.obs_shape(B):
+            raise ValueError("obs shape %s, expected %s" % (obs.shape, self.obs_shape(B)))
+        out = dict(u0=np.empty((B, nu)), X=np.empty((B, N + 1, nx)), U=np.empty((B, N, nu)), s=np.empty((B, N + 1)),
+                   status=np.empty(B, np.int32), iters=np.empty(B, np.int32), cost=np.empty(B))
+        self._chk(lib().mmpc_solve_batch(self._h, B, _d(x_init), _d(traj_ref), _d(u_ref), _d(obs), _d(out["u0"]),
+                                         _d(out["X"]), _d(out["U"]), _d(out["s"]), _i(out["status"]),
+                                         _i(out["iters"]), _d(out["cost"])), "mmpc_solve_batch")
+        return out
+
+    def get_u_latest(self, B):
+        a = np.empty((B, self.N, self.nu))
+        self._chk(lib().mmpc_get_u_latest(self._h, B, _d(a)), "mmpc_get_u_latest")
+        return a
+
+    def set_u_latest(self, u):
+        u = np.ascontiguousarray(u, float)
+        self._chk(lib().mmpc_set_u_latest(self._h, u.shape[0], _d(u)), "mmpc_set_u_latest")
+
+    def solve_batch_device(self, x_init, traj_ref, u_ref, u_last, obs, x_guess=None, out=None, stream=None):
+        """torch CUDA float64 tensors in / out, asynchronous on torch's current stream (or `stream`).
+        PyTorch is only the owner of the device memory and of the stream here."""
+        import torch
+        N, nx, nu = self.N, self.nx, self.nu
+        B = x_init.shape[0]
+        for t_, shp in ((x_init, (B, nx)), (traj_ref, (B, N + 1, nx)), (u_ref, (B, N, nu)), (u_last, (B, N, nu))):
+            if tuple(t_.shape) != shp or t_.dtype != torch.float64 or not t_.is_cuda or not t_.is_contiguous():
+                raise ValueError("device tensor must be contiguous cuda float64 of shape %s" % (shp,))
+        if tuple(obs.shape) != self.obs_shape(B) or obs.dtype != torch.float64 or not obs.is_contiguous():
+            raise ValueError("obs must be contiguous cuda float64 of shape %s" % (self.obs_shape(B),))
+        dev = x_init.device
+        if out is None:
+            out = dict(X=torch.empty((B, N + 1, nx), dtype=torch.float64, device=dev),
+                       U=torch.empty((B, N, nu), dtype=torch.float64, device=dev),
+                       s=torch.empty((B, N + 1), dtype=torch.float64, device=dev),
+                       status=torch.empty(B, dtype=torch.int32, device=dev),
+                       iters=torch.empty(B, dtype=torch.int32, device=dev),
+                       cost=torch.empty(B, dtype=torch.float64, device=dev),
+                       err=torch.empty(B, dtype=torch.float64, device=dev))
+        st = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
+        p = lambda t_: C.c_void_p(t_.data_ptr()) if t_ is not None else None
+        self._chk(lib().mmpc_solve_batch_device(self._h, B, p(x_init), p(traj_ref), p(u_ref), p(u_last), p(x_guess),
+                                                p(obs), p(out["X"]), p(out["U"]), p(out["s"]), p(out["status"]),
+                                                p(out["iters"]), p(out["cost"]), p(out["err"]), C.c_void_p(st)),
+                  "mmpc_solve_batch_device")
+        return out

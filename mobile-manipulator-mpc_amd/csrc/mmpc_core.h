@@ -1,0 +1,985 @@
+// mmpc_core.h - one-wavefront-per-problem interior-point MPC solver (gfx950).
+//
+// Replaces, for a batch of independent problem instances, what the reference does in
+// MPCWholeBody.solve() / MPCBase.solve() (controllers/mpc_wholebody_qref.py:287-331,
+// controllers/mpc_base.py:191-226): solve the multiple-shooting NLP that reset() builds
+// (mpc_wholebody_qref.py:142-285, mpc_base.py:114-189) from the initial point
+// X = tile(x_init) (or the previous X for the base kind), U = u_latest, s = 0.
+// The reference delegates to CasADi -> IPOPT -> MUMPS; this is a direct primal-dual
+// interior-point loop whose KKT system is factorised stage by stage (Riccati recursion).
+//
+// Execution model: ONE 64-lane wavefront (= one workgroup) owns one problem.  All solver
+// state lives in that workgroup's LDS slab.  The code is a sequence of PHASES: inside a
+// phase every lane works on its own slice (a stage, a matrix entry, a column) and reads
+// only data produced by earlier phases; phases are separated by a workgroup barrier.
+// No lane-private value crosses a phase boundary except wave-uniform scalars that every
+// lane computes identically.  That discipline lets the very same source be compiled
+//   (a) by hipcc for gfx950 (MMPC_EMU undefined): LANES_BEGIN/END = "this lane" + barrier
+//   (b) by g++ with -DMMPC_EMU: LANES_BEGIN/END = a loop over the 64 lanes
+// (b) exists only so that tests can run the kernel logic under ASAN/UBSAN on the CPU before
+// it is launched on a GPU; it is never part of the product library.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#ifdef MMPC_EMU
+#define MMPC_DEV inline
+#define MMPC_HD inline
+#define MMPC_CONST static const
+#define LANES_BEGIN for (int lane = emu.first; lane != emu.end; lane += emu.step) {
+#define LANES_END }
+struct MmpcEmu { int first, end, step; };
+#define MMPC_EMU_ARG , MmpcEmu emu
+#else
+#define MMPC_DEV __device__ __forceinline__
+#define MMPC_HD __host__ __device__ inline
+#define MMPC_CONST __device__ __constant__ static const
+#define LANES_BEGIN { const int lane = (int)threadIdx.x;
+#define LANES_END } __syncthreads();
+#define MMPC_EMU_ARG
+#endif
+
+#define MMPC_WAVE 64
+#define MMPC_FCAP 16
+#define MMPC_MAX_LS 20
+
+// Per-launch constants (device memory, read through the scalar cache).
+struct MmpcParams {
+    int N, M, obs_per_stage, max_iter, use_xguess, terminal_xy_eq;
+    double dt, tol, mu_init, S;
+    double Q2[81], P2[81];   // Q+Q^T, P+P^T (row-major, leading dimension NX)
+    double RW2[25];          // (R+R^T)+(W+W^T), leading dimension NU
+    double R2[25], W2[25];   // R+R^T, W+W^T
+    double ulim[2][5], xlim[2][9], dulim[2][5];
+};
+
+// robot_models/manipulator_3DoF.py:18-22, mobile_manipulator.py:14-15, base.py:15,
+// mpc_wholebody_qref.py:43
+#define MMPC_A2 0.316
+#define MMPC_A3 0.0825
+#define MMPC_A5 0.384
+#define MMPC_A6 0.088
+#define MMPC_A7 0.107
+#define MMPC_BX (-0.007)
+#define MMPC_BZ (0.606 + 0.333)
+#define MMPC_BASE_R 0.4
+#define MMPC_SELF_R 0.05
+
+// ---- structure of [A B] = d f / d(x,u) for the diff-drive base (+ integrator arm) -----------
+// robot_models/base.py:19-26, manipulator_3DoF.py:190.  Every column has at most 4 non-zeros.
+// Coefficient ids index the per-stage vector CV[k][11]:
+//   0:0  1:1  2:dt  3:a32=-dt*u0*sin  4:a42=dt*u0*cos  5:a43=dt*dpsi  6:a34=-dt*dpsi
+//   7:a35=-dt*dy  8:a45=dt*dx  9:dt*cos  10:dt*sin
+#define MMPC_NCV 11
+MMPC_CONST unsigned char kColRowWB[14][4] = {
+    {0, 0, 0, 0}, {1, 0, 0, 0}, {2, 3, 4, 0}, {3, 0, 4, 0}, {4, 1, 3, 0}, {5, 2, 3, 4}, {6, 0, 0, 0},
+    {7, 0, 0, 0}, {8, 0, 0, 0}, {3, 4, 0, 0}, {5, 0, 0, 0}, {6, 0, 0, 0}, {7, 0, 0, 0}, {8, 0, 0, 0}};
+MMPC_CONST unsigned char kColCvWB[14][4] = {
+    {1, 0, 0, 0}, {1, 0, 0, 0}, {1, 3, 4, 0}, {1, 2, 5, 0}, {1, 2, 6, 0}, {1, 2, 7, 8}, {1, 0, 0, 0},
+    {1, 0, 0, 0}, {1, 0, 0, 0}, {9, 10, 0, 0}, {2, 0, 0, 0}, {2, 0, 0, 0}, {2, 0, 0, 0}, {2, 0, 0, 0}};
+MMPC_CONST unsigned char kColRowB[8][4] = {
+    {0, 0, 0, 0}, {1, 0, 0, 0}, {2, 3, 4, 0}, {3, 0, 4, 0}, {4, 1, 3, 0}, {5, 2, 3, 4}, {3, 4, 0, 0}, {5, 0, 0, 0}};
+MMPC_CONST unsigned char kColCvB[8][4] = {
+    {1, 0, 0, 0}, {1, 0, 0, 0}, {1, 3, 4, 0}, {1, 2, 5, 0}, {1, 2, 6, 0}, {1, 2, 7, 8}, {9, 10, 0, 0}, {2, 0, 0, 0}};
+// rows of [A B] (forward roll-out): column index into [dx;du] and coefficient id, <= 5 terms
+MMPC_CONST unsigned char kRowColWB[9][5] = {
+    {0, 3, 0, 0, 0}, {1, 4, 0, 0, 0}, {2, 5, 0, 0, 0}, {3, 2, 4, 5, 9}, {4, 2, 3, 5, 9}, {5, 10, 0, 0, 0},
+    {6, 11, 0, 0, 0}, {7, 12, 0, 0, 0}, {8, 13, 0, 0, 0}};
+MMPC_CONST unsigned char kRowCvWB[9][5] = {
+    {1, 2, 0, 0, 0}, {1, 2, 0, 0, 0}, {1, 2, 0, 0, 0}, {1, 3, 6, 7, 9}, {1, 4, 5, 8, 10}, {1, 2, 0, 0, 0},
+    {1, 2, 0, 0, 0}, {1, 2, 0, 0, 0}, {1, 2, 0, 0, 0}};
+MMPC_CONST unsigned char kRowColB[6][5] = {
+    {0, 3, 0, 0, 0}, {1, 4, 0, 0, 0}, {2, 5, 0, 0, 0}, {3, 2, 4, 5, 6}, {4, 2, 3, 5, 6}, {5, 7, 0, 0, 0}};
+MMPC_CONST unsigned char kRowCvB[6][5] = {
+    {1, 2, 0, 0, 0}, {1, 2, 0, 0, 0}, {1, 2, 0, 0, 0}, {1, 3, 6, 7, 9}, {1, 4, 5, 8, 10}, {1, 2, 0, 0, 0}};
+// packed lower-triangular index e -> (i,j), i>=j  (e = i(i+1)/2 + j), up to 9x9
+MMPC_CONST unsigned char kTriI[45] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 4, 5, 5, 5, 5, 5, 5, 6, 6,
+                                      6, 6, 6, 6, 6, 7, 7, 7, 7, 7, 7, 7, 7, 8, 8, 8, 8, 8, 8, 8, 8, 8};
+MMPC_CONST unsigned char kTriJ[45] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3, 0, 1, 2, 3, 4, 0, 1, 2, 3, 4, 5, 0, 1,
+                                      2, 3, 4, 5, 6, 0, 1, 2, 3, 4, 5, 6, 7, 0, 1, 2, 3, 4, 5, 6, 7, 8};
+// self-collision check points p_i = alpha j2 + beta j3 (mpc_wholebody_qref.py:219)
+MMPC_CONST double kSelfAB[4][2] = {{0.0, 0.0}, {0.5, 0.0}, {1.0, 0.0}, {0.5, 0.5}};
+// state entries the forward kinematics depends on: x, y, psi, q1, q2, q3
+MMPC_CONST unsigned char kY[6] = {0, 1, 2, 6, 7, 8};
+
+template <int KIND>
+struct MmpcDims {
+    static constexpr int NX = KIND == 0 ? 9 : 6;
+    static constexpr int NU = KIND == 0 ? 5 : 2;
+    static constexpr int NSELF = KIND == 0 ? 4 : 0;
+    static constexpr int NV = NX + NU;
+    static constexpr int NXX = NX * (NX + 1) / 2;
+    static constexpr int NUU = NU * (NU + 1) / 2;
+};
+
+// LDS slab layout (offsets in doubles).  Shared by host (size query) and device.
+struct MmpcLayout {
+    int X, U, S, LAM, XREF, UREF, ULAST, OBS, T, Z, HR, DTR, GC, HC, GSF, CV, CD, GX, GU, HXX, QX, HUXL, HUUL,
+        HUX02, HUUD, QU, HSS, GSS, VX, VXN, KK, KF, DX, DU, DS, DLAM, PF, TT, PC, MF, MG, MH, MGX, MGU, RED, FILT,
+        MISC, total;
+    int R, NR;
+};
+
+template <int KIND>
+MMPC_HD MmpcLayout mmpc_layout(int N, int M, int obs_per_stage) {
+    typedef MmpcDims<KIND> D;
+    MmpcLayout L;
+    int o = 0;
+    const int NS = N + 1;
+    L.R = 2 * D::NU + 2 * D::NX + M + D::NSELF;
+    L.NR = M + D::NSELF;
+#define MMPC_CARVE(name, n) L.name = o; o += (n); o = (o + 1) & ~1;
+    MMPC_CARVE(X, NS * D::NX) MMPC_CARVE(U, N * D::NU) MMPC_CARVE(S, NS) MMPC_CARVE(LAM, NS * D::NX)
+    MMPC_CARVE(XREF, NS * D::NX) MMPC_CARVE(UREF, N * D::NU) MMPC_CARVE(ULAST, N * D::NU)
+    MMPC_CARVE(OBS, (obs_per_stage ? NS : 1) * M * 3)
+    MMPC_CARVE(T, NS * L.R) MMPC_CARVE(Z, NS * L.R) MMPC_CARVE(HR, NS * L.NR) MMPC_CARVE(DTR, NS * L.NR)
+    MMPC_CARVE(GC, NS * M * 2) MMPC_CARVE(HC, NS * M * 3) MMPC_CARVE(GSF, NS * D::NSELF * 6)
+    MMPC_CARVE(CV, NS * MMPC_NCV) MMPC_CARVE(CD, NS * D::NX) MMPC_CARVE(GX, NS * D::NX) MMPC_CARVE(GU, NS * D::NU)
+    MMPC_CARVE(HXX, NS * D::NXX) MMPC_CARVE(QX, NS * D::NX) MMPC_CARVE(HUXL, D::NU * D::NX) MMPC_CARVE(HUUL, D::NUU)
+    MMPC_CARVE(HUX02, NS) MMPC_CARVE(HUUD, NS * D::NU) MMPC_CARVE(QU, NS * D::NU) MMPC_CARVE(HSS, NS)
+    MMPC_CARVE(GSS, NS) MMPC_CARVE(VX, NS * 6) MMPC_CARVE(VXN, 6 + D::NX + D::NU)
+    MMPC_CARVE(KK, N * D::NU * D::NX) MMPC_CARVE(KF, N * D::NU)
+    MMPC_CARVE(DX, NS * D::NX) MMPC_CARVE(DU, NS * D::NU) MMPC_CARVE(DS, NS) MMPC_CARVE(DLAM, NS * D::NX)
+    MMPC_CARVE(PF, D::NX * D::NX) MMPC_CARVE(TT, D::NX * D::NV) MMPC_CARVE(PC, D::NX) MMPC_CARVE(MF, D::NXX)
+    MMPC_CARVE(MG, D::NU * D::NX) MMPC_CARVE(MH, D::NUU) MMPC_CARVE(MGX, D::NX) MMPC_CARVE(MGU, D::NU)
+    MMPC_CARVE(RED, 8 * MMPC_WAVE) MMPC_CARVE(FILT, 2 * MMPC_FCAP) MMPC_CARVE(MISC, 8)
+#undef MMPC_CARVE
+    L.total = o;
+    return L;
+}
+
+struct MmpcIO {
+    const double *x_init, *traj_ref, *u_ref, *u_last, *x_guess, *obs;  // this problem's slices
+    double *X, *U, *s, *cost, *err;
+    int *status, *iters;
+};
+
+MMPC_DEV double mmpc_min(double a, double b) { return a < b ? a : b; }
+MMPC_DEV double mmpc_max(double a, double b) { return a > b ? a : b; }
+MMPC_DEV bool mmpc_finite(double v) { return fabs(v) < 1.0e300; }
+
+// planar arm segments, manipulator_3DoF.py:29-73 collapsed with A=q1-q2, B=q1-q2-q3
+MMPC_DEV void mmpc_arm_segments(double q1, double q2, double q3, double dr[3], double dz[3]) {
+    double s1, c1, sA, cA, sB, cB;
+    sincos(q1, &s1, &c1);
+    sincos(q1 - q2, &sA, &cA);
+    sincos(q1 - q2 - q3, &sB, &cB);
+    dr[0] = MMPC_A2 * s1 + MMPC_A3 * c1;
+    dz[0] = MMPC_A2 * c1 - MMPC_A3 * s1;
+    dr[1] = -MMPC_A3 * cA + MMPC_A5 * sA;
+    dz[1] = MMPC_A3 * sA + MMPC_A5 * cA;
+    dr[2] = MMPC_A6 * cB - MMPC_A7 * sB;
+    dz[2] = -MMPC_A6 * sB - MMPC_A7 * cB;
+}
+
+// self-collision row i (mpc_wholebody_qref.py:219-222): h = 0.05 - ||alpha j2 + beta j3 - e||
+// (world points).  g6 (may be null) = dh/d(x,y,psi,q1,q2,q3).
+MMPC_DEV double mmpc_self_row(int i, double px, double py, double c, double s, const double dr[3], const double dz[3],
+                              double *g6) {
+    const double al = kSelfAB[i][0], be = kSelfAB[i][1], kap = al + be - 1.0;
+    const double cm0 = kap, cm1 = be - 1.0, cm2 = -1.0;
+    const double R = kap * MMPC_BX + cm0 * dr[0] + cm1 * dr[1] + cm2 * dr[2];
+    const double Z = kap * MMPC_BZ + cm0 * dz[0] + cm1 * dz[1] + cm2 * dz[2];
+    const double C = px * c + py * s, Dv = -px * s + py * c;
+    const double mm = kap * kap * (px * px + py * py) + 2 * kap * R * C + R * R + Z * Z;
+    const double n = sqrt(mm);
+    if (g6) {
+        // segment m rotates with angle a_m.q, a_1=(1,0,0), a_2=(1,-1,0), a_3=(1,-1,-1)
+        const double z0 = cm0 * dz[0], z1 = cm1 * dz[1], z2 = cm2 * dz[2];
+        const double r0 = cm0 * dr[0], r1 = cm1 * dr[1], r2 = cm2 * dr[2];
+        const double Ri0 = z0 + z1 + z2, Ri1 = -z1 - z2, Ri2 = -z2;
+        const double Zi0 = -(r0 + r1 + r2), Zi1 = r1 + r2, Zi2 = r2;
+        const double inv = -1.0 / (2 * n);
+        const double f = 2 * (kap * C + R);
+        g6[0] = (2 * kap * kap * px + 2 * kap * R * c) * inv;
+        g6[1] = (2 * kap * kap * py + 2 * kap * R * s) * inv;
+        g6[2] = (2 * kap * R * Dv) * inv;
+        g6[3] = (f * Ri0 + 2 * Z * Zi0) * inv;
+        g6[4] = (f * Ri1 + 2 * Z * Zi1) * inv;
+        g6[5] = (f * Ri2 + 2 * Z * Zi2) * inv;
+    }
+    return MMPC_SELF_R - n;
+}
+
+MMPC_DEV double mmpc_angle_diff(double a, double b) {  // mpc_base.py:56-94
+    const double PI = 3.14159265358979323846;
+    a = fmod(a + PI, 2 * PI) - PI;
+    b = fmod(b + PI, 2 * PI) - PI;
+    const double d = a - b;
+    if (a * b >= 0) return d;
+    if (a > b) return d <= PI ? d : d - 2 * PI;
+    return d > -PI ? d : d + 2 * PI;
+}
+
+template <int KIND>
+struct MmpcTab;
+template <>
+struct MmpcTab<0> {
+    MMPC_DEV static int crow(int j, int q) { return kColRowWB[j][q]; }
+    MMPC_DEV static int ccv(int j, int q) { return kColCvWB[j][q]; }
+    MMPC_DEV static int rcol(int i, int q) { return kRowColWB[i][q]; }
+    MMPC_DEV static int rcv(int i, int q) { return kRowCvWB[i][q]; }
+};
+template <>
+struct MmpcTab<1> {
+    MMPC_DEV static int crow(int j, int q) { return kColRowB[j][q]; }
+    MMPC_DEV static int ccv(int j, int q) { return kColCvB[j][q]; }
+    MMPC_DEV static int rcol(int i, int q) { return kRowColB[i][q]; }
+    MMPC_DEV static int rcv(int i, int q) { return kRowCvB[i][q]; }
+};
+
+// ------------------------------------------------------------------------------------------
+// The solver.  `lds` points at this problem's slab of mmpc_layout<KIND>(N,M,..).total doubles.
+// ------------------------------------------------------------------------------------------
+template <int KIND>
+MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds MMPC_EMU_ARG) {
+    typedef MmpcDims<KIND> D;
+    typedef MmpcTab<KIND> TB;
+    constexpr int NX = D::NX, NU = D::NU, NSELF = D::NSELF, NV = D::NV, NXX = D::NXX, NUU = D::NUU;
+    const int N = P.N, M = P.M, NS = N + 1;
+    const MmpcLayout L = mmpc_layout<KIND>(N, M, P.obs_per_stage);
+    const int R = L.R, NR = L.NR;
+    double *X = lds + L.X, *U = lds + L.U, *S = lds + L.S, *LAM = lds + L.LAM, *XREF = lds + L.XREF,
+           *UREF = lds + L.UREF, *ULAST = lds + L.ULAST, *OBS = lds + L.OBS, *T = lds + L.T, *Z = lds + L.Z,
+           *HR = lds + L.HR, *DTR = lds + L.DTR, *GC = lds + L.GC, *HC = lds + L.HC, *GSF = lds + L.GSF,
+           *CV = lds + L.CV, *CD = lds + L.CD, *GX = lds + L.GX, *GU = lds + L.GU, *HXX = lds + L.HXX,
+           *QX = lds + L.QX, *HUXL = lds + L.HUXL, *HUUL = lds + L.HUUL, *HUX02 = lds + L.HUX02,
+           *HUUD = lds + L.HUUD, *QU = lds + L.QU, *HSS = lds + L.HSS, *GSS = lds + L.GSS, *VX = lds + L.VX,
+           *VXN = lds + L.VXN, *KK = lds + L.KK, *KF = lds + L.KF, *DX = lds + L.DX, *DU = lds + L.DU,
+           *DS = lds + L.DS, *DLAM = lds + L.DLAM, *PF = lds + L.PF, *TT = lds + L.TT, *PC = lds + L.PC,
+           *MF = lds + L.MF, *MG = lds + L.MG, *MH = lds + L.MH, *MGX = lds + L.MGX, *MGU = lds + L.MGU,
+           *RED = lds + L.RED, *FILT = lds + L.FILT, *MISC = lds + L.MISC;
+    const int SL_UHI = NU, SL_XLO = 2 * NU, SL_XHI = 2 * NU + NX, SL_C = 2 * NU + 2 * NX, SL_S = SL_C + M;
+    const double dt = P.dt, Sw = P.S, tol = P.tol;
+
+    // bound of a box slot r at stage k; returns false when the row does not exist
+    auto box_bound = [&](int k, int r, double &b) -> bool {
+        if (r < SL_XLO) {
+            if (k >= N) return false;
+            const int j = r < NU ? r : r - NU;
+            const double ul = ULAST[k * NU + j];
+            if (r < NU) b = mmpc_max(P.ulim[0][j], ul + P.dulim[0][j]);
+            else b = mmpc_min(P.ulim[1][j], ul + P.dulim[1][j]);
+        } else {
+            if (k < 1) return false;
+            const int q = r - SL_XLO;
+            b = q < NX ? P.xlim[0][q] : P.xlim[1][q - NX];
+        }
+        return mmpc_finite(b);
+    };
+    auto obs_ptr = [&](int k, int m) -> const double * {
+        return OBS + ((P.obs_per_stage ? k * M : 0) + m) * 3;
+    };
+    auto slack_idx = [&](int k) -> int { return k < N - 1 ? k : N - 1; };  // :265 quirk (Q1)
+
+    // ---------------------------------------------------------------- load + initial point
+    LANES_BEGIN
+    for (int i = lane; i < NS * NX; i += MMPC_WAVE) {
+        const int j = i % NX;
+        double x0 = io.x_init[j];
+        if (KIND == 0) x0 = mmpc_max(mmpc_min(x0, P.xlim[1][j]), P.xlim[0][j]);  // :290-291
+        XREF[i] = io.traj_ref[i];
+        X[i] = (P.use_xguess && i >= NX) ? io.x_guess[i] : x0;  // :302 / mpc_base.py:200
+        LAM[i] = 0.0;
+    }
+    for (int i = lane; i < N * NU; i += MMPC_WAVE) {
+        UREF[i] = io.u_ref[i];
+        ULAST[i] = io.u_last[i];
+        U[i] = io.u_last[i];  // :303,:310
+    }
+    for (int i = lane; i < NS; i += MMPC_WAVE) S[i] = 0.0;  // :304
+    for (int i = lane; i < (P.obs_per_stage ? NS : 1) * M * 3; i += MMPC_WAVE) OBS[i] = io.obs[i];
+    LANES_END
+
+    // value of the non-box rows of stage k at a point (used for slack init and line search)
+    // returns via hr[NR]
+    auto nl_rows = [&](int k, const double *xk, double sk, double sks, double *hr) {
+        for (int m = 0; m < M; m++) {
+            const double *o = obs_ptr(k, m);
+            const double dx = xk[0] - o[0], dy = xk[1] - o[1];
+            hr[m] = (o[2] + MMPC_BASE_R) - sqrt(dx * dx + dy * dy) - sk;  // mpc_wholebody_qref.py:53
+        }
+        if (NSELF) {
+            double dr[3], dz[3], sn, cs;
+            sincos(xk[2], &sn, &cs);
+            mmpc_arm_segments(xk[NX - 3], xk[NX - 2], xk[NX - 1], dr, dz);
+            for (int i = 0; i < NSELF; i++) hr[M + i] = mmpc_self_row(i, xk[0], xk[1], cs, sn, dr, dz, nullptr) - sks;
+        }
+    };
+
+    double mu = P.mu_init;
+    // ---------------------------------------------------------------- slack / multiplier init
+    LANES_BEGIN
+    for (int k = lane; k < NS; k += MMPC_WAVE) {
+        double hr[16 + 4];
+        nl_rows(k, X + k * NX, S[k], S[slack_idx(k)], hr);
+        for (int r = 0; r < R; r++) {
+            double h = 0.0, b;
+            bool act = true;
+            if (r < SL_C) {
+                act = box_bound(k, r, b);
+                if (act) {
+                    if (r < NU) h = b - U[k * NU + r];
+                    else if (r < SL_XLO) h = U[k * NU + r - NU] - b;
+                    else if (r < SL_XHI) h = b - X[k * NX + r - SL_XLO];
+                    else h = X[k * NX + r - SL_XHI] - b;
+                }
+            } else h = hr[r - SL_C];
+            const double t0 = act ? mmpc_max(-h, 1e-2) : 1.0;
+            T[k * R + r] = t0;
+            Z[k * R + r] = act ? mu / t0 : 0.0;
+        }
+    }
+    LANES_END
+
+    int status = 1, it = 0, nfilt = 0, filt_init = 0, nrows_act = 0;
+    double E0 = 0.0, th_max = 0.0, th_min = 0.0;
+    // number of active rows (uniform): box rows that exist + all non-box rows
+    for (int r = 0; r < SL_C; r++) {
+        // u rows depend on k only through u_last (finite => same activity for all k unless dulim finite and
+        // ulim infinite, still finite); count exactly:
+        for (int k = 0; k < NS; k++) { double b; if (box_bound(k, r, b)) nrows_act++; }
+    }
+    nrows_act += NS * NR;
+
+    for (it = 0; it <= P.max_iter; it++) {
+        // ============================================================ E1: evaluation + KKT partials
+        LANES_BEGIN
+        double e_d = 0.0, e_p = 0.0, tzmax = 0.0, tzmin = 1e300, zsum = 0.0;
+        for (int k = lane; k < NS; k += MMPC_WAVE) {
+            const double *xk = X + k * NX;
+            double sn, cs;
+            sincos(xk[2], &sn, &cs);
+            double rdx[NX], rdu[NU > 0 ? NU : 1];
+            // cost gradient (mpc_wholebody_qref.py:192-201,240-242; mpc_base.py:146-153)
+            {
+                double e[NX];
+                for (int j = 0; j < NX; j++) e[j] = xk[j] - XREF[k * NX + j];
+                if (KIND == 1) e[2] = mmpc_angle_diff(xk[2], XREF[k * NX + 2]);
+                const double *W2 = k < N ? P.Q2 : P.P2;
+                for (int i = 0; i < NX; i++) {
+                    double v = 0.0;
+                    for (int j = 0; j < NX; j++) v += W2[i * NX + j] * e[j];
+                    GX[k * NX + i] = v;
+                    rdx[i] = v + (k >= 1 ? LAM[k * NX + i] : 0.0);
+                }
+            }
+            double *cv = CV + k * MMPC_NCV;
+            if (k < N) {
+                const double *uk = U + k * NU;
+                cv[0] = 0.0; cv[1] = 1.0; cv[2] = dt;
+                cv[3] = -dt * uk[0] * sn; cv[4] = dt * uk[0] * cs; cv[5] = dt * xk[5]; cv[6] = -dt * xk[5];
+                cv[7] = -dt * xk[4]; cv[8] = dt * xk[3]; cv[9] = dt * cs; cv[10] = dt * sn;
+                // defect c_k = f(x_k,u_k) - x_{k+1}   (base.py:19-26, manipulator_3DoF.py:190)
+                double xn[NX];
+                xn[0] = xk[0] + dt * xk[3]; xn[1] = xk[1] + dt * xk[4]; xn[2] = xk[2] + dt * xk[5];
+                xn[3] = xk[3] + dt * (uk[0] * cs - xk[4] * xk[5]);
+                xn[4] = xk[4] + dt * (uk[0] * sn + xk[3] * xk[5]);
+                xn[5] = xk[5] + dt * uk[1];
+                if (KIND == 0) { xn[6] = xk[6] + dt * uk[2]; xn[7] = xk[7] + dt * uk[3]; xn[8] = xk[8] + dt * uk[4]; }
+                for (int j = 0; j < NX; j++) {
+                    const double c = xn[j] - X[(k + 1) * NX + j];
+                    CD[k * NX + j] = c;
+                    e_p = mmpc_max(e_p, fabs(c));
+                    zsum += fabs(LAM[(k + 1) * NX + j]);
+                }
+                for (int a = 0; a < NU; a++) {
+                    double v = 0.0;
+                    for (int b = 0; b < NU; b++)
+                        v += P.R2[a * NU + b] * (uk[b] - UREF[k * NU + b]) + P.W2[a * NU + b] * (uk[b] - ULAST[k * NU + b]);
+                    GU[k * NU + a] = v;
+                    rdu[a] = v;
+                }
+                // - A^T lam_{k+1}, - B^T lam_{k+1}
+                const double *ln = LAM + (k + 1) * NX;
+                for (int j = 0; j < NV; j++) {
+                    double v = 0.0;
+                    for (int q = 0; q < 4; q++) v += cv[TB::ccv(j, q)] * ln[TB::crow(j, q)];
+                    if (j < NX) rdx[j] -= v; else rdu[j - NX] -= v;
+                }
+            }
+            // box rows
+            for (int r = 0; r < SL_C; r++) {
+                double b;
+                if (!box_bound(k, r, b)) continue;
+                const double t = T[k * R + r], z = Z[k * R + r];
+                double h;
+                if (r < NU) { h = b - U[k * NU + r]; rdu[r] -= z; }
+                else if (r < SL_XLO) { h = U[k * NU + r - NU] - b; rdu[r - NU] += z; }
+                else if (r < SL_XHI) { h = b - xk[r - SL_XLO]; rdx[r - SL_XLO] -= z; }
+                else { h = xk[r - SL_XHI] - b; rdx[r - SL_XHI] += z; }
+                e_p = mmpc_max(e_p, fabs(h + t));
+                tzmax = mmpc_max(tzmax, t * z); tzmin = mmpc_min(tzmin, t * z); zsum += z;
+            }
+            // circle rows: value, gradient, Hessian (mpc_wholebody_qref.py:49-54)
+            double rds = 2 * Sw * S[k], selfz = 0.0;
+            for (int m = 0; m < M; m++) {
+                const double *o = obs_ptr(k, m);
+                const double dx = xk[0] - o[0], dy = xk[1] - o[1], d = sqrt(dx * dx + dy * dy), id = 1.0 / d;
+                const double nxv = dx * id, nyv = dy * id;
+                const double h = (o[2] + MMPC_BASE_R) - d - S[k];
+                HR[k * NR + m] = h;
+                GC[(k * M + m) * 2 + 0] = -nxv; GC[(k * M + m) * 2 + 1] = -nyv;
+                HC[(k * M + m) * 3 + 0] = -(1 - nxv * nxv) * id; HC[(k * M + m) * 3 + 1] = nxv * nyv * id;
+                HC[(k * M + m) * 3 + 2] = -(1 - nyv * nyv) * id;
+                const double t = T[k * R + SL_C + m], z = Z[k * R + SL_C + m];
+                rdx[0] -= nxv * z; rdx[1] -= nyv * z; rds -= z;
+                e_p = mmpc_max(e_p, fabs(h + t));
+                tzmax = mmpc_max(tzmax, t * z); tzmin = mmpc_min(tzmin, t * z); zsum += z;
+            }
+            if (NSELF) {
+                double dr[3], dz[3];
+                mmpc_arm_segments(xk[NX - 3], xk[NX - 2], xk[NX - 1], dr, dz);
+                const double sks = S[slack_idx(k)];
+                for (int i = 0; i < NSELF; i++) {
+                    double g6[6];
+                    const double h = mmpc_self_row(i, xk[0], xk[1], cs, sn, dr, dz, g6) - sks;
+                    HR[k * NR + M + i] = h;
+                    const double t = T[k * R + SL_S + i], z = Z[k * R + SL_S + i];
+                    for (int a = 0; a < 6; a++) { GSF[(k * NSELF + i) * 6 + a] = g6[a]; rdx[kY[a]] += g6[a] * z; }
+                    selfz += z;
+                    e_p = mmpc_max(e_p, fabs(h + t));
+                    tzmax = mmpc_max(tzmax, t * z); tzmin = mmpc_min(tzmin, t * z); zsum += z;
+                }
+            }
+            if (k < N) rds -= selfz; else MISC[1] = selfz;
+            DS[k] = rds;  // stage-local part of the s-stationarity residual (finished in E1b)
+            if (k >= 1) for (int i = 0; i < NX; i++) e_d = mmpc_max(e_d, fabs(rdx[i]));
+            if (k < N) for (int a = 0; a < NU; a++) e_d = mmpc_max(e_d, fabs(rdu[a]));
+        }
+        RED[0 * MMPC_WAVE + lane] = e_d; RED[1 * MMPC_WAVE + lane] = e_p; RED[2 * MMPC_WAVE + lane] = tzmax;
+        RED[3 * MMPC_WAVE + lane] = tzmin; RED[4 * MMPC_WAVE + lane] = zsum;
+        if (lane == 0) MISC[0] = 0.0;
+        if (NSELF == 0 && lane == 0) MISC[1] = 0.0;
+        LANES_END
+        // ---- E1b: finish the s residual (terminal self rows are bound to s_{N-1})
+        LANES_BEGIN
+        double e_s = 0.0;
+        for (int k = lane; k < NS; k += MMPC_WAVE) e_s = mmpc_max(e_s, fabs(DS[k] - (k == N - 1 ? MISC[1] : 0.0)));
+        RED[5 * MMPC_WAVE + lane] = e_s;
+        LANES_END
+        double err_d = 0.0, err_p = 0.0, tzmax = 0.0, tzmin = 1e300, zsum = 0.0;
+        for (int i = 0; i < MMPC_WAVE; i++) {
+            err_d = mmpc_max(err_d, mmpc_max(RED[0 * MMPC_WAVE + i], RED[5 * MMPC_WAVE + i]));
+            err_p = mmpc_max(err_p, RED[1 * MMPC_WAVE + i]);
+            tzmax = mmpc_max(tzmax, RED[2 * MMPC_WAVE + i]);
+            tzmin = mmpc_min(tzmin, RED[3 * MMPC_WAVE + i]);
+            zsum += RED[4 * MMPC_WAVE + i];
+        }
+        double sd = zsum / (double)(nrows_act + NS * NX);
+        sd = (sd > 100.0 ? sd : 100.0) / 100.0;
+        E0 = mmpc_max(mmpc_max(err_d / sd, err_p), tzmax / sd);
+        if (!(E0 == E0) || !mmpc_finite(E0)) { status = 2; break; }
+        if (E0 <= tol) { status = 0; break; }
+        if (it == P.max_iter) break;
+        {
+            // barrier schedule (Fiacco-McCormick, as IPOPT's monotone mode)
+            bool changed = false;
+            for (;;) {
+                const double compmu = mmpc_max(fabs(tzmax - mu), fabs(tzmin - mu));
+                const double Emu = mmpc_max(mmpc_max(err_d / sd, err_p), compmu / sd);
+                if (!(Emu <= 10.0 * mu && mu > tol / 10)) break;
+                mu = mmpc_max(tol / 10, mmpc_min(0.2 * mu, mu * sqrt(mu)));
+                changed = true;
+            }
+            if (changed) filt_init = 0;
+        }
+
+        // ============================================================ Newton direction
+        int failed = 0;
+        for (int attempt = 0; attempt < 2; attempt++) {
+            const bool exact = attempt == 0;
+            // ---- A1: stage Hessian / gradient assembly
+            LANES_BEGIN
+            for (int k = lane; k < NS; k += MMPC_WAVE) {
+                double *hxx = HXX + k * NXX, *qx = QX + k * NX;
+                const double *W2 = k < N ? P.Q2 : P.P2;
+                for (int e = 0; e < NXX; e++) hxx[e] = W2[kTriI[e] * NX + kTriJ[e]];
+                for (int j = 0; j < NX; j++) qx[j] = GX[k * NX + j];
+                if (k < N) {
+                    for (int a = 0; a < NU; a++) { HUUD[k * NU + a] = 0.0; QU[k * NU + a] = GU[k * NU + a]; }
+                    double h02 = 0.0;
+                    if (exact) {
+                        // - sum_j lam_{k+1,j} d2 f_j/d(x,u)2 : only f3, f4 are nonlinear (base.py:23-24)
+                        const double *cv = CV + k * MMPC_NCV;
+                        const double l3 = LAM[(k + 1) * NX + 3], l4 = LAM[(k + 1) * NX + 4];
+                        hxx[5] += l3 * cv[4] - l4 * cv[3];   // (2,2): dt*u0*(l3 cos + l4 sin)
+                        hxx[19] += dt * l3;   // (5,4)
+                        hxx[18] -= dt * l4;   // (5,3)
+                        h02 = -(-l3 * cv[10] + l4 * cv[9]);
+                    }
+                    HUX02[k] = h02;
+                }
+                double hss = 2 * Sw, gss = 2 * Sw * S[k], vx[6] = {0, 0, 0, 0, 0, 0};
+                for (int r = 0; r < SL_C; r++) {
+                    double b;
+                    if (!box_bound(k, r, b)) continue;
+                    const double t = T[k * R + r], z = Z[k * R + r], w = z / t;
+                    double h;
+                    if (r < NU) h = b - U[k * NU + r];
+                    else if (r < SL_XLO) h = U[k * NU + r - NU] - b;
+                    else if (r < SL_XHI) h = b - X[k * NX + r - SL_XLO];
+                    else h = X[k * NX + r - SL_XHI] - b;
+                    const double zh = mu / t + w * (h + t);
+                    if (r < NU) { HUUD[k * NU + r] += w; QU[k * NU + r] -= zh; }
+                    else if (r < SL_XLO) { HUUD[k * NU + r - NU] += w; QU[k * NU + r - NU] += zh; }
+                    else if (r < SL_XHI) { const int j = r - SL_XLO; hxx[j * (j + 1) / 2 + j] += w; qx[j] -= zh; }
+                    else { const int j = r - SL_XHI; hxx[j * (j + 1) / 2 + j] += w; qx[j] += zh; }
+                }
+                for (int m = 0; m < M; m++) {
+                    const double t = T[k * R + SL_C + m], z = Z[k * R + SL_C + m], w = z / t;
+                    const double zh = mu / t + w * (HR[k * NR + m] + t);
+                    const double g0 = GC[(k * M + m) * 2], g1 = GC[(k * M + m) * 2 + 1];
+                    hxx[0] += w * g0 * g0; hxx[1] += w * g1 * g0; hxx[2] += w * g1 * g1;
+                    if (exact) {
+                        hxx[0] += z * HC[(k * M + m) * 3]; hxx[1] += z * HC[(k * M + m) * 3 + 1];
+                        hxx[2] += z * HC[(k * M + m) * 3 + 2];
+                    }
+                    qx[0] += g0 * zh; qx[1] += g1 * zh;
+                    hss += w; gss -= zh; vx[0] += w * g0; vx[1] += w * g1;
+                }
+                double hssN = 0.0, gssN = 0.0, vN[6] = {0, 0, 0, 0, 0, 0};
+                for (int i = 0; i < NSELF; i++) {
+                    const double t = T[k * R + SL_S + i], z = Z[k * R + SL_S + i], w = z / t;
+                    const double zh = mu / t + w * (HR[k * NR + M + i] + t);
+                    const double *g6 = GSF + (k * NSELF + i) * 6;
+                    for (int a = 0; a < 6; a++) {
+                        const int ia = kY[a];
+                        for (int b = 0; b <= a; b++) hxx[ia * (ia + 1) / 2 + kY[b]] += w * g6[a] * g6[b];
+                        qx[ia] += g6[a] * zh;
+                    }
+                    if (k < N) { hss += w; gss -= zh; for (int a = 0; a < 6; a++) vx[a] += w * g6[a]; }
+                    else { hssN += w; gssN -= zh; for (int a = 0; a < 6; a++) vN[a] += w * g6[a]; }
+                }
+                HSS[k] = hss; GSS[k] = gss;
+                for (int a = 0; a < 6; a++) VX[k * 6 + a] = vx[a];
+                if (k == N) { MISC[2] = hssN; MISC[3] = gssN; for (int a = 0; a < 6; a++) VXN[a] = vN[a]; }
+            }
+            LANES_END
+            // ---- A2: Schur complement of s_k (H_xs = -v); stage N-1 also carries the terminal
+            //          self rows (Q1): a = v + A^T vN, b = B^T vN, gamma = g_s - vN.c
+            LANES_BEGIN
+            for (int k = lane; k < NS; k += MMPC_WAVE) {
+                double *hxx = HXX + k * NXX, *qx = QX + k * NX;
+                if (k == N - 1 && NSELF) {
+                    const double hss = HSS[k] + MISC[2];
+                    double gam = GSS[k] + MISC[3];
+                    HSS[k] = hss; GSS[k] = gam;
+                    const double ih = 1.0 / hss;
+                    double vfull[NX], a[NX], b[NU > 0 ? NU : 1];
+                    for (int j = 0; j < NX; j++) { vfull[j] = 0.0; a[j] = 0.0; }
+                    for (int q = 0; q < 6; q++) { vfull[kY[q]] = VXN[q]; a[kY[q]] = VX[k * 6 + q]; }
+                    const double *cv = CV + k * MMPC_NCV;
+                    for (int j = 0; j < NV; j++) {
+                        double v = 0.0;
+                        for (int q = 0; q < 4; q++) v += cv[TB::ccv(j, q)] * vfull[TB::crow(j, q)];
+                        if (j < NX) a[j] += v; else b[j - NX] = v;
+                    }
+                    for (int j = 0; j < NX; j++) gam -= vfull[j] * CD[k * NX + j];
+                    for (int e = 0; e < NXX; e++) hxx[e] -= a[kTriI[e]] * a[kTriJ[e]] * ih;
+                    for (int j = 0; j < NX; j++) { qx[j] += a[j] * gam * ih; VXN[6 + j] = a[j]; }
+                    for (int c = 0; c < NU; c++) {
+                        for (int j = 0; j < NX; j++) HUXL[c * NX + j] = -b[c] * a[j] * ih;
+                        for (int d = 0; d <= c; d++) HUUL[c * (c + 1) / 2 + d] = -b[c] * b[d] * ih;
+                        QU[k * NU + c] += b[c] * gam * ih;
+                    }
+                } else {
+                    if (k == N - 1) {  // no self rows: still define the dense last-stage blocks
+                        for (int c = 0; c < NU * NX; c++) HUXL[c] = 0.0;
+                        for (int c = 0; c < NUU; c++) HUUL[c] = 0.0;
+                    }
+                    const double ih = 1.0 / HSS[k], gam = GSS[k];
+                    const double *v = VX + k * 6;
+                    const int ny = NSELF ? 6 : 2;
+                    for (int a = 0; a < ny; a++) {
+                        const int ia = kY[a];
+                        for (int b = 0; b <= a; b++) hxx[ia * (ia + 1) / 2 + kY[b]] -= v[a] * v[b] * ih;
+                        qx[ia] += v[a] * gam * ih;
+                    }
+                }
+            }
+            // unpack P_N (stage-N Hessian after its Schur step is written by another lane in this
+            // phase, so the unpack happens in R0 below)
+            LANES_END
+            // ---- R0: full copy of P_N
+            LANES_BEGIN
+            for (int e = lane; e < NX * NX; e += MMPC_WAVE) {
+                const int i = e / NX, j = e % NX;
+                PF[e] = HXX[N * NXX + (i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i)];
+            }
+            LANES_END
+            // ---- Riccati recursion (block LDL^T of the stage-wise KKT matrix)
+            for (int k = N - 1; k >= 0; k--) {
+                const double *cv = CV + k * MMPC_NCV;
+                // R1: T = P [A B],  pc = p + P c
+                LANES_BEGIN
+                for (int e = lane; e < NX * NV + NX; e += MMPC_WAVE) {
+                    if (e < NX * NV) {
+                        const int i = e / NV, j = e % NV;
+                        double v = 0.0;
+                        for (int q = 0; q < 4; q++) v += PF[i * NX + TB::crow(j, q)] * cv[TB::ccv(j, q)];
+                        TT[e] = v;
+                    } else {
+                        const int i = e - NX * NV;
+                        double v = QX[(k + 1) * NX + i];
+                        for (int m = 0; m < NX; m++) v += PF[i * NX + m] * CD[k * NX + m];
+                        PC[i] = v;
+                    }
+                }
+                LANES_END
+                // R2: [F G^T; G Hh] = [A B]^T T + stage Hessian;  [gx; gu] = q + [A B]^T pc
+                LANES_BEGIN
+                for (int e = lane; e < NXX + NU * NX + NUU + NV; e += MMPC_WAVE) {
+                    if (e < NXX) {
+                        const int i = kTriI[e], j = kTriJ[e];
+                        double v = HXX[k * NXX + e];
+                        for (int q = 0; q < 4; q++) v += cv[TB::ccv(i, q)] * TT[TB::crow(i, q) * NV + j];
+                        MF[e] = v;
+                    } else if (e < NXX + NU * NX) {
+                        const int e2 = e - NXX, a = e2 / NX, j = e2 % NX, col = NX + a;
+                        double v = (k == N - 1 ? HUXL[e2] : 0.0) + ((a == 0 && j == 2) ? HUX02[k] : 0.0);
+                        for (int q = 0; q < 4; q++) v += cv[TB::ccv(col, q)] * TT[TB::crow(col, q) * NV + j];
+                        MG[e2] = v;
+                    } else if (e < NXX + NU * NX + NUU) {
+                        const int e2 = e - NXX - NU * NX, a = kTriI[e2], b = kTriJ[e2], col = NX + a;
+                        double v = P.RW2[a * NU + b] + (a == b ? HUUD[k * NU + a] : 0.0) + (k == N - 1 ? HUUL[e2] : 0.0);
+                        for (int q = 0; q < 4; q++) v += cv[TB::ccv(col, q)] * TT[TB::crow(col, q) * NV + NX + b];
+                        MH[e2] = v;
+                    } else {
+                        const int j = e - NXX - NU * NX - NUU;
+                        double v = j < NX ? QX[k * NX + j] : QU[k * NU + j - NX];
+                        for (int q = 0; q < 4; q++) v += cv[TB::ccv(j, q)] * PC[TB::crow(j, q)];
+                        if (j < NX) MGX[j] = v; else MGU[j - NX] = v;
+                    }
+                }
+                LANES_END
+                // R3/R4: Cholesky of Hh (every solving lane redundantly, in registers), then one
+                //        right-hand side per lane: K = -Hh^{-1} G (NX columns), kf = -Hh^{-1} gu
+                LANES_BEGIN
+                if (lane <= NX) {
+                    double Lc[NUU];
+                    bool ok = true;
+#pragma unroll
+                    for (int j = 0; j < NU; j++) {
+                        double d = MH[j * (j + 1) / 2 + j];
+#pragma unroll
+                        for (int q = 0; q < j; q++) d -= Lc[j * (j + 1) / 2 + q] * Lc[j * (j + 1) / 2 + q];
+                        if (!(d > 0.0) || !mmpc_finite(d)) { ok = false; d = 1.0; }
+                        const double ljj = sqrt(d), il = 1.0 / ljj;
+                        Lc[j * (j + 1) / 2 + j] = il;  // store the inverse pivot
+#pragma unroll
+                        for (int i = j + 1; i < NU; i++) {
+                            double v = MH[i * (i + 1) / 2 + j];
+#pragma unroll
+                            for (int q = 0; q < j; q++) v -= Lc[i * (i + 1) / 2 + q] * Lc[j * (j + 1) / 2 + q];
+                            Lc[i * (i + 1) / 2 + j] = v * il;
+                        }
+                    }
+                    double rhs[NU];
+#pragma unroll
+                    for (int a = 0; a < NU; a++) rhs[a] = lane < NX ? MG[a * NX + lane] : MGU[a];
+#pragma unroll
+                    for (int i = 0; i < NU; i++) {
+                        double v = rhs[i];
+#pragma unroll
+                        for (int q = 0; q < i; q++) v -= Lc[i * (i + 1) / 2 + q] * rhs[q];
+                        rhs[i] = v * Lc[i * (i + 1) / 2 + i];
+                    }
+#pragma unroll
+                    for (int i = NU - 1; i >= 0; i--) {
+                        double v = rhs[i];
+#pragma unroll
+                        for (int q = i + 1; q < NU; q++) v -= Lc[q * (q + 1) / 2 + i] * rhs[q];
+                        rhs[i] = v * Lc[i * (i + 1) / 2 + i];
+                    }
+#pragma unroll
+                    for (int a = 0; a < NU; a++) {
+                        if (lane < NX) KK[(k * NU + a) * NX + lane] = -rhs[a];
+                        else KF[k * NU + a] = -rhs[a];
+                    }
+                    if (!ok && lane == 0) MISC[0] = 1.0;
+                }
+                LANES_END
+                if (MISC[0] != 0.0) { failed = 1; break; }
+                // R5: P_k = F + G^T K,  p_k = gx + G^T kf   (overwrite the stage blocks)
+                LANES_BEGIN
+                for (int e = lane; e < NXX + NX; e += MMPC_WAVE) {
+                    if (e < NXX) {
+                        const int i = kTriI[e], j = kTriJ[e];
+                        double v = MF[e];
+                        for (int a = 0; a < NU; a++) v += MG[a * NX + i] * KK[(k * NU + a) * NX + j];
+                        HXX[k * NXX + e] = v;
+                        PF[i * NX + j] = v; PF[j * NX + i] = v;
+                    } else {
+                        const int i = e - NXX;
+                        double v = MGX[i];
+                        for (int a = 0; a < NU; a++) v += MG[a * NX + i] * KF[k * NU + a];
+                        QX[k * NX + i] = v;
+                    }
+                }
+                LANES_END
+            }
+            if (!failed) break;
+            if (attempt == 1) break;
+            failed = 0;
+            LANES_BEGIN
+            if (lane == 0) MISC[0] = 0.0;
+            LANES_END
+        }
+        if (failed) { status = 2; break; }
+
+        // ---- forward roll-out of the linearised dynamics
+        LANES_BEGIN
+        for (int j = lane; j < NX; j += MMPC_WAVE) DX[j] = 0.0;
+        LANES_END
+        for (int k = 0; k < N; k++) {
+            LANES_BEGIN
+            if (lane < NU) {
+                double v = KF[k * NU + lane];
+                for (int j = 0; j < NX; j++) v += KK[(k * NU + lane) * NX + j] * DX[k * NX + j];
+                DU[k * NU + lane] = v;
+            }
+            LANES_END
+            LANES_BEGIN
+            if (lane < NX) {
+                const double *cv = CV + k * MMPC_NCV;
+                double v = CD[k * NX + lane];
+                for (int q = 0; q < 5; q++) {
+                    const int c = TB::rcol(lane, q);
+                    v += cv[TB::rcv(lane, q)] * (c < NX ? DX[k * NX + c] : DU[k * NU + c - NX]);
+                }
+                DX[(k + 1) * NX + lane] = v;
+            }
+            LANES_END
+        }
+        // ---- D1: multiplier step and slack-variable step
+        LANES_BEGIN
+        for (int k = lane; k < NS; k += MMPC_WAVE) {
+            const double *dx = DX + k * NX;
+            for (int i = 0; i < NX; i++) {
+                double v = QX[k * NX + i];
+                for (int j = 0; j < NX; j++)
+                    v += HXX[k * NXX + (i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i)] * dx[j];
+                DLAM[k * NX + i] = -v - LAM[k * NX + i];
+            }
+            double vdx = 0.0;
+            const int ny = NSELF ? 6 : 2;
+            for (int a = 0; a < ny; a++) vdx += VX[k * 6 + a] * dx[kY[a]];
+            if (k == N - 1 && NSELF) for (int a = 0; a < 6; a++) vdx += VXN[a] * DX[N * NX + kY[a]];
+            DS[k] = -(GSS[k] - vdx) / HSS[k];
+        }
+        LANES_END
+        // ---- D2: row steps, fraction-to-boundary, directional derivative, merit at alpha = 0
+        const double tau = mmpc_max(0.99, 1.0 - mu);
+        auto stage_merit = [&](int k, double alpha, double &phi_k, double &th_k) {
+            // barrier objective and l1 infeasibility contributions of stage k at w + alpha dw
+            double xk[NX], uk[NU > 0 ? NU : 1];
+            for (int j = 0; j < NX; j++) xk[j] = X[k * NX + j] + alpha * DX[k * NX + j];
+            const double sk = S[k] + alpha * DS[k];
+            const int ks = slack_idx(k);
+            const double sks = S[ks] + alpha * DS[ks];
+            double f = Sw * sk * sk, th = 0.0;
+            {
+                double e[NX];
+                for (int j = 0; j < NX; j++) e[j] = xk[j] - XREF[k * NX + j];
+                if (KIND == 1) e[2] = mmpc_angle_diff(xk[2], XREF[k * NX + 2]);
+                const double *W2 = k < N ? P.Q2 : P.P2;
+                double q = 0.0;
+                for (int i = 0; i < NX; i++) for (int j = 0; j < NX; j++) q += e[i] * W2[i * NX + j] * e[j];
+                f += 0.5 * q;
+            }
+            double sn, cs;
+            sincos(xk[2], &sn, &cs);
+            if (k < N) {
+                for (int a = 0; a < NU; a++) uk[a] = U[k * NU + a] + alpha * DU[k * NU + a];
+                double q = 0.0;
+                for (int a = 0; a < NU; a++) for (int b = 0; b < NU; b++)
+                    q += (uk[a] - UREF[k * NU + a]) * P.R2[a * NU + b] * (uk[b] - UREF[k * NU + b])
+                       + (uk[a] - ULAST[k * NU + a]) * P.W2[a * NU + b] * (uk[b] - ULAST[k * NU + b]);
+                f += 0.5 * q;
+                double xn[NX];
+                xn[0] = xk[0] + dt * xk[3]; xn[1] = xk[1] + dt * xk[4]; xn[2] = xk[2] + dt * xk[5];
+                xn[3] = xk[3] + dt * (uk[0] * cs - xk[4] * xk[5]);
+                xn[4] = xk[4] + dt * (uk[0] * sn + xk[3] * xk[5]);
+                xn[5] = xk[5] + dt * uk[1];
+                if (KIND == 0) { xn[6] = xk[6] + dt * uk[2]; xn[7] = xk[7] + dt * uk[3]; xn[8] = xk[8] + dt * uk[4]; }
+                for (int j = 0; j < NX; j++) th += fabs(xn[j] - (X[(k + 1) * NX + j] + alpha * DX[(k + 1) * NX + j]));
+            }
+            // sum of log t: product of mantissas + sum of exponents (one log per stage)
+            double mant = 1.0; int ex = 0;
+            auto acc = [&](double tv) { int e2; mant *= frexp(tv, &e2); ex += e2; if (mant < 1e-200) { mant = frexp(mant, &e2); ex += e2; } };
+            for (int r = 0; r < SL_C; r++) {
+                double b;
+                if (!box_bound(k, r, b)) continue;
+                double h, dv;
+                if (r < NU) { h = b - uk[r]; dv = -DU[k * NU + r]; }
+                else if (r < SL_XLO) { h = uk[r - NU] - b; dv = DU[k * NU + r - NU]; }
+                else if (r < SL_XHI) { h = b - xk[r - SL_XLO]; dv = -DX[k * NX + r - SL_XLO]; }
+                else { h = xk[r - SL_XHI] - b; dv = DX[k * NX + r - SL_XHI]; }
+                // at alpha: t + alpha dt, with dt = -(h0 + t) - dv and h linear:  h(alpha) = h0 + alpha dv
+                const double t0 = T[k * R + r];
+                const double h0 = h - alpha * dv;
+                const double tv = t0 + alpha * (-(h0 + t0) - dv);
+                th += fabs(h + tv);
+                acc(tv);
+            }
+            double hr[16 + 4];
+            {
+                for (int m = 0; m < M; m++) {
+                    const double *o = obs_ptr(k, m);
+                    const double dx = xk[0] - o[0], dy = xk[1] - o[1];
+                    hr[m] = (o[2] + MMPC_BASE_R) - sqrt(dx * dx + dy * dy) - sk;
+                }
+                if (NSELF) {
+                    double dr[3], dz[3];
+                    mmpc_arm_segments(xk[NX - 3], xk[NX - 2], xk[NX - 1], dr, dz);
+                    for (int i = 0; i < NSELF; i++) hr[M + i] = mmpc_self_row(i, xk[0], xk[1], cs, sn, dr, dz, nullptr) - sks;
+                }
+            }
+            for (int m = 0; m < NR; m++) {
+                const double tv = T[k * R + SL_C + m] + alpha * DTR[k * NR + m];
+                th += fabs(hr[m] + tv);
+                acc(tv);
+            }
+            phi_k = f - mu * (log(mant) + (double)ex * 0.69314718055994530942);
+            th_k = th;
+        };
+        LANES_BEGIN
+        double ap = 1.0, ad = 1.0, dphi = 0.0;
+        for (int k = lane; k < NS; k += MMPC_WAVE) {
+            const double *dx = DX + k * NX;
+            for (int r = 0; r < R; r++) {
+                double h, jd, b;
+                if (r < SL_C) {
+                    if (!box_bound(k, r, b)) continue;
+                    if (r < NU) { h = b - U[k * NU + r]; jd = -DU[k * NU + r]; }
+                    else if (r < SL_XLO) { h = U[k * NU + r - NU] - b; jd = DU[k * NU + r - NU]; }
+                    else if (r < SL_XHI) { h = b - X[k * NX + r - SL_XLO]; jd = -dx[r - SL_XLO]; }
+                    else { h = X[k * NX + r - SL_XHI] - b; jd = dx[r - SL_XHI]; }
+                } else if (r < SL_S) {
+                    const int m = r - SL_C;
+                    h = HR[k * NR + m];
+                    jd = GC[(k * M + m) * 2] * dx[0] + GC[(k * M + m) * 2 + 1] * dx[1] - DS[k];
+                } else {
+                    const int i = r - SL_S;
+                    h = HR[k * NR + M + i];
+                    jd = -DS[slack_idx(k)];
+                    for (int a = 0; a < 6; a++) jd += GSF[(k * NSELF + i) * 6 + a] * dx[kY[a]];
+                }
+                const double t = T[k * R + r], z = Z[k * R + r];
+                const double dtv = -(h + t) - jd, dzv = mu / t - z - (z / t) * dtv;
+                if (r >= SL_C) DTR[k * NR + r - SL_C] = dtv;
+                if (dtv < 0) ap = mmpc_min(ap, -tau * t / dtv);
+                if (dzv < 0) ad = mmpc_min(ad, -tau * z / dzv);
+                dphi -= mu * dtv / t;
+            }
+            for (int j = 0; j < NX; j++) dphi += GX[k * NX + j] * dx[j];
+            if (k < N) for (int a = 0; a < NU; a++) dphi += GU[k * NU + a] * DU[k * NU + a];
+            dphi += 2 * Sw * S[k] * DS[k];
+        }
+        RED[0 * MMPC_WAVE + lane] = ap; RED[1 * MMPC_WAVE + lane] = ad; RED[2 * MMPC_WAVE + lane] = dphi;
+        LANES_END
+        double ap = 1.0, ad = 1.0, dphi = 0.0;
+        for (int i = 0; i < MMPC_WAVE; i++) {
+            ap = mmpc_min(ap, RED[0 * MMPC_WAVE + i]);
+            ad = mmpc_min(ad, RED[1 * MMPC_WAVE + i]);
+            dphi += RED[2 * MMPC_WAVE + i];
+        }
+        // ---- merit at the current point (needs DTR from D2 only formally: alpha = 0)
+        LANES_BEGIN
+        double ph = 0.0, th = 0.0;
+        for (int k = lane; k < NS; k += MMPC_WAVE) { double a, b; stage_merit(k, 0.0, a, b); ph += a; th += b; }
+        RED[3 * MMPC_WAVE + lane] = ph; RED[4 * MMPC_WAVE + lane] = th;
+        LANES_END
+        double phi0 = 0.0, th0 = 0.0;
+        for (int i = 0; i < MMPC_WAVE; i++) { phi0 += RED[3 * MMPC_WAVE + i]; th0 += RED[4 * MMPC_WAVE + i]; }
+        if (!filt_init) { nfilt = 0; th_max = 1e4 * mmpc_max(1.0, th0); th_min = 1e-4 * mmpc_max(1.0, th0); filt_init = 1; }
+
+        // ---- filter line search (Waechter-Biegler acceptance rules, no restoration phase)
+        double alpha = ap;
+        for (int ls = 0; ls < MMPC_MAX_LS; ls++) {
+            LANES_BEGIN
+            double ph = 0.0, th = 0.0;
+            for (int k = lane; k < NS; k += MMPC_WAVE) { double a, b; stage_merit(k, alpha, a, b); ph += a; th += b; }
+            RED[5 * MMPC_WAVE + lane] = ph; RED[6 * MMPC_WAVE + lane] = th;
+            LANES_END
+            double phi = 0.0, th = 0.0;
+            for (int i = 0; i < MMPC_WAVE; i++) { phi += RED[5 * MMPC_WAVE + i]; th += RED[6 * MMPC_WAVE + i]; }
+            bool okf = th < th_max;
+            for (int i = 0; i < nfilt && okf; i++) if (th >= FILT[2 * i] && phi >= FILT[2 * i + 1]) okf = false;
+            const bool ftype = dphi < 0 && th0 <= th_min && alpha * pow(-dphi, 2.3) > pow(th0, 1.1);
+            bool accepted = false, augment = false;
+            if (okf) {
+                if (ftype) accepted = phi <= phi0 + 1e-8 * alpha * dphi + 1e-14 * fabs(phi0);
+                else if (th <= (1 - 1e-5) * th0 || phi <= phi0 - 1e-5 * th0) { accepted = true; augment = true; }
+            }
+            if (augment) {
+                int slot = nfilt;
+                if (nfilt >= MMPC_FCAP) { slot = 0; for (int i = 1; i < MMPC_FCAP; i++) if (FILT[2 * i] > FILT[2 * slot]) slot = i; }
+                else nfilt++;
+                LANES_BEGIN
+                if (lane == 0) { FILT[2 * slot] = (1 - 1e-5) * th0; FILT[2 * slot + 1] = phi0 - 1e-5 * th0; }
+                LANES_END
+            }
+            if (accepted) break;
+            if (ls < MMPC_MAX_LS - 1) alpha *= 0.5;
+        }
+        // ---- update
+        LANES_BEGIN
+        for (int k = lane; k < NS; k += MMPC_WAVE) {
+            for (int r = 0; r < R; r++) {
+                double dtv, b;
+                if (r < SL_C) {
+                    if (!box_bound(k, r, b)) continue;
+                    double h, jd;
+                    if (r < NU) { h = b - U[k * NU + r]; jd = -DU[k * NU + r]; }
+                    else if (r < SL_XLO) { h = U[k * NU + r - NU] - b; jd = DU[k * NU + r - NU]; }
+                    else if (r < SL_XHI) { h = b - X[k * NX + r - SL_XLO]; jd = -DX[k * NX + r - SL_XLO]; }
+                    else { h = X[k * NX + r - SL_XHI] - b; jd = DX[k * NX + r - SL_XHI]; }
+                    dtv = -(h + T[k * R + r]) - jd;
+                } else dtv = DTR[k * NR + r - SL_C];
+                const double t = T[k * R + r], z = Z[k * R + r];
+                const double dzv = mu / t - z - (z / t) * dtv;
+                T[k * R + r] = t + alpha * dtv;
+                Z[k * R + r] = z + ad * dzv;
+            }
+        }
+        LANES_END
+        LANES_BEGIN
+        for (int i = lane; i < NS * NX; i += MMPC_WAVE)
+            if (i >= NX) { X[i] += alpha * DX[i]; LAM[i] += alpha * DLAM[i]; }
+        for (int i = lane; i < N * NU; i += MMPC_WAVE) U[i] += alpha * DU[i];
+        for (int i = lane; i < NS; i += MMPC_WAVE) S[i] += alpha * DS[i];
+        LANES_END
+    }
+
+    // ---------------------------------------------------------------- results
+    LANES_BEGIN
+    double f = 0.0;
+    for (int k = lane; k < NS; k += MMPC_WAVE) {
+        const double *xk = X + k * NX;
+        double e[NX];
+        for (int j = 0; j < NX; j++) e[j] = xk[j] - XREF[k * NX + j];
+        if (KIND == 1) e[2] = mmpc_angle_diff(xk[2], XREF[k * NX + 2]);
+        const double *W2 = k < N ? P.Q2 : P.P2;
+        double q = 0.0;
+        for (int i = 0; i < NX; i++) for (int j = 0; j < NX; j++) q += e[i] * W2[i * NX + j] * e[j];
+        if (k < N) {
+            const double *uk = U + k * NU;
+            for (int a = 0; a < NU; a++) for (int b = 0; b < NU; b++)
+                q += (uk[a] - UREF[k * NU + a]) * P.R2[a * NU + b] * (uk[b] - UREF[k * NU + b])
+                   + (uk[a] - ULAST[k * NU + a]) * P.W2[a * NU + b] * (uk[b] - ULAST[k * NU + b]);
+        }
+        f += 0.5 * q + Sw * S[k] * S[k];
+    }
+    RED[lane] = f;
+    for (int i = lane; i < NS * NX; i += MMPC_WAVE) io.X[i] = X[i];
+    for (int i = lane; i < N * NU; i += MMPC_WAVE) io.U[i] = U[i];
+    for (int i = lane; i < NS; i += MMPC_WAVE) io.s[i] = S[i];
+    LANES_END
+    double cost = 0.0;
+    for (int i = 0; i < MMPC_WAVE; i++) cost += RED[i];
+    LANES_BEGIN
+    if (lane == 0) { *io.status = status; *io.iters = it; *io.cost = cost; *io.err = E0; }
+    LANES_END
+}

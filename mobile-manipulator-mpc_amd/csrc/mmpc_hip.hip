@@ -1,0 +1,271 @@
+// mmpc_hip.hip - gfx950 kernels + the C ABI of include/mmpc.h (libmmpc.so).
+// One 64-lane workgroup (= one wavefront) per problem instance; the solver core is
+// mmpc_core.h.  No CPU fallback: every entry point needs a HIP device.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <new>
+
+#include "../../include/mmpc.h"
+#include "mmpc_core.h"
+
+template <int KIND>
+__global__ __launch_bounds__(MMPC_WAVE) void mmpc_solve_kernel(
+    const MmpcParams *__restrict__ Pp, int B, const double *__restrict__ x_init, const double *__restrict__ traj_ref,
+    const double *__restrict__ u_ref, const double *__restrict__ u_last, const double *__restrict__ x_guess,
+    const double *__restrict__ obs, double *__restrict__ X, double *__restrict__ U, double *__restrict__ s,
+    int *__restrict__ status, int *__restrict__ iters, double *__restrict__ cost, double *__restrict__ err) {
+    extern __shared__ double lds[];
+    typedef MmpcDims<KIND> D;
+    const int b = (int)blockIdx.x;
+    if (b >= B) return;
+    const MmpcParams &P = *Pp;
+    const int N = P.N, M = P.M;
+    const size_t so = (size_t)(P.obs_per_stage ? N + 1 : 1) * M * 3;
+    MmpcIO io;
+    io.x_init = x_init + (size_t)b * D::NX;
+    io.traj_ref = traj_ref + (size_t)b * (N + 1) * D::NX;
+    io.u_ref = u_ref + (size_t)b * N * D::NU;
+    io.u_last = u_last + (size_t)b * N * D::NU;
+    io.x_guess = x_guess ? x_guess + (size_t)b * (N + 1) * D::NX : nullptr;
+    io.obs = obs + (size_t)b * so;
+    io.X = X + (size_t)b * (N + 1) * D::NX;
+    io.U = U + (size_t)b * N * D::NU;
+    io.s = s + (size_t)b * (N + 1);
+    io.status = status + b;
+    io.iters = iters + b;
+    io.cost = cost + b;
+    io.err = err + b;
+    mmpc_solve_one<KIND>(P, io, lds);
+}
+
+// out_u0[b][a] = U[b][0][a]
+__global__ void mmpc_gather_u0(int B, int NU, int stride, const double *__restrict__ U, double *__restrict__ u0) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B * NU) u0[i] = U[(size_t)(i / NU) * stride + (i % NU)];
+}
+
+struct mmpc_handle_s {
+    mmpc_config cfg;
+    MmpcParams hp;          // host copy
+    MmpcParams *dp;         // device copy
+    int nx, nu, lds_bytes;
+    int warm;               // 1 once a solve has filled u_latest (x_guess)
+    // device-side state and staging (capacity max_batch)
+    double *d_x_init, *d_traj, *d_uref, *d_obs, *d_ulatest, *d_xguess, *d_X, *d_U, *d_s, *d_cost, *d_err, *d_u0;
+    int *d_status, *d_iters;
+    char err[512];
+};
+
+static int fail(mmpc_handle h, int code, const char *fmt, const char *a = "", const char *b = "") {
+    if (h) snprintf(h->err, sizeof(h->err), fmt, a, b);
+    return code;
+}
+#define HIPCHK(h, call)                                                                   \
+    do {                                                                                  \
+        hipError_t e_ = (call);                                                           \
+        if (e_ != hipSuccess) return fail(h, MMPC_E_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+static void default_weights(mmpc_handle h) {
+    // mpc_wholebody_qref.py:12-16 / mpc_base.py:11-14
+    MmpcParams &p = h->hp;
+    memset(p.Q2, 0, sizeof(p.Q2)); memset(p.P2, 0, sizeof(p.P2)); memset(p.RW2, 0, sizeof(p.RW2));
+    memset(p.R2, 0, sizeof(p.R2)); memset(p.W2, 0, sizeof(p.W2));
+    const int nx = h->nx, nu = h->nu;
+    if (h->cfg.kind == MMPC_KIND_WHOLEBODY) {
+        const double q[9] = {25, 25, 0, 0, 0, 5, 5, 5, 5}, r[5] = {0.1, 0.1, 0, 0, 0}, w[5] = {0, 0, 0.1, 0.1, 0.1};
+        for (int i = 0; i < nx; i++) p.Q2[i * nx + i] = p.P2[i * nx + i] = 2 * q[i];
+        for (int i = 0; i < nu; i++) { p.R2[i * nu + i] = 2 * r[i]; p.W2[i * nu + i] = 2 * w[i]; }
+    } else {
+        const double q[6] = {5, 5, 0, 0, 0, 1};
+        for (int i = 0; i < nx; i++) p.Q2[i * nx + i] = p.P2[i * nx + i] = 2 * q[i];
+        for (int i = 0; i < nu; i++) p.R2[i * nu + i] = 2.0;
+    }
+    for (int i = 0; i < nu * nu; i++) p.RW2[i] = p.R2[i] + p.W2[i];
+    p.S = 1e5;
+}
+
+static int upload_params(mmpc_handle h) {
+    HIPCHK(h, hipMemcpy(h->dp, &h->hp, sizeof(MmpcParams), hipMemcpyHostToDevice));
+    return MMPC_OK;
+}
+
+extern "C" const char *mmpc_version(void) { return "mmpc 0.1 (gfx950)"; }
+extern "C" const char *mmpc_last_error(mmpc_handle h) { return h ? h->err : "null handle"; }
+extern "C" int mmpc_lds_bytes(mmpc_handle h) { return h ? h->lds_bytes : MMPC_E_ARG; }
+
+extern "C" int mmpc_create(const mmpc_config *cfg, mmpc_handle *out) {
+    if (!cfg || !out) return MMPC_E_ARG;
+    *out = nullptr;
+    if (cfg->kind != MMPC_KIND_WHOLEBODY && cfg->kind != MMPC_KIND_BASE) return MMPC_E_ARG;
+    if (cfg->N < 1 || cfg->N > 63 || cfg->M < 0 || cfg->M > 16 || cfg->max_batch < 1) return MMPC_E_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) return MMPC_E_NODEVICE;
+    mmpc_handle h = new (std::nothrow) mmpc_handle_s();
+    if (!h) return MMPC_E_ARG;
+    memset(h, 0, sizeof(*h));
+    h->cfg = *cfg;
+    h->nx = cfg->kind == MMPC_KIND_WHOLEBODY ? 9 : 6;
+    h->nu = cfg->kind == MMPC_KIND_WHOLEBODY ? 5 : 2;
+    *out = h;  // returned even on failure below so that the caller can read the error text
+    HIPCHK(h, hipSetDevice(cfg->device));
+    MmpcParams &p = h->hp;
+    p.N = cfg->N; p.M = cfg->M; p.obs_per_stage = cfg->obs_per_stage ? 1 : 0;
+    p.max_iter = cfg->max_iter > 0 ? cfg->max_iter : 200;
+    p.use_xguess = 0; p.terminal_xy_eq = 0;
+    p.dt = cfg->dt; p.tol = cfg->tol > 0 ? cfg->tol : 1e-8; p.mu_init = cfg->mu_init > 0 ? cfg->mu_init : 1.0;
+    for (int r = 0; r < 2; r++) {
+        for (int j = 0; j < 5; j++) { p.ulim[r][j] = cfg->ulim[r][j]; p.dulim[r][j] = cfg->dulim[r][j]; }
+        for (int j = 0; j < 9; j++) p.xlim[r][j] = cfg->xlim[r][j];
+    }
+    default_weights(h);
+    const MmpcLayout L = cfg->kind == MMPC_KIND_WHOLEBODY ? mmpc_layout<0>(cfg->N, cfg->M, p.obs_per_stage)
+                                                          : mmpc_layout<1>(cfg->N, cfg->M, p.obs_per_stage);
+    h->lds_bytes = L.total * (int)sizeof(double);
+    if (h->lds_bytes > 160 * 1024) return fail(h, MMPC_E_ARG, "problem needs %s bytes of LDS%s", "more than 163840");
+    if (cfg->kind == MMPC_KIND_WHOLEBODY)
+        HIPCHK(h, hipFuncSetAttribute((const void *)mmpc_solve_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes));
+    else
+        HIPCHK(h, hipFuncSetAttribute((const void *)mmpc_solve_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes));
+    const size_t B = (size_t)cfg->max_batch, N = (size_t)cfg->N, nx = (size_t)h->nx, nu = (size_t)h->nu;
+    const size_t nobs = (size_t)(p.obs_per_stage ? N + 1 : 1) * (size_t)cfg->M * 3;
+    HIPCHK(h, hipMalloc(&h->dp, sizeof(MmpcParams)));
+    HIPCHK(h, hipMalloc(&h->d_x_init, B * nx * 8));
+    HIPCHK(h, hipMalloc(&h->d_traj, B * (N + 1) * nx * 8));
+    HIPCHK(h, hipMalloc(&h->d_uref, B * N * nu * 8));
+    HIPCHK(h, hipMalloc(&h->d_obs, (B * nobs + 1) * 8));
+    HIPCHK(h, hipMalloc(&h->d_ulatest, B * N * nu * 8));
+    HIPCHK(h, hipMalloc(&h->d_xguess, B * (N + 1) * nx * 8));
+    HIPCHK(h, hipMalloc(&h->d_X, B * (N + 1) * nx * 8));
+    HIPCHK(h, hipMalloc(&h->d_U, B * N * nu * 8));
+    HIPCHK(h, hipMalloc(&h->d_s, B * (N + 1) * 8));
+    HIPCHK(h, hipMalloc(&h->d_cost, B * 8));
+    HIPCHK(h, hipMalloc(&h->d_err, B * 8));
+    HIPCHK(h, hipMalloc(&h->d_u0, B * nu * 8));
+    HIPCHK(h, hipMalloc(&h->d_status, B * 4));
+    HIPCHK(h, hipMalloc(&h->d_iters, B * 4));
+    HIPCHK(h, hipMemset(h->d_ulatest, 0, B * N * nu * 8));
+    int rc = upload_params(h);
+    if (rc) return rc;
+    h->err[0] = 0;
+    return MMPC_OK;
+}
+
+extern "C" int mmpc_destroy(mmpc_handle h) {
+    if (!h) return MMPC_E_ARG;
+    void *ptrs[] = {h->dp, h->d_x_init, h->d_traj, h->d_uref, h->d_obs, h->d_ulatest, h->d_xguess, h->d_X, h->d_U,
+                    h->d_s, h->d_cost, h->d_err, h->d_u0, h->d_status, h->d_iters};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    delete h;
+    return MMPC_OK;
+}
+
+extern "C" int mmpc_set_weights(mmpc_handle h, const double *Q, const double *R, const double *P, double S, const double *W) {
+    if (!h) return MMPC_E_ARG;
+    const int nx = h->nx, nu = h->nu;
+    MmpcParams &p = h->hp;
+    if (Q) for (int i = 0; i < nx; i++) for (int j = 0; j < nx; j++) p.Q2[i * nx + j] = Q[i * nx + j] + Q[j * nx + i];
+    if (P) for (int i = 0; i < nx; i++) for (int j = 0; j < nx; j++) p.P2[i * nx + j] = P[i * nx + j] + P[j * nx + i];
+    if (R) for (int i = 0; i < nu; i++) for (int j = 0; j < nu; j++) p.R2[i * nu + j] = R[i * nu + j] + R[j * nu + i];
+    if (W) for (int i = 0; i < nu; i++) for (int j = 0; j < nu; j++) p.W2[i * nu + j] = W[i * nu + j] + W[j * nu + i];
+    if (S >= 0) p.S = S;
+    for (int i = 0; i < nu * nu; i++) p.RW2[i] = p.R2[i] + p.W2[i];
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    return upload_params(h);
+}
+
+extern "C" int mmpc_set_terminal_xy_equality(mmpc_handle h, int on) {
+    if (!h) return MMPC_E_ARG;
+    if (on) return fail(h, MMPC_E_UNSUPPORTED, "terminal xy equality (interface_wholebody_qref.py:166-167) %s%s", "is not implemented yet");
+    h->hp.terminal_xy_eq = 0;
+    return MMPC_OK;
+}
+
+extern "C" int mmpc_reset(mmpc_handle h) {
+    if (!h) return MMPC_E_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const size_t n = (size_t)h->cfg.max_batch * h->cfg.N * h->nu * 8;
+    HIPCHK(h, hipMemset(h->d_ulatest, 0, n));
+    h->warm = 0;
+    return MMPC_OK;
+}
+
+static int launch(mmpc_handle h, int B, const double *x_init, const double *traj, const double *uref, const double *ulast,
+                  const double *xguess, const double *obs, double *X, double *U, double *s, int *status, int *iters,
+                  double *cost, double *err, hipStream_t st) {
+    // use_xguess is a launch-time property: keep the device params in sync
+    const int want = xguess ? 1 : 0;
+    if (h->hp.use_xguess != want) {
+        h->hp.use_xguess = want;
+        HIPCHK(h, hipMemcpyAsync(h->dp, &h->hp, sizeof(MmpcParams), hipMemcpyHostToDevice, st));
+    }
+    if (h->cfg.kind == MMPC_KIND_WHOLEBODY)
+        hipLaunchKernelGGL(mmpc_solve_kernel<0>, dim3(B), dim3(MMPC_WAVE), h->lds_bytes, st, h->dp, B, x_init, traj, uref,
+                           ulast, xguess, obs, X, U, s, status, iters, cost, err);
+    else
+        hipLaunchKernelGGL(mmpc_solve_kernel<1>, dim3(B), dim3(MMPC_WAVE), h->lds_bytes, st, h->dp, B, x_init, traj, uref,
+                           ulast, xguess, obs, X, U, s, status, iters, cost, err);
+    HIPCHK(h, hipGetLastError());
+    return MMPC_OK;
+}
+
+extern "C" int mmpc_solve_batch_device(mmpc_handle h, int B, const double *d_x_init, const double *d_traj_ref,
+                                       const double *d_u_ref, const double *d_u_last, const double *d_x_guess,
+                                       const double *d_obs, double *d_X, double *d_U, double *d_s, int *d_status,
+                                       int *d_iters, double *d_cost, double *d_err, void *stream) {
+    if (!h || B < 1 || !d_x_init || !d_traj_ref || !d_u_ref || !d_u_last || !d_X || !d_U || !d_s || !d_status ||
+        !d_iters || !d_cost || !d_err || (h->cfg.M > 0 && !d_obs))
+        return fail(h, MMPC_E_ARG, "mmpc_solve_batch_device: %s%s", "bad argument");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    return launch(h, B, d_x_init, d_traj_ref, d_u_ref, d_u_last, d_x_guess, d_obs ? d_obs : h->d_obs, d_X, d_U, d_s,
+                  d_status, d_iters, d_cost, d_err, (hipStream_t)stream);
+}
+
+extern "C" int mmpc_solve_batch(mmpc_handle h, int B, const double *x_init, const double *traj_ref, const double *u_ref,
+                                const double *obs, double *out_u0, double *out_X, double *out_U, double *out_s,
+                                int *out_status, int *out_iters, double *out_cost) {
+    if (!h || B < 1 || B > h->cfg.max_batch || !x_init || !traj_ref || !u_ref || !out_u0 || (h->cfg.M > 0 && !obs))
+        return fail(h, MMPC_E_ARG, "mmpc_solve_batch: %s%s", "bad argument (B must be in 1..max_batch)");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const size_t N = (size_t)h->cfg.N, nx = (size_t)h->nx, nu = (size_t)h->nu, b = (size_t)B;
+    const size_t nobs = (size_t)(h->hp.obs_per_stage ? N + 1 : 1) * (size_t)h->cfg.M * 3;
+    hipStream_t st = 0;
+    HIPCHK(h, hipMemcpyAsync(h->d_x_init, x_init, b * nx * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(h, hipMemcpyAsync(h->d_traj, traj_ref, b * (N + 1) * nx * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(h, hipMemcpyAsync(h->d_uref, u_ref, b * N * nu * 8, hipMemcpyHostToDevice, st));
+    if (nobs) HIPCHK(h, hipMemcpyAsync(h->d_obs, obs, b * nobs * 8, hipMemcpyHostToDevice, st));
+    // base kind warm-starts X as well (mpc_base.py:194-201); whole-body never does (:301-302)
+    const double *xg = (h->cfg.kind == MMPC_KIND_BASE && h->warm) ? h->d_xguess : nullptr;
+    int rc = launch(h, B, h->d_x_init, h->d_traj, h->d_uref, h->d_ulatest, xg, h->d_obs, h->d_X, h->d_U, h->d_s,
+                    h->d_status, h->d_iters, h->d_cost, h->d_err, st);
+    if (rc) return rc;
+    // u_latest <- U*, x_guess <- X*  (:329-330)
+    HIPCHK(h, hipMemcpyAsync(h->d_ulatest, h->d_U, b * N * nu * 8, hipMemcpyDeviceToDevice, st));
+    HIPCHK(h, hipMemcpyAsync(h->d_xguess, h->d_X, b * (N + 1) * nx * 8, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(mmpc_gather_u0, dim3((B * (int)nu + 255) / 256), dim3(256), 0, st, B, (int)nu, (int)(N * nu), h->d_U, h->d_u0);
+    HIPCHK(h, hipMemcpyAsync(out_u0, h->d_u0, b * nu * 8, hipMemcpyDeviceToHost, st));
+    if (out_X) HIPCHK(h, hipMemcpyAsync(out_X, h->d_X, b * (N + 1) * nx * 8, hipMemcpyDeviceToHost, st));
+    if (out_U) HIPCHK(h, hipMemcpyAsync(out_U, h->d_U, b * N * nu * 8, hipMemcpyDeviceToHost, st));
+    if (out_s) HIPCHK(h, hipMemcpyAsync(out_s, h->d_s, b * (N + 1) * 8, hipMemcpyDeviceToHost, st));
+    if (out_status) HIPCHK(h, hipMemcpyAsync(out_status, h->d_status, b * 4, hipMemcpyDeviceToHost, st));
+    if (out_iters) HIPCHK(h, hipMemcpyAsync(out_iters, h->d_iters, b * 4, hipMemcpyDeviceToHost, st));
+    if (out_cost) HIPCHK(h, hipMemcpyAsync(out_cost, h->d_cost, b * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    h->warm = 1;
+    return MMPC_OK;
+}
+
+extern "C" int mmpc_get_u_latest(mmpc_handle h, int B, double *u_latest) {
+    if (!h || !u_latest || B < 1 || B > h->cfg.max_batch) return MMPC_E_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipMemcpy(u_latest, h->d_ulatest, (size_t)B * h->cfg.N * h->nu * 8, hipMemcpyDeviceToHost));
+    return MMPC_OK;
+}
+extern "C" int mmpc_set_u_latest(mmpc_handle h, int B, const double *u_latest) {
+    if (!h || !u_latest || B < 1 || B > h->cfg.max_batch) return MMPC_E_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipMemcpy(h->d_ulatest, u_latest, (size_t)B * h->cfg.N * h->nu * 8, hipMemcpyHostToDevice));
+    return MMPC_OK;
+}

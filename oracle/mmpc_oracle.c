@@ -1,0 +1,622 @@
+/*
+ * mmpc_oracle.c - scalar C (fp64) restatement of the MPC hot path, CPU only.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load the library built from this file, and only as the
+ * checker / reported CPU baseline ("port").  The product library
+ * (mobile-manipulator-mpc_amd/csrc) never links or calls it.
+ *
+ * What it restates (paths relative to /root/reference):
+ *   - the NLP the reference builds in MPCWholeBody.reset()
+ *     (controllers/mpc_wholebody_qref.py:142-285) and MPCBase.reset()
+ *     (controllers/mpc_base.py:114-189): dynamics robot_models/base.py:17-26,
+ *     robot_models/manipulator_3DoF.py:189-191, robot_models/mobile_manipulator.py:57-75;
+ *     forward kinematics manipulator_3DoF.py:10-77 + mobile_manipulator.py:17-55;
+ *     circle rows mpc_wholebody_qref.py:49-54; self-collision rows :219-222,:261-265
+ *     (incl. the s[N-1] quirk of :265); boxes :203-205,:245;
+ *   - the per-tick protocol of solve() (mpc_wholebody_qref.py:287-331, mpc_base.py:191-226).
+ * The reference hands that NLP to CasADi 3.6.4 -> IPOPT -> MUMPS (requirements.txt:9), which
+ * is not in this image; the solver below is the build's own interior-point method - the same
+ * algorithm as oracle/ipm_numpy.py and the HIP kernels, written independently of the latter as
+ * straightforward dense scalar code.
+ *
+ * PARITY STATUS: model functions pinned by tests/golden (reference robot_models + sympy DH);
+ * solve() output of the reference is UNPINNED (no executable IPOPT here, no reference tests);
+ * certified by KKT residuals (oracle/nlp.py:kkt_certificate) and scipy SLSQP (oracle/xcheck.py).
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define NXM 9
+#define NUM 5
+#define NSM 65          /* max stages (N+1) */
+#define MMX 16          /* max circle obstacles */
+#define RMX (2 * NUM + 2 * NXM + MMX + 4)
+#define FCAP 16
+
+typedef struct {
+    int kind;            /* 0 whole-body (nx=9,nu=5), 1 base-only (nx=6,nu=2) */
+    int N, M;
+    int obs_per_stage;   /* 0: obs[M][3]; 1: obs[N+1][M][3] */
+    int terminal_xy_eq;
+    double dt;
+    double Q[NXM * NXM], P[NXM * NXM], R[NUM * NUM], W[NUM * NUM], S;
+    double ulim[2][NUM], xlim[2][NXM], dulim[2][NUM];
+    double tol, mu_init;
+    int max_iter;
+} oracle_cfg;
+
+/* robot_models/manipulator_3DoF.py:18-22, mobile_manipulator.py:14-15, base.py:15,
+ * mpc_wholebody_qref.py:43 */
+static const double A2 = 0.316, A3 = 0.0825, A5 = 0.384, A6 = 0.088, A7 = 0.107;
+static const double BX = -0.007, BZ = 0.606 + 0.333, BASE_R = 0.4, SELF_R = 0.05;
+
+/* ------------------------------------------------------------------ model */
+static void f_dyn(int kind, double dt, const double *x, const double *u, double *xn) {
+    /* base.py:19-26 */
+    double c = cos(x[2]), s = sin(x[2]);
+    xn[0] = x[0] + dt * x[3];
+    xn[1] = x[1] + dt * x[4];
+    xn[2] = x[2] + dt * x[5];
+    xn[3] = x[3] + dt * (u[0] * c - x[4] * x[5]);
+    xn[4] = x[4] + dt * (u[0] * s + x[3] * x[5]);
+    xn[5] = x[5] + dt * u[1];
+    if (kind == 0) { /* manipulator_3DoF.py:190 */
+        xn[6] = x[6] + dt * u[2];
+        xn[7] = x[7] + dt * u[3];
+        xn[8] = x[8] + dt * u[4];
+    }
+}
+
+static void f_jac(int kind, double dt, const double *x, const double *u, double A[NXM][NXM], double B[NXM][NUM]) {
+    int nx = kind == 0 ? 9 : 6;
+    memset(A, 0, sizeof(double) * NXM * NXM);
+    memset(B, 0, sizeof(double) * NXM * NUM);
+    for (int i = 0; i < nx; i++) A[i][i] = 1.0;
+    double c = cos(x[2]), s = sin(x[2]);
+    A[0][3] = dt; A[1][4] = dt; A[2][5] = dt;
+    A[3][2] = -dt * u[0] * s; A[3][4] = -dt * x[5]; A[3][5] = -dt * x[4];
+    A[4][2] = dt * u[0] * c;  A[4][3] = dt * x[5];  A[4][5] = dt * x[3];
+    B[3][0] = dt * c; B[4][0] = dt * s; B[5][1] = dt;
+    if (kind == 0) { B[6][2] = dt; B[7][3] = dt; B[8][4] = dt; }
+}
+
+/* planar segments of the arm, manipulator_3DoF.py:29-73 collapsed */
+static void arm_segments(const double *q, double drho[3], double dzet[3]) {
+    double a = q[0] - q[1], b = q[0] - q[1] - q[2];
+    double s1 = sin(q[0]), c1 = cos(q[0]), sA = sin(a), cA = cos(a), sB = sin(b), cB = cos(b);
+    drho[0] = A2 * s1 + A3 * c1;   dzet[0] = A2 * c1 - A3 * s1;
+    drho[1] = -A3 * cA + A5 * sA;  dzet[1] = A3 * sA + A5 * cA;
+    drho[2] = A6 * cB - A7 * sB;   dzet[2] = -A6 * sB - A7 * cB;
+}
+
+/* world FK, mobile_manipulator.py:17-55: out e[4], j2[3], j3[3] */
+void mmpc_oracle_fk(const double *x, double *e, double *j2, double *j3) {
+    double dr[3], dz[3];
+    arm_segments(x + 6, dr, dz);
+    double c = cos(x[2]), s = sin(x[2]);
+    double r2 = dr[0], z2 = dz[0], r3 = r2 + dr[1], z3 = z2 + dz[1], re = r3 + dr[2], ze = z3 + dz[2];
+    j2[0] = x[0] + (r2 + BX) * c; j2[1] = x[1] + (r2 + BX) * s; j2[2] = z2 + BZ;
+    j3[0] = x[0] + (r3 + BX) * c; j3[1] = x[1] + (r3 + BX) * s; j3[2] = z3 + BZ;
+    e[0] = x[0] + (re + BX) * c;  e[1] = x[1] + (re + BX) * s;  e[2] = ze + BZ; e[3] = x[2];
+}
+
+void mmpc_oracle_f(int kind, double dt, const double *x, const double *u, double *xn) { f_dyn(kind, dt, x, u, xn); }
+
+static const double SEGC[3][3] = {{1, 0, 0}, {1, -1, 0}, {1, -1, -1}};
+static const double AB_SELF[4][2] = {{0, 0}, {0.5, 0}, {1, 0}, {0.5, 0.5}};
+static const int YIDX[6] = {0, 1, 2, 6, 7, 8};
+
+/* self-collision row i: h = 0.05 - ||alpha j2 + beta j3 - e||  (mpc_wholebody_qref.py:219-222);
+ * g6 = dh/d(x,y,psi,q1,q2,q3) */
+static double self_row(const double *x, int i, double *g6) {
+    double al = AB_SELF[i][0], be = AB_SELF[i][1], kap = al + be - 1.0;
+    double cm[3] = {kap, be - 1.0, -1.0};
+    double dr[3], dz[3];
+    arm_segments(x + 6, dr, dz);
+    double R = kap * BX, Z = kap * BZ;
+    for (int m = 0; m < 3; m++) { R += cm[m] * dr[m]; Z += cm[m] * dz[m]; }
+    double px = x[0], py = x[1], c = cos(x[2]), s = sin(x[2]);
+    double C = px * c + py * s, D = -px * s + py * c;
+    double mm = kap * kap * (px * px + py * py) + 2 * kap * R * C + R * R + Z * Z;
+    double n = sqrt(mm);
+    if (g6) {
+        double Ri[3] = {0, 0, 0}, Zi[3] = {0, 0, 0};
+        for (int m = 0; m < 3; m++)
+            for (int j = 0; j < 3; j++) { Ri[j] += cm[m] * dz[m] * SEGC[m][j]; Zi[j] -= cm[m] * dr[m] * SEGC[m][j]; }
+        double gm[6];
+        gm[0] = 2 * kap * kap * px + 2 * kap * R * c;
+        gm[1] = 2 * kap * kap * py + 2 * kap * R * s;
+        gm[2] = 2 * kap * R * D;
+        for (int j = 0; j < 3; j++) gm[3 + j] = 2 * (kap * C + R) * Ri[j] + 2 * Z * Zi[j];
+        for (int j = 0; j < 6; j++) g6[j] = -gm[j] / (2 * n);
+    }
+    return SELF_R - n;
+}
+
+/* circle row: g = (r+0.4) - dist  (mpc_wholebody_qref.py:53); grad (2), hess (xx,xy,yy) */
+static double circ_row(const double *x, const double *o, double *g2, double *h3) {
+    double dx = x[0] - o[0], dy = x[1] - o[1], d = sqrt(dx * dx + dy * dy);
+    if (g2) { g2[0] = -dx / d; g2[1] = -dy / d; }
+    if (h3) {
+        double nx_ = dx / d, ny_ = dy / d;
+        h3[0] = -(1 - nx_ * nx_) / d; h3[1] = nx_ * ny_ / d; h3[2] = -(1 - ny_ * ny_) / d;
+    }
+    return (o[2] + BASE_R) - d;
+}
+
+static double angle_diff(double a, double b) { /* mpc_base.py:56-94 */
+    a = fmod(a + M_PI, 2 * M_PI) - M_PI;
+    b = fmod(b + M_PI, 2 * M_PI) - M_PI;
+    double d = a - b;
+    if (a * b >= 0) return d;
+    if (a > b) return d <= M_PI ? d : d - 2 * M_PI;
+    return d > -M_PI ? d : d + 2 * M_PI;
+}
+double mmpc_oracle_angle_diff(double a, double b) { return angle_diff(a, b); }
+
+/* ------------------------------------------------------------ solver state */
+typedef struct {
+    const oracle_cfg *cfg;
+    int nx, nu, N, M, nrow; /* nrow = slots per stage */
+    const double *xinit, *xref, *uref, *ulast, *obs;
+    double X[NSM][NXM], U[NSM][NUM], s[NSM], lam[NSM][NXM];
+    double t[NSM][RMX], z[NSM][RMX], bnd[NSM][RMX];
+    int act[NSM][RMX];
+    /* evaluation */
+    double h[NSM][RMX];
+    double gcirc[NSM][MMX][2], hcirc[NSM][MMX][3], gself[NSM][4][6];
+    double A[NSM][NXM][NXM], B[NSM][NXM][NUM], c[NSM][NXM];
+    double gX[NSM][NXM], gU[NSM][NUM], gs[NSM];
+    /* QP */
+    double Hxx[NSM][NXM][NXM], Hux[NSM][NUM][NXM], Huu[NSM][NUM][NUM], qx[NSM][NXM], qu[NSM][NUM];
+    double hss[NSM], gss[NSM], vx[NSM][NXM], vxN[NXM];
+    double K[NSM][NUM][NXM], kf[NSM][NUM];
+    double dX[NSM][NXM], dU[NSM][NUM], ds[NSM], lamn[NSM][NXM];
+    double dt_[NSM][RMX], dz[NSM][RMX];
+    double Q2[NXM][NXM], P2[NXM][NXM], RW2[NUM][NUM];
+} work;
+
+static const double *obs_at(const work *w, int k, int m) {
+    return w->cfg->obs_per_stage ? w->obs + ((size_t)k * w->M + m) * 3 : w->obs + (size_t)m * 3;
+}
+/* slot layout: [0,nu) u-lo, [nu,2nu) u-hi, then x-lo (nx), x-hi (nx), circ (M), self (4) */
+#define SL_ULO(w, j) (j)
+#define SL_UHI(w, j) ((w)->nu + (j))
+#define SL_XLO(w, j) (2 * (w)->nu + (j))
+#define SL_XHI(w, j) (2 * (w)->nu + (w)->nx + (j))
+#define SL_CIRC(w, m) (2 * (w)->nu + 2 * (w)->nx + (m))
+#define SL_SELF(w, i) (2 * (w)->nu + 2 * (w)->nx + (w)->M + (i))
+
+static int slack_idx(const work *w, int k) { return k < w->N - 1 ? k : w->N - 1; } /* :265 quirk */
+
+static void setup_rows(work *w) {
+    const oracle_cfg *c = w->cfg;
+    for (int k = 0; k <= w->N; k++) {
+        for (int r = 0; r < w->nrow; r++) { w->act[k][r] = 0; w->bnd[k][r] = 0; }
+        if (k < w->N)
+            for (int j = 0; j < w->nu; j++) {
+                /* merged box: ulim (:203) and u_last + dulim (:205) bound the same variable */
+                double lo = c->ulim[0][j], hi = c->ulim[1][j];
+                double l2 = w->ulast[k * w->nu + j] + c->dulim[0][j], h2 = w->ulast[k * w->nu + j] + c->dulim[1][j];
+                if (l2 > lo) lo = l2;
+                if (h2 < hi) hi = h2;
+                if (isfinite(lo)) { w->act[k][SL_ULO(w, j)] = 1; w->bnd[k][SL_ULO(w, j)] = lo; }
+                if (isfinite(hi)) { w->act[k][SL_UHI(w, j)] = 1; w->bnd[k][SL_UHI(w, j)] = hi; }
+            }
+        if (k >= 1)
+            for (int j = 0; j < w->nx; j++) {
+                if (isfinite(c->xlim[0][j])) { w->act[k][SL_XLO(w, j)] = 1; w->bnd[k][SL_XLO(w, j)] = c->xlim[0][j]; }
+                if (isfinite(c->xlim[1][j])) { w->act[k][SL_XHI(w, j)] = 1; w->bnd[k][SL_XHI(w, j)] = c->xlim[1][j]; }
+            }
+        for (int m = 0; m < w->M; m++) w->act[k][SL_CIRC(w, m)] = 1;
+        if (c->kind == 0) for (int i = 0; i < 4; i++) w->act[k][SL_SELF(w, i)] = 1;
+    }
+}
+
+/* row values at (X,U,s); with_deriv also fills gcirc/hcirc/gself */
+static void eval_rows(work *w, double X[NSM][NXM], double U[NSM][NUM], const double *s, double h[NSM][RMX], int with_deriv) {
+    for (int k = 0; k <= w->N; k++) {
+        if (k < w->N)
+            for (int j = 0; j < w->nu; j++) {
+                if (w->act[k][SL_ULO(w, j)]) h[k][SL_ULO(w, j)] = w->bnd[k][SL_ULO(w, j)] - U[k][j];
+                if (w->act[k][SL_UHI(w, j)]) h[k][SL_UHI(w, j)] = U[k][j] - w->bnd[k][SL_UHI(w, j)];
+            }
+        for (int j = 0; j < w->nx; j++) {
+            if (w->act[k][SL_XLO(w, j)]) h[k][SL_XLO(w, j)] = w->bnd[k][SL_XLO(w, j)] - X[k][j];
+            if (w->act[k][SL_XHI(w, j)]) h[k][SL_XHI(w, j)] = X[k][j] - w->bnd[k][SL_XHI(w, j)];
+        }
+        for (int m = 0; m < w->M; m++)
+            h[k][SL_CIRC(w, m)] = circ_row(X[k], obs_at(w, k, m), with_deriv ? w->gcirc[k][m] : 0,
+                                            with_deriv ? w->hcirc[k][m] : 0) - s[k];
+        if (w->cfg->kind == 0)
+            for (int i = 0; i < 4; i++)
+                h[k][SL_SELF(w, i)] = self_row(X[k], i, with_deriv ? w->gself[k][i] : 0) - s[slack_idx(w, k)];
+    }
+}
+
+static void state_err(const work *w, const double *xk, const double *ref, double *e) {
+    for (int j = 0; j < w->nx; j++) e[j] = xk[j] - ref[j];
+    if (w->cfg->kind == 1) e[2] = angle_diff(xk[2], ref[2]); /* mpc_base.py:148 */
+}
+
+static double cost_fn(const work *w, double X[NSM][NXM], double U[NSM][NUM], const double *s) {
+    /* mpc_wholebody_qref.py:199-201,227,242,270 */
+    const oracle_cfg *c = w->cfg;
+    int nx = w->nx, nu = w->nu;
+    double J = 0, e[NXM], a[NUM], b[NUM];
+    for (int k = 0; k <= w->N; k++) {
+        const double *Wt = k < w->N ? c->Q : c->P;
+        state_err(w, X[k], w->xref + k * nx, e);
+        for (int i = 0; i < nx; i++) for (int j = 0; j < nx; j++) J += e[i] * Wt[i * nx + j] * e[j];
+        J += c->S * s[k] * s[k];
+        if (k < w->N) {
+            for (int j = 0; j < nu; j++) { a[j] = U[k][j] - w->uref[k * nu + j]; b[j] = U[k][j] - w->ulast[k * nu + j]; }
+            for (int i = 0; i < nu; i++) for (int j = 0; j < nu; j++)
+                J += a[i] * c->R[i * nu + j] * a[j] + b[i] * c->W[i * nu + j] * b[j];
+        }
+    }
+    return J;
+}
+
+/* barrier objective and l1 infeasibility at a trial point */
+static void merit_parts(work *w, double X[NSM][NXM], double U[NSM][NUM], const double *s, double t[NSM][RMX],
+                        double mu, double *phi, double *th) {
+    static __thread double h[NSM][RMX];
+    eval_rows(w, X, U, s, h, 0);
+    double f = cost_fn(w, X, U, s), bar = 0, theta = 0, xn[NXM];
+    for (int k = 0; k < w->N; k++) {
+        f_dyn(w->cfg->kind, w->cfg->dt, X[k], U[k], xn);
+        for (int j = 0; j < w->nx; j++) theta += fabs(xn[j] - X[k + 1][j]);
+    }
+    for (int k = 0; k <= w->N; k++)
+        for (int r = 0; r < w->nrow; r++)
+            if (w->act[k][r]) { theta += fabs(h[k][r] + t[k][r]); bar -= mu * log(t[k][r]); }
+    *phi = f + bar;
+    *th = theta;
+}
+
+/* Cholesky of n x n (row-major, leading dim NUM); returns 0 if a pivot is not > 0 */
+static int chol(double H[NUM][NUM], int n, double L[NUM][NUM]) {
+    memset(L, 0, sizeof(double) * NUM * NUM);
+    for (int j = 0; j < n; j++) {
+        double d = H[j][j];
+        for (int k = 0; k < j; k++) d -= L[j][k] * L[j][k];
+        if (!(d > 0.0) || !isfinite(d)) return 0;
+        L[j][j] = sqrt(d);
+        for (int i = j + 1; i < n; i++) {
+            double v = H[i][j];
+            for (int k = 0; k < j; k++) v -= L[i][k] * L[j][k];
+            L[i][j] = v / L[j][j];
+        }
+    }
+    return 1;
+}
+static void chol_solve(double L[NUM][NUM], int n, double *b) {
+    for (int i = 0; i < n; i++) { double v = b[i]; for (int k = 0; k < i; k++) v -= L[i][k] * b[k]; b[i] = v / L[i][i]; }
+    for (int i = n - 1; i >= 0; i--) { double v = b[i]; for (int k = i + 1; k < n; k++) v -= L[k][i] * b[k]; b[i] = v / L[i][i]; }
+}
+
+/* stage QP assembly + s Schur complement + Riccati factorisation.  returns 0 on a failed pivot */
+static int factor(work *w, double mu, int use_exact) {
+    const oracle_cfg *c = w->cfg;
+    int nx = w->nx, nu = w->nu, N = w->N;
+    for (int k = 0; k <= N; k++) { w->hss[k] = 2 * c->S; w->gss[k] = w->gs[k]; memset(w->vx[k], 0, sizeof(w->vx[k])); }
+    memset(w->vxN, 0, sizeof(w->vxN));
+    for (int k = 0; k <= N; k++) {
+        for (int i = 0; i < nx; i++) { for (int j = 0; j < nx; j++) w->Hxx[k][i][j] = k < N ? w->Q2[i][j] : w->P2[i][j]; w->qx[k][i] = w->gX[k][i]; }
+        if (k < N) {
+            for (int i = 0; i < nu; i++) { for (int j = 0; j < nu; j++) w->Huu[k][i][j] = w->RW2[i][j]; w->qu[k][i] = w->gU[k][i]; for (int j = 0; j < nx; j++) w->Hux[k][i][j] = 0; }
+            if (use_exact) {
+                /* - sum_j lam_{k+1,j} d2 f_j : only f3, f4 (base.py:23-24) are nonlinear */
+                double sn = sin(w->X[k][2]), cs = cos(w->X[k][2]), l3 = w->lam[k + 1][3], l4 = w->lam[k + 1][4], dt = c->dt;
+                w->Hxx[k][2][2] -= dt * w->U[k][0] * (-l3 * cs - l4 * sn);
+                w->Hxx[k][4][5] -= -dt * l3; w->Hxx[k][5][4] -= -dt * l3;
+                w->Hxx[k][3][5] -= dt * l4;  w->Hxx[k][5][3] -= dt * l4;
+                w->Hux[k][0][2] -= dt * (-l3 * sn + l4 * cs);
+            }
+        }
+        for (int r = 0; r < w->nrow; r++) {
+            if (!w->act[k][r]) continue;
+            double tt = w->t[k][r], zz = w->z[k][r], wt = zz / tt, rh = w->h[k][r] + tt, zh = mu / tt + wt * rh;
+            if (r < 2 * nu) {
+                int j = r < nu ? r : r - nu; double sg = r < nu ? -1.0 : 1.0;
+                w->Huu[k][j][j] += wt; w->qu[k][j] += sg * zh;
+            } else if (r < 2 * nu + 2 * nx) {
+                int q = r - 2 * nu; int j = q < nx ? q : q - nx; double sg = q < nx ? -1.0 : 1.0;
+                w->Hxx[k][j][j] += wt; w->qx[k][j] += sg * zh;
+            } else {
+                int ks; double jx[NXM]; memset(jx, 0, sizeof(jx));
+                if (r < 2 * nu + 2 * nx + w->M) {
+                    int m = r - 2 * nu - 2 * nx; ks = k;
+                    jx[0] = w->gcirc[k][m][0]; jx[1] = w->gcirc[k][m][1];
+                    if (use_exact) {
+                        w->Hxx[k][0][0] += zz * w->hcirc[k][m][0]; w->Hxx[k][0][1] += zz * w->hcirc[k][m][1];
+                        w->Hxx[k][1][0] += zz * w->hcirc[k][m][1]; w->Hxx[k][1][1] += zz * w->hcirc[k][m][2];
+                    }
+                } else {
+                    int i = r - 2 * nu - 2 * nx - w->M; ks = slack_idx(w, k);
+                    for (int j = 0; j < 6; j++) jx[YIDX[j]] = w->gself[k][i][j];
+                }
+                for (int i = 0; i < nx; i++) { for (int j = 0; j < nx; j++) w->Hxx[k][i][j] += wt * jx[i] * jx[j]; w->qx[k][i] += jx[i] * zh; }
+                w->hss[ks] += wt; w->gss[ks] -= zh;
+                if (ks == k) for (int i = 0; i < nx; i++) w->vx[k][i] += wt * jx[i];
+                else for (int i = 0; i < nx; i++) w->vxN[i] += wt * jx[i];
+            }
+        }
+    }
+    /* Schur complement of s_k (H_xs = -v) */
+    for (int k = 0; k <= N; k++) {
+        double a[NXM], b[NUM], gam = w->gss[k], ih = 1.0 / w->hss[k];
+        for (int i = 0; i < nx; i++) a[i] = w->vx[k][i];
+        for (int i = 0; i < nu; i++) b[i] = 0;
+        if (k == N - 1) {
+            for (int i = 0; i < nx; i++) for (int j = 0; j < nx; j++) a[i] += w->A[k][j][i] * w->vxN[j];
+            for (int i = 0; i < nu; i++) for (int j = 0; j < nx; j++) b[i] += w->B[k][j][i] * w->vxN[j];
+            for (int j = 0; j < nx; j++) gam -= w->vxN[j] * w->c[k][j];
+        }
+        for (int i = 0; i < nx; i++) { for (int j = 0; j < nx; j++) w->Hxx[k][i][j] -= a[i] * a[j] * ih; w->qx[k][i] += a[i] * gam * ih; }
+        if (k == N - 1)
+            for (int i = 0; i < nu; i++) {
+                for (int j = 0; j < nx; j++) w->Hux[k][i][j] -= b[i] * a[j] * ih;
+                for (int j = 0; j < nu; j++) w->Huu[k][i][j] -= b[i] * b[j] * ih;
+                w->qu[k][i] += b[i] * gam * ih;
+            }
+    }
+    /* Riccati: P_k, p_k overwrite Hxx[k], qx[k] */
+    for (int k = N - 1; k >= 0; k--) {
+        double (*P)[NXM] = w->Hxx[k + 1]; double *p = w->qx[k + 1];
+        double PA[NXM][NXM], PB[NXM][NUM], pc[NXM];
+        for (int i = 0; i < nx; i++) {
+            for (int j = 0; j < nx; j++) { double v = 0; for (int l = 0; l < nx; l++) v += P[i][l] * w->A[k][l][j]; PA[i][j] = v; }
+            for (int j = 0; j < nu; j++) { double v = 0; for (int l = 0; l < nx; l++) v += P[i][l] * w->B[k][l][j]; PB[i][j] = v; }
+            double v = p[i]; for (int l = 0; l < nx; l++) v += P[i][l] * w->c[k][l]; pc[i] = v;
+        }
+        double F[NXM][NXM], G[NUM][NXM], Hh[NUM][NUM], gx[NXM], gu[NUM];
+        for (int i = 0; i < nx; i++) {
+            for (int j = 0; j < nx; j++) { double v = w->Hxx[k][i][j]; for (int l = 0; l < nx; l++) v += w->A[k][l][i] * PA[l][j]; F[i][j] = v; }
+            double v = w->qx[k][i]; for (int l = 0; l < nx; l++) v += w->A[k][l][i] * pc[l]; gx[i] = v;
+        }
+        for (int i = 0; i < nu; i++) {
+            for (int j = 0; j < nx; j++) { double v = w->Hux[k][i][j]; for (int l = 0; l < nx; l++) v += w->B[k][l][i] * PA[l][j]; G[i][j] = v; }
+            for (int j = 0; j < nu; j++) { double v = w->Huu[k][i][j]; for (int l = 0; l < nx; l++) v += w->B[k][l][i] * PB[l][j]; Hh[i][j] = v; }
+            double v = w->qu[k][i]; for (int l = 0; l < nx; l++) v += w->B[k][l][i] * pc[l]; gu[i] = v;
+        }
+        double L[NUM][NUM];
+        if (!chol(Hh, nu, L)) return 0;
+        for (int j = 0; j < nx; j++) {
+            double col[NUM]; for (int i = 0; i < nu; i++) col[i] = G[i][j];
+            chol_solve(L, nu, col);
+            for (int i = 0; i < nu; i++) w->K[k][i][j] = -col[i];
+        }
+        { double col[NUM]; for (int i = 0; i < nu; i++) col[i] = gu[i]; chol_solve(L, nu, col); for (int i = 0; i < nu; i++) w->kf[k][i] = -col[i]; }
+        double Pn[NXM][NXM];
+        for (int i = 0; i < nx; i++) {
+            for (int j = 0; j < nx; j++) { double v = F[i][j]; for (int l = 0; l < nu; l++) v += G[l][i] * w->K[k][l][j]; Pn[i][j] = v; }
+            double v = gx[i]; for (int l = 0; l < nu; l++) v += G[l][i] * w->kf[k][l]; w->qx[k][i] = v;
+        }
+        for (int i = 0; i < nx; i++) for (int j = 0; j < nx; j++) w->Hxx[k][i][j] = 0.5 * (Pn[i][j] + Pn[j][i]);
+    }
+    return 1;
+}
+
+typedef struct { double th, phi; } fent;
+
+/*
+ * Solve one instance.  Inputs row-major: x_init[nx] (already clipped by the caller for the
+ * whole-body kind, mpc_wholebody_qref.py:290-291), traj_ref[(N+1)*nx], u_ref[N*nu],
+ * u_last[N*nu] (U_last parameter AND initial U, :303,:310), X0 (NULL => tile(x_init), :302; base
+ * kind passes the previous X, mpc_base.py:200), obs.  Outputs X,U,s; returns status
+ * (0 converged, 1 max_iter, 2 numerical failure).
+ */
+int mmpc_oracle_solve(const oracle_cfg *cfg, const double *x_init, const double *traj_ref, const double *u_ref,
+                      const double *u_last, const double *X0, const double *U0, const double *obs, double *Xo, double *Uo,
+                      double *so, int *iters_out, double *cost_out, double *err_out) {
+    work *w = (work *)calloc(1, sizeof(work));
+    if (!w) return 2;
+    w->cfg = cfg; w->N = cfg->N; w->M = cfg->M;
+    w->nx = cfg->kind == 0 ? 9 : 6; w->nu = cfg->kind == 0 ? 5 : 2;
+    int nx = w->nx, nu = w->nu, N = w->N;
+    w->nrow = 2 * nu + 2 * nx + w->M + (cfg->kind == 0 ? 4 : 0);
+    w->xinit = x_init; w->xref = traj_ref; w->uref = u_ref; w->ulast = u_last; w->obs = obs;
+    for (int i = 0; i < nx; i++) for (int j = 0; j < nx; j++) {
+        w->Q2[i][j] = cfg->Q[i * nx + j] + cfg->Q[j * nx + i]; w->P2[i][j] = cfg->P[i * nx + j] + cfg->P[j * nx + i]; }
+    for (int i = 0; i < nu; i++) for (int j = 0; j < nu; j++)
+        w->RW2[i][j] = cfg->R[i * nu + j] + cfg->R[j * nu + i] + cfg->W[i * nu + j] + cfg->W[j * nu + i];
+    for (int k = 0; k <= N; k++) {
+        for (int j = 0; j < nx; j++) w->X[k][j] = (X0 && k > 0) ? X0[k * nx + j] : x_init[j];
+        if (k < N) for (int j = 0; j < nu; j++) w->U[k][j] = U0 ? U0[k * nu + j] : u_last[k * nu + j];
+        w->s[k] = 0;
+    }
+    setup_rows(w);
+    double mu = cfg->mu_init;
+    eval_rows(w, w->X, w->U, w->s, w->h, 0);
+    int nrows_act = 0;
+    for (int k = 0; k <= N; k++) for (int r = 0; r < w->nrow; r++) if (w->act[k][r]) {
+        double v = -w->h[k][r]; w->t[k][r] = v > 1e-2 ? v : 1e-2; w->z[k][r] = mu / w->t[k][r]; nrows_act++; }
+    int status = 1, it = 0, nf = 0;
+    double th_max = 0, th_min = 0, E0 = 0;
+    fent filt[FCAP];
+    int filt_init = 0, nfilt = 0;
+    const double tol = cfg->tol;
+    static __thread double Xn[NSM][NXM], Un[NSM][NUM], sn[NSM], tn[NSM][RMX];
+    for (it = 0; it <= cfg->max_iter; it++) {
+        /* ---- evaluation at the current point */
+        eval_rows(w, w->X, w->U, w->s, w->h, 1);
+        double e[NXM];
+        for (int k = 0; k <= N; k++) {
+            const double *Wt2 = k < N ? &w->Q2[0][0] : &w->P2[0][0];
+            state_err(w, w->X[k], w->xref + k * nx, e);
+            for (int i = 0; i < nx; i++) { double v = 0; for (int j = 0; j < nx; j++) v += Wt2[i * NXM + j] * e[j]; w->gX[k][i] = v; }
+            w->gs[k] = 2 * cfg->S * w->s[k];
+            if (k < N) {
+                for (int i = 0; i < nu; i++) {
+                    double v = 0;
+                    for (int j = 0; j < nu; j++)
+                        v += (cfg->R[i * nu + j] + cfg->R[j * nu + i]) * (w->U[k][j] - w->uref[k * nu + j])
+                           + (cfg->W[i * nu + j] + cfg->W[j * nu + i]) * (w->U[k][j] - w->ulast[k * nu + j]);
+                    w->gU[k][i] = v;
+                }
+                f_jac(cfg->kind, cfg->dt, w->X[k], w->U[k], w->A[k], w->B[k]);
+                double xn[NXM]; f_dyn(cfg->kind, cfg->dt, w->X[k], w->U[k], xn);
+                for (int j = 0; j < nx; j++) w->c[k][j] = xn[j] - w->X[k + 1][j];
+            }
+        }
+        /* ---- KKT error */
+        double err_d = 0, err_p = 0, comp0 = 0, compmu = 0, zsum = 0;
+        {
+            static __thread double rdx[NSM][NXM], rdu[NSM][NUM], rds[NSM];
+            for (int k = 0; k <= N; k++) { memcpy(rdx[k], w->gX[k], sizeof(rdx[k])); memcpy(rdu[k], w->gU[k], sizeof(rdu[k])); rds[k] = w->gs[k]; }
+            for (int k = 0; k <= N; k++) for (int r = 0; r < w->nrow; r++) {
+                if (!w->act[k][r]) continue;
+                double zz = w->z[k][r], tt = w->t[k][r];
+                zsum += zz;
+                double cp = tt * zz; if (cp > comp0) comp0 = cp; if (fabs(cp - mu) > compmu) compmu = fabs(cp - mu);
+                double rh = fabs(w->h[k][r] + tt); if (rh > err_p) err_p = rh;
+                if (r < 2 * nu) { int j = r < nu ? r : r - nu; rdu[k][j] += (r < nu ? -zz : zz); }
+                else if (r < 2 * nu + 2 * nx) { int q = r - 2 * nu; int j = q < nx ? q : q - nx; rdx[k][j] += (q < nx ? -zz : zz); }
+                else if (r < 2 * nu + 2 * nx + w->M) { int m = r - 2 * nu - 2 * nx; rdx[k][0] += w->gcirc[k][m][0] * zz; rdx[k][1] += w->gcirc[k][m][1] * zz; rds[k] -= zz; }
+                else { int i = r - 2 * nu - 2 * nx - w->M; for (int j = 0; j < 6; j++) rdx[k][YIDX[j]] += w->gself[k][i][j] * zz; rds[slack_idx(w, k)] -= zz; }
+            }
+            for (int k = 0; k < N; k++) {
+                for (int i = 0; i < nx; i++) {
+                    rdx[k + 1][i] += w->lam[k + 1][i];
+                    double v = 0; for (int j = 0; j < nx; j++) v += w->A[k][j][i] * w->lam[k + 1][j]; rdx[k][i] -= v;
+                }
+                for (int i = 0; i < nu; i++) { double v = 0; for (int j = 0; j < nx; j++) v += w->B[k][j][i] * w->lam[k + 1][j]; rdu[k][i] -= v; }
+                for (int j = 0; j < nx; j++) { if (fabs(w->c[k][j]) > err_p) err_p = fabs(w->c[k][j]); zsum += fabs(w->lam[k + 1][j]); }
+            }
+            for (int k = 0; k <= N; k++) {
+                if (k > 0) for (int i = 0; i < nx; i++) if (fabs(rdx[k][i]) > err_d) err_d = fabs(rdx[k][i]);
+                if (k < N) for (int i = 0; i < nu; i++) if (fabs(rdu[k][i]) > err_d) err_d = fabs(rdu[k][i]);
+                if (fabs(rds[k]) > err_d) err_d = fabs(rds[k]);
+            }
+        }
+        double sd = zsum / (nrows_act + (N + 1) * nx); sd = (sd > 100.0 ? sd : 100.0) / 100.0;
+        E0 = fmax(fmax(err_d / sd, err_p), comp0 / sd);
+        double Emu = fmax(fmax(err_d / sd, err_p), compmu / sd);
+        if (!(E0 == E0)) { status = 2; break; }
+        if (E0 <= tol) { status = 0; break; }
+        if (it == cfg->max_iter) break;
+        int changed = 0;
+        while (Emu <= 10.0 * mu && mu > tol / 10) {
+            double m1 = 0.2 * mu, m2 = pow(mu, 1.5);
+            mu = fmax(tol / 10, fmin(m1, m2));
+            compmu = 0;
+            for (int k = 0; k <= N; k++) for (int r = 0; r < w->nrow; r++) if (w->act[k][r]) { double d = fabs(w->t[k][r] * w->z[k][r] - mu); if (d > compmu) compmu = d; }
+            Emu = fmax(fmax(err_d / sd, err_p), compmu / sd);
+            changed = 1;
+        }
+        if (changed) filt_init = 0;
+        /* ---- Newton direction */
+        if (!factor(w, mu, 1)) if (!factor(w, mu, 0)) { status = 2; break; }
+        for (int j = 0; j < nx; j++) w->dX[0][j] = 0;
+        for (int k = 0; k < N; k++) {
+            for (int i = 0; i < nu; i++) { double v = w->kf[k][i]; for (int j = 0; j < nx; j++) v += w->K[k][i][j] * w->dX[k][j]; w->dU[k][i] = v; }
+            for (int i = 0; i < nx; i++) {
+                double v = w->c[k][i];
+                for (int j = 0; j < nx; j++) v += w->A[k][i][j] * w->dX[k][j];
+                for (int j = 0; j < nu; j++) v += w->B[k][i][j] * w->dU[k][j];
+                w->dX[k + 1][i] = v;
+            }
+        }
+        for (int k = 1; k <= N; k++) for (int i = 0; i < nx; i++) {
+            double v = w->qx[k][i]; for (int j = 0; j < nx; j++) v += w->Hxx[k][i][j] * w->dX[k][j]; w->lamn[k][i] = -v; }
+        for (int k = 0; k <= N; k++) {
+            double vdx = 0; for (int j = 0; j < nx; j++) vdx += w->vx[k][j] * w->dX[k][j];
+            if (k == N - 1) for (int j = 0; j < nx; j++) vdx += w->vxN[j] * w->dX[N][j];
+            w->ds[k] = -(w->gss[k] - vdx) / w->hss[k];
+        }
+        double tau = fmax(0.99, 1 - mu), ap = 1, ad = 1, dphi = 0;
+        for (int k = 0; k <= N; k++) {
+            for (int r = 0; r < w->nrow; r++) {
+                if (!w->act[k][r]) continue;
+                double jd;
+                if (r < 2 * nu) { int j = r < nu ? r : r - nu; jd = (r < nu ? -1.0 : 1.0) * w->dU[k][j]; }
+                else if (r < 2 * nu + 2 * nx) { int q = r - 2 * nu; int j = q < nx ? q : q - nx; jd = (q < nx ? -1.0 : 1.0) * w->dX[k][j]; }
+                else if (r < 2 * nu + 2 * nx + w->M) { int m = r - 2 * nu - 2 * nx; jd = w->gcirc[k][m][0] * w->dX[k][0] + w->gcirc[k][m][1] * w->dX[k][1] - w->ds[k]; }
+                else { int i = r - 2 * nu - 2 * nx - w->M; jd = -w->ds[slack_idx(w, k)]; for (int j = 0; j < 6; j++) jd += w->gself[k][i][j] * w->dX[k][YIDX[j]]; }
+                double tt = w->t[k][r], zz = w->z[k][r];
+                double dtv = -(w->h[k][r] + tt) - jd, dzv = mu / tt - zz - (zz / tt) * dtv;
+                w->dt_[k][r] = dtv; w->dz[k][r] = dzv;
+                if (dtv < 0) { double a = -tau * tt / dtv; if (a < ap) ap = a; }
+                if (dzv < 0) { double a = -tau * zz / dzv; if (a < ad) ad = a; }
+                dphi -= mu * dtv / tt;
+            }
+            for (int j = 0; j < nx; j++) dphi += w->gX[k][j] * w->dX[k][j];
+            if (k < N) for (int j = 0; j < nu; j++) dphi += w->gU[k][j] * w->dU[k][j];
+            dphi += w->gs[k] * w->ds[k];
+        }
+        /* ---- filter line search */
+        double phi0, th0;
+        merit_parts(w, w->X, w->U, w->s, w->t, mu, &phi0, &th0);
+        if (!filt_init) { nfilt = 0; th_max = 1e4 * fmax(1.0, th0); th_min = 1e-4 * fmax(1.0, th0); filt_init = 1; }
+        double alpha = ap; int accepted = 0;
+        for (int ls = 0; ls < 20; ls++) {
+            for (int k = 0; k <= N; k++) {
+                for (int j = 0; j < nx; j++) Xn[k][j] = w->X[k][j] + alpha * w->dX[k][j];
+                if (k < N) for (int j = 0; j < nu; j++) Un[k][j] = w->U[k][j] + alpha * w->dU[k][j];
+                sn[k] = w->s[k] + alpha * w->ds[k];
+                for (int r = 0; r < w->nrow; r++) if (w->act[k][r]) tn[k][r] = w->t[k][r] + alpha * w->dt_[k][r];
+            }
+            double phi, th;
+            merit_parts(w, Xn, Un, sn, tn, mu, &phi, &th);
+            int okf = th < th_max;
+            for (int i = 0; i < nfilt && okf; i++) if (th >= filt[i].th && phi >= filt[i].phi) okf = 0;
+            int ftype = dphi < 0 && th0 <= th_min && alpha * pow(-dphi, 2.3) > pow(th0, 1.1);
+            if (okf) {
+                if (ftype) {
+                    if (phi <= phi0 + 1e-8 * alpha * dphi + 1e-14 * fabs(phi0)) { accepted = 1; break; }
+                } else if (th <= (1 - 1e-5) * th0 || phi <= phi0 - 1e-5 * th0) {
+                    accepted = 1;
+                    fent ne = {(1 - 1e-5) * th0, phi0 - 1e-5 * th0};
+                    if (nfilt < FCAP) filt[nfilt++] = ne;
+                    else { int im = 0; for (int i = 1; i < FCAP; i++) if (filt[i].th > filt[im].th) im = i; filt[im] = ne; }
+                    break;
+                }
+            }
+            if (ls < 19) alpha *= 0.5;
+        }
+        nf += !accepted;
+        /* ---- update */
+        for (int k = 0; k <= N; k++) {
+            if (k > 0) for (int j = 0; j < nx; j++) { w->X[k][j] += alpha * w->dX[k][j]; w->lam[k][j] += alpha * (w->lamn[k][j] - w->lam[k][j]); }
+            if (k < N) for (int j = 0; j < nu; j++) w->U[k][j] += alpha * w->dU[k][j];
+            w->s[k] += alpha * w->ds[k];
+            for (int r = 0; r < w->nrow; r++) if (w->act[k][r]) { w->t[k][r] += alpha * w->dt_[k][r]; w->z[k][r] += ad * w->dz[k][r]; }
+        }
+    }
+    for (int k = 0; k <= N; k++) {
+        for (int j = 0; j < nx; j++) Xo[k * nx + j] = w->X[k][j];
+        if (k < N) for (int j = 0; j < nu; j++) Uo[k * nu + j] = w->U[k][j];
+        so[k] = w->s[k];
+    }
+    if (iters_out) *iters_out = it;
+    if (cost_out) *cost_out = cost_fn(w, w->X, w->U, w->s);
+    if (err_out) *err_out = E0;
+    (void)nf;
+    free(w);
+    return status;
+}
+
+/* batch driver (OpenMP over instances when compiled with -fopenmp).  obs stride = M*3 or (N+1)*M*3 */
+int mmpc_oracle_solve_batch(const oracle_cfg *cfg, int B, const double *x_init, const double *traj_ref, const double *u_ref,
+                            const double *u_last, const double *X0, const double *obs, double *Xo, double *Uo, double *so,
+                            int *status, int *iters, double *cost, double *err, int nthreads) {
+    int nx = cfg->kind == 0 ? 9 : 6, nu = cfg->kind == 0 ? 5 : 2, N = cfg->N;
+    size_t so_ = (size_t)(cfg->obs_per_stage ? (N + 1) : 1) * cfg->M * 3;
+    (void)nthreads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads > 0 ? nthreads : 1)
+#endif
+    for (int b = 0; b < B; b++) {
+        status[b] = mmpc_oracle_solve(cfg, x_init + (size_t)b * nx, traj_ref + (size_t)b * (N + 1) * nx, u_ref + (size_t)b * N * nu,
+                                      u_last + (size_t)b * N * nu, X0 ? X0 + (size_t)b * (N + 1) * nx : 0, 0, obs + (size_t)b * so_,
+                                      Xo + (size_t)b * (N + 1) * nx, Uo + (size_t)b * N * nu, so + (size_t)b * (N + 1),
+                                      iters + b, cost + b, err + b);
+    }
+    return 0;
+}
+
+size_t mmpc_oracle_cfg_size(void) { return sizeof(oracle_cfg); }

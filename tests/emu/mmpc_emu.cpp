@@ -1,0 +1,52 @@
+// Host lane-emulation build of the HIP solver core (TEST ONLY - never part of the product).
+// Compiles mobile-manipulator-mpc_amd/csrc/mmpc_core.h with -DMMPC_EMU so that the phase
+// structured kernel runs on the CPU: each phase is a loop over the 64 lanes.  Used by
+// tests/test_emu_kernel.py to check the kernel logic (and its memory accesses, under ASAN)
+// against the oracle before anything is launched on a GPU.  `reverse` runs the lanes of every
+// phase in the opposite order: a result that changes exposes an intra-phase data race.
+#define MMPC_EMU 1
+#include "../../mobile-manipulator-mpc_amd/csrc/mmpc_core.h"
+#include <stdlib.h>
+#include <string.h>
+
+template <int KIND>
+static void run(const MmpcParams *P, int B, const double *x_init, const double *traj_ref, const double *u_ref,
+                const double *u_last, const double *x_guess, const double *obs, double *X, double *U, double *s,
+                int *status, int *iters, double *cost, double *err, int reverse) {
+    typedef MmpcDims<KIND> D;
+    const int N = P->N, M = P->M;
+    MmpcLayout L = mmpc_layout<KIND>(N, M, P->obs_per_stage);
+    const size_t so = (size_t)(P->obs_per_stage ? N + 1 : 1) * M * 3;
+    for (int b = 0; b < B; b++) {
+        // exact-size heap slab so that ASAN sees any out-of-slab access
+        double *lds = (double *)malloc(sizeof(double) * L.total);
+        for (int i = 0; i < L.total; i++) lds[i] = NAN;
+        MmpcIO io;
+        io.x_init = x_init + (size_t)b * D::NX;
+        io.traj_ref = traj_ref + (size_t)b * (N + 1) * D::NX;
+        io.u_ref = u_ref + (size_t)b * N * D::NU;
+        io.u_last = u_last + (size_t)b * N * D::NU;
+        io.x_guess = x_guess ? x_guess + (size_t)b * (N + 1) * D::NX : nullptr;
+        io.obs = obs + (size_t)b * so;
+        io.X = X + (size_t)b * (N + 1) * D::NX;
+        io.U = U + (size_t)b * N * D::NU;
+        io.s = s + (size_t)b * (N + 1);
+        io.status = status + b; io.iters = iters + b; io.cost = cost + b; io.err = err + b;
+        MmpcEmu emu = reverse ? MmpcEmu{63, -1, -1} : MmpcEmu{0, 64, 1};
+        mmpc_solve_one<KIND>(*P, io, lds, emu);
+        free(lds);
+    }
+}
+
+extern "C" int mmpc_emu_solve(int kind, const MmpcParams *P, int B, const double *x_init, const double *traj_ref,
+                              const double *u_ref, const double *u_last, const double *x_guess, const double *obs,
+                              double *X, double *U, double *s, int *status, int *iters, double *cost, double *err,
+                              int reverse) {
+    if (kind == 0) run<0>(P, B, x_init, traj_ref, u_ref, u_last, x_guess, obs, X, U, s, status, iters, cost, err, reverse);
+    else run<1>(P, B, x_init, traj_ref, u_ref, u_last, x_guess, obs, X, U, s, status, iters, cost, err, reverse);
+    return 0;
+}
+extern "C" int mmpc_emu_lds_doubles(int kind, int N, int M, int obs_per_stage) {
+    return kind == 0 ? mmpc_layout<0>(N, M, obs_per_stage).total : mmpc_layout<1>(N, M, obs_per_stage).total;
+}
+extern "C" int mmpc_emu_params_size() { return (int)sizeof(MmpcParams); }

@@ -1,0 +1,75 @@
+"""CPU: the HIP solver core (mobile-manipulator-mpc_amd/csrc/mmpc_core.h) compiled for the host with
+-DMMPC_EMU (every phase = a loop over the 64 lanes) against the independent C oracle; run again
+with the lanes of every phase in reverse order (exposes intra-phase races), and under ASAN."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import nlp, coracle, synth
+import emu_helper
+
+
+def _cmp(par, d, obs, ul, x_guess=None, X0=None):
+    r = coracle.solve_batch(par, d["x_init"], d["traj_ref"], d["u_ref"], ul, obs, X0=X0, nthreads=4)
+    e = emu_helper.solve_batch(par, d["x_init"], d["traj_ref"], d["u_ref"], ul, obs, x_guess=x_guess)
+    e2 = emu_helper.solve_batch(par, d["x_init"], d["traj_ref"], d["u_ref"], ul, obs, x_guess=x_guess, reverse=True)
+    assert (r["status"] == 0).all() and (e["status"] == 0).all()
+    assert (r["iters"] == e["iters"]).mean() > 0.9
+    assert np.abs(r["X"] - e["X"]).max() < 1e-6 and np.abs(r["U"] - e["U"]).max() < 1e-6
+    assert np.abs(r["s"] - e["s"]).max() < 1e-8
+    assert np.array_equal(e["X"], e2["X"]) and np.array_equal(e["U"], e2["U"]) and np.array_equal(e["iters"], e2["iters"])
+    return r, e
+
+
+def test_emu_wholebody_c3():
+    B = 24
+    d = synth.make_batch(B)
+    _cmp(nlp.WholeBodyParams(), d, d["obs"], np.zeros((B, 20, 5)))
+
+
+def test_emu_base_c2_and_warm_start():
+    B = 16
+    d = synth.make_batch(B, N=15, M=3, kind="base", config_id=2)
+    par = nlp.BaseParams(N=15)
+    r, _ = _cmp(par, d, d["obs"], np.zeros((B, 15, 2)))
+    d2 = dict(d)
+    d2["x_init"] = np.array([coracle.f("base", 0.1, d["x_init"][b], r["U"][b, 0]) for b in range(B)])
+    _cmp(par, d2, d["obs"], r["U"], x_guess=r["X"], X0=r["X"])     # mpc_base.py:200-201
+
+
+def test_emu_wholebody_c5_moving_obstacles():
+    B = 6
+    d = synth.make_batch(B, N=30, M=8, config_id=5, moving=True)
+    obs = np.zeros((B, 31, 8, 3))
+    for k in range(31):
+        obs[:, k, :, :2] = d["obs"][:, :, :2] + d["obs_vel"] * k * 0.1
+        obs[:, k, :, 2] = d["obs"][:, :, 2]
+    _cmp(nlp.WholeBodyParams(N=30), d, obs, np.zeros((B, 30, 5)))
+
+
+def test_emu_edge_sizes():
+    """M=0 (no obstacles), N=1, and N=63 (largest supported horizon: 64 stages = one per lane)."""
+    for N, M in ((1, 0), (3, 1), (63, 2)):
+        B = 2
+        d = synth.make_batch(B, N=N, M=max(M, 1), config_id=7)
+        obs = d["obs"][:, :M]
+        _cmp(nlp.WholeBodyParams(N=N), d, obs, np.zeros((B, N, 5)))
+
+
+def test_emu_under_asan():
+    code = ("import sys; sys.path[:0]=[%r,%r]\n"
+            "import numpy as np, emu_helper\n"
+            "from oracle import nlp, synth\n"
+            "d=synth.make_batch(3)\n"
+            "e=emu_helper.solve_batch(nlp.WholeBodyParams(),d['x_init'],d['traj_ref'],d['u_ref'],np.zeros((3,20,5)),d['obs'],asan=True)\n"
+            "assert (e['status']==0).all()\n"
+            "d=synth.make_batch(2,N=15,M=3,kind='base')\n"
+            "e=emu_helper.solve_batch(nlp.BaseParams(N=15),d['x_init'],d['traj_ref'],d['u_ref'],np.zeros((2,15,2)),d['obs'],asan=True)\n"
+            "assert (e['status']==0).all(); print('ASAN-OK')\n") % (emu_helper._HERE + "/..", emu_helper._HERE)
+    libasan = subprocess.check_output(["gcc", "-print-file-name=libasan.so"]).decode().strip()
+    env = dict(os.environ, LD_PRELOAD=libasan, ASAN_OPTIONS="detect_leaks=0")
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "ASAN-OK" in p.stdout, p.stderr[-3000:]

@@ -1,0 +1,158 @@
+"""GPU (MI355X): the HIP path, called through the C ABI, against the CPU oracle on identical seeded
+inputs, and size-independent properties at the BASELINE batch size.  Tolerances: the oracle and the
+kernel run the same algorithm in fp64 but with different libm / reduction order, so iterates agree
+to ~1e-9 and minimisers to 1e-6 (stated tolerance, BASELINE.md §3: 1e-4 on X,U across solvers)."""
+import numpy as np
+import pytest
+
+from oracle import nlp, coracle, synth
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-6
+
+
+def _wb(mm, N, M, B, **kw):
+    return mm.MPCWholeBody(mm.MobileManipulator(0.1), [], [], N=N, max_batch=B, n_obstacles=M, **kw)
+
+
+def test_wholebody_c3_parity(mm):
+    B = 256
+    d = synth.make_batch(B)
+    ctrl = _wb(mm, 20, 5, B)
+    r = ctrl.solve_batch(d["x_init"], d["traj_ref"], d["u_ref"], d["obs"])
+    o = coracle.solve_batch(nlp.WholeBodyParams(), d["x_init"], d["traj_ref"], d["u_ref"], np.zeros((B, 20, 5)), d["obs"], nthreads=8)
+    assert (r["status"] == 0).all() and (o["status"] == 0).all()
+    assert (r["iters"] == o["iters"]).mean() > 0.9
+    assert np.abs(r["X"] - o["X"]).max() < TOL and np.abs(r["U"] - o["U"]).max() < TOL and np.abs(r["s"] - o["s"]).max() < TOL
+    assert np.abs(r["cost"] / o["cost"] - 1).max() < 1e-9
+    assert np.array_equal(r["u0"], r["U"][:, 0, :])
+
+
+def test_wholebody_warm_started_ticks(mm):
+    """3 receding-horizon ticks: handle keeps u_latest (U init and U_last, unshifted; :303,:310,:330)."""
+    B = 32
+    d = synth.make_batch(B)
+    par = nlp.WholeBodyParams()
+    ctrl = _wb(mm, 20, 5, B)
+    x = np.clip(d["x_init"], par.xlim[0], par.xlim[1])
+    ul = np.zeros((B, 20, 5))
+    for tick in range(3):
+        r = ctrl.solve_batch(x, d["traj_ref"], d["u_ref"], d["obs"])
+        o = coracle.solve_batch(par, x, d["traj_ref"], d["u_ref"], ul, d["obs"], nthreads=8)
+        assert (r["status"] == 0).all()
+        assert np.abs(r["X"] - o["X"]).max() < TOL and np.abs(r["U"] - o["U"]).max() < TOL
+        ul = o["U"]
+        x = np.array([coracle.f("wholebody", 0.1, x[b], o["U"][b, 0]) for b in range(B)])
+    assert np.abs(ctrl._engine.get_u_latest(B) - ul).max() < TOL
+    ctrl.reset()
+    assert np.abs(ctrl._engine.get_u_latest(B)).max() == 0.0
+
+
+def test_base_c2_parity_and_warm_start(mm):
+    B = 128
+    d = synth.make_batch(B, N=15, M=3, kind="base", config_id=2)
+    par = nlp.BaseParams(N=15)
+    ctrl = mm.MPCBase(mm.Base(0.1), [], N=15, max_batch=B, n_obstacles=3)
+    r = ctrl.solve_batch(d["x_init"], d["traj_ref"], d["u_ref"], d["obs"])
+    o = coracle.solve_batch(par, d["x_init"], d["traj_ref"], d["u_ref"], np.zeros((B, 15, 2)), d["obs"], nthreads=8)
+    assert (r["status"] == 0).all()
+    assert np.abs(r["X"] - o["X"]).max() < TOL and np.abs(r["U"] - o["U"]).max() < TOL
+    x1 = np.array([coracle.f("base", 0.1, d["x_init"][b], o["U"][b, 0]) for b in range(B)])
+    r2 = ctrl.solve_batch(x1, d["traj_ref"], d["u_ref"], d["obs"])          # X and U warm start (mpc_base.py:200-201)
+    o2 = coracle.solve_batch(par, x1, d["traj_ref"], d["u_ref"], o["U"], d["obs"], X0=o["X"], nthreads=8)
+    assert (r2["status"] == 0).all()
+    assert np.abs(r2["X"] - o2["X"]).max() < TOL and np.abs(r2["U"] - o2["U"]).max() < TOL
+
+
+def test_wholebody_c5_moving_obstacles(mm):
+    B = 48
+    d = synth.make_batch(B, N=30, M=8, config_id=5, moving=True)
+    obs = np.zeros((B, 31, 8, 3))
+    for k in range(31):
+        obs[:, k, :, :2] = d["obs"][:, :, :2] + d["obs_vel"] * k * 0.1
+        obs[:, k, :, 2] = d["obs"][:, :, 2]
+    ctrl = _wb(mm, 30, 8, B, obs_per_stage=True)
+    r = ctrl.solve_batch(d["x_init"], d["traj_ref"], d["u_ref"], obs)
+    o = coracle.solve_batch(nlp.WholeBodyParams(N=30), d["x_init"], d["traj_ref"], d["u_ref"], np.zeros((B, 30, 5)), obs, nthreads=8)
+    ok = (r["status"] == 0) & (o["status"] == 0)
+    assert ok.mean() > 0.95
+    assert np.abs(r["X"][ok] - o["X"][ok]).max() < 1e-5 and np.abs(r["U"][ok] - o["U"][ok]).max() < 1e-5
+
+
+def test_single_instance_reference_api(mm):
+    """demo_wholebody_qref.py:35-44 debug scenario (no half-spaces): the reference's call sequence."""
+    robot = mm.MobileManipulator(0.1)
+    obstacles = [mm.Obstacles(2.5, 3.0, 0.6), mm.Obstacles(2.5, 1.0, 0.6), mm.Obstacles(5 - 0.6, 5, 0.1)]
+    ctrl = mm.MPCWholeBody(robot, obstacles, [], N=20)
+    x0 = np.zeros(9)
+    target = np.array([5.0, 5.0, -np.pi, 0, 0, 0, 0, 0, 0])
+    glob = np.linspace(x0, target, 51)                       # interface_wholebody_qref.py:247-266
+    traj, uref = glob[:21], np.zeros((20, 5))
+    x_in = np.array([0, 0, 0, 0, 0, 0, 0.0, 0.3, -0.2])      # joints outside limits -> clipped in place (:290)
+    u0 = ctrl.solve(x_in, traj, uref)
+    assert x_in[7] == 0.0 and x_in[8] == 0.0 and u0.shape == (5,)
+    par = nlp.WholeBodyParams()
+    o = coracle.solve_batch(par, x_in[None], traj[None], uref[None], np.zeros((1, 20, 5)),
+                            np.array([[[2.5, 3.0, 0.6], [2.5, 1.0, 0.6], [4.4, 5, 0.1]]]))
+    assert np.abs(u0 - o["U"][0, 0]).max() < TOL
+    assert np.abs(ctrl.u_latest - o["U"][0]).max() < TOL and np.abs(ctrl.x_guess - o["X"][0]).max() < TOL
+    u1 = ctrl.solve(robot.f_kinematics(x_in, u0), traj, uref)            # second tick, warm
+    assert np.isfinite(u1).all()
+    ctrl.setWeight(Q=np.diag([5, 5, 5, 0, 0, 1, 1, 1, 1.0]), P=np.diag([5, 5, 5, 0, 0, 1, 1, 1, 1.0]))   # interface:175-177
+    u2 = ctrl.solve(robot.f_kinematics(x_in, u0), traj, uref)
+    assert np.isfinite(u2).all() and np.abs(u2 - u1).max() > 1e-6
+    assert abs(ctrl.angleDiff(-3.14, 3.14) - 0.0031853) < 1e-7
+
+
+def test_full_size_properties(mm):
+    """BASELINE batch (8192): every instance converges to scaled KKT <= 1e-8, the solve is deterministic,
+    dynamics are satisfied by the returned trajectory, bounds hold, and a permutation of the batch
+    permutes the outputs (instances are independent)."""
+    import torch
+    B = 8192
+    d = synth.make_batch(B)
+    par = nlp.WholeBodyParams()
+    ctrl = _wb(mm, 20, 5, B)
+    eng = ctrl._engine
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    xi = np.clip(d["x_init"], par.xlim[0], par.xlim[1])
+    ul = torch.zeros((B, 20, 5), dtype=torch.float64, device=dev)
+    r = eng.solve_batch_device(t(xi), t(d["traj_ref"]), t(d["u_ref"]), ul, t(d["obs"]))
+    torch.cuda.synchronize()
+    st, err = r["status"].cpu().numpy(), r["err"].cpu().numpy()
+    assert (st == 0).all() and err.max() <= 1e-8
+    X, U, s = r["X"].cpu().numpy(), r["U"].cpu().numpy(), r["s"].cpu().numpy()
+    # dynamics residual of the returned trajectory (robot_models/base.py:19-26, manipulator_3DoF.py:190)
+    Xn = X[:, :-1].copy()
+    c, sn = np.cos(X[:, :-1, 2]), np.sin(X[:, :-1, 2])
+    Xn[:, :, 0] += 0.1 * X[:, :-1, 3]; Xn[:, :, 1] += 0.1 * X[:, :-1, 4]; Xn[:, :, 2] += 0.1 * X[:, :-1, 5]
+    Xn[:, :, 3] += 0.1 * (U[:, :, 0] * c - X[:, :-1, 4] * X[:, :-1, 5])
+    Xn[:, :, 4] += 0.1 * (U[:, :, 0] * sn + X[:, :-1, 3] * X[:, :-1, 5])
+    Xn[:, :, 5] += 0.1 * U[:, :, 1]
+    Xn[:, :, 6:] += 0.1 * U[:, :, 2:]
+    assert np.abs(Xn - X[:, 1:]).max() < 1e-8
+    assert (U <= par.ulim[1] + 1e-7).all() and (U >= par.ulim[0] - 1e-7).all()
+    assert (X[:, 1:] <= par.xlim[1] + 1e-7).all() and (X[:, 1:] >= par.xlim[0] - 1e-7).all()
+    assert (s > -1e-6).all()
+    # deterministic
+    r2 = eng.solve_batch_device(t(xi), t(d["traj_ref"]), t(d["u_ref"]), ul, t(d["obs"]))
+    torch.cuda.synchronize()
+    assert torch.equal(r["X"], r2["X"]) and torch.equal(r["U"], r2["U"])
+    # independence: reversed batch order
+    rev = lambda a: np.ascontiguousarray(a[::-1])
+    r3 = eng.solve_batch_device(t(rev(xi)), t(rev(d["traj_ref"])), t(rev(d["u_ref"])), ul, t(rev(d["obs"])))
+    torch.cuda.synchronize()
+    assert torch.equal(torch.flip(r3["X"], [0]), r["X"])
+    # spot parity vs the oracle on a slice of the full batch
+    o = coracle.solve_batch(par, xi[:64], d["traj_ref"][:64], d["u_ref"][:64], np.zeros((64, 20, 5)), d["obs"][:64], nthreads=8)
+    assert np.abs(X[:64] - o["X"]).max() < TOL
+
+
+def test_bad_arguments_raise(mm):
+    ctrl = _wb(mm, 20, 5, 4)
+    d = synth.make_batch(8)
+    with pytest.raises(RuntimeError, match="max_batch"):
+        ctrl.solve_batch(d["x_init"], d["traj_ref"], d["u_ref"], d["obs"])
+    with pytest.raises(ValueError):
+        ctrl.solve_batch(d["x_init"][:4], d["traj_ref"][:4, :5], d["u_ref"][:4], d["obs"][:4])
