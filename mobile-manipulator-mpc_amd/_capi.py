@@ -6,7 +6,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmmpc.so")
+LIB_PATH = os.environ.get("MMPC_LIB") or os.path.join(_HERE, "csrc", "libmmpc.so")   # MMPC_LIB: A/B builds of the same HIP library
 
 KIND_WHOLEBODY, KIND_BASE = 0, 1
 STATUS_CONVERGED, STATUS_MAXITER, STATUS_NUMERIC = 0, 1, 2

@@ -34,7 +34,10 @@ struct MmpcEmu { int first, end, step; };
 #define MMPC_DEV __device__ __forceinline__
 #define MMPC_HD __host__ __device__ inline
 #define MMPC_CONST __device__ __constant__ static const
-#define LANES_BEGIN { const int lane = (int)threadIdx.x;
+// The lane id is re-materialised through an opaque asm in every phase: otherwise LLVM hoists every
+// lane-derived address out of the solver's loops and the hoisted values alone exceed the register file.
+__device__ __forceinline__ int mmpc_lane_id() { int l = (int)threadIdx.x; asm volatile("" : "+v"(l)); return l; }
+#define LANES_BEGIN { const int lane = mmpc_lane_id();
 #define LANES_END } __syncthreads();
 #define MMPC_EMU_ARG
 #endif
@@ -176,7 +179,8 @@ MMPC_DEV void mmpc_arm_segments(double q1, double q2, double q3, double dr[3], d
 // (world points).  g6 (may be null) = dh/d(x,y,psi,q1,q2,q3).
 MMPC_DEV double mmpc_self_row(int i, double px, double py, double c, double s, const double dr[3], const double dz[3],
                               double *g6) {
-    const double al = kSelfAB[i][0], be = kSelfAB[i][1], kap = al + be - 1.0;
+    // p_i = alpha j2 + beta j3: (0,0), (1/2,0), (1,0), (1/2,1/2)   (mpc_wholebody_qref.py:219)
+    const double al = i == 0 ? 0.0 : (i == 2 ? 1.0 : 0.5), be = i == 3 ? 0.5 : 0.0, kap = al + be - 1.0;
     const double cm0 = kap, cm1 = be - 1.0, cm2 = -1.0;
     const double R = kap * MMPC_BX + cm0 * dr[0] + cm1 * dr[1] + cm2 * dr[2];
     const double Z = kap * MMPC_BZ + cm0 * dz[0] + cm1 * dz[1] + cm2 * dz[2];
@@ -897,32 +901,38 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
 
         // ---- filter line search (Waechter-Biegler acceptance rules, no restoration phase)
         double alpha = ap;
-        for (int ls = 0; ls < MMPC_MAX_LS; ls++) {
-            LANES_BEGIN
-            double ph = 0.0, th = 0.0;
-            for (int k = lane; k < NS; k += MMPC_WAVE) { double a, b; stage_merit(k, alpha, a, b); ph += a; th += b; }
-            RED[5 * MMPC_WAVE + lane] = ph; RED[6 * MMPC_WAVE + lane] = th;
-            LANES_END
-            double phi = 0.0, th = 0.0;
-            for (int i = 0; i < MMPC_WAVE; i++) { phi += RED[5 * MMPC_WAVE + i]; th += RED[6 * MMPC_WAVE + i]; }
-            bool okf = th < th_max;
-            for (int i = 0; i < nfilt && okf; i++) if (th >= FILT[2 * i] && phi >= FILT[2 * i + 1]) okf = false;
-            const bool ftype = dphi < 0 && th0 <= th_min && alpha * pow(-dphi, 2.3) > pow(th0, 1.1);
-            bool accepted = false, augment = false;
-            if (okf) {
-                if (ftype) accepted = phi <= phi0 + 1e-8 * alpha * dphi + 1e-14 * fabs(phi0);
-                else if (th <= (1 - 1e-5) * th0 || phi <= phi0 - 1e-5 * th0) { accepted = true; augment = true; }
-            }
-            if (augment) {
-                int slot = nfilt;
-                if (nfilt >= MMPC_FCAP) { slot = 0; for (int i = 1; i < MMPC_FCAP; i++) if (FILT[2 * i] > FILT[2 * slot]) slot = i; }
-                else nfilt++;
+        for (int lspass = 0; lspass < 2; lspass++) {
+            bool accepted = false;
+            alpha = ap;
+            for (int ls = 0; ls < MMPC_MAX_LS; ls++) {
                 LANES_BEGIN
-                if (lane == 0) { FILT[2 * slot] = (1 - 1e-5) * th0; FILT[2 * slot + 1] = phi0 - 1e-5 * th0; }
+                double ph = 0.0, th = 0.0;
+                for (int k = lane; k < NS; k += MMPC_WAVE) { double a, b; stage_merit(k, alpha, a, b); ph += a; th += b; }
+                RED[5 * MMPC_WAVE + lane] = ph; RED[6 * MMPC_WAVE + lane] = th;
                 LANES_END
+                double phi = 0.0, th = 0.0;
+                for (int i = 0; i < MMPC_WAVE; i++) { phi += RED[5 * MMPC_WAVE + i]; th += RED[6 * MMPC_WAVE + i]; }
+                bool okf = th < th_max;
+                for (int i = 0; i < nfilt && okf; i++) if (th >= FILT[2 * i] && phi >= FILT[2 * i + 1]) okf = false;
+                const bool ftype = dphi < 0 && th0 <= th_min && alpha * pow(-dphi, 2.3) > pow(th0, 1.1);
+                bool augment = false;
+                if (okf) {
+                    if (ftype) accepted = phi <= phi0 + 1e-8 * alpha * dphi + 1e-14 * fabs(phi0);
+                    else if (th <= (1 - 1e-5) * th0 || phi <= phi0 - 1e-5 * th0) { accepted = true; augment = true; }
+                }
+                if (augment) {
+                    int slot = nfilt;
+                    if (nfilt >= MMPC_FCAP) { slot = 0; for (int i = 1; i < MMPC_FCAP; i++) if (FILT[2 * i] > FILT[2 * slot]) slot = i; }
+                    else nfilt++;
+                    LANES_BEGIN
+                    if (lane == 0) { FILT[2 * slot] = (1 - 1e-5) * th0; FILT[2 * slot + 1] = phi0 - 1e-5 * th0; }
+                    LANES_END
+                }
+                if (accepted) break;
+                if (ls < MMPC_MAX_LS - 1) alpha *= 0.5;
             }
-            if (accepted) break;
-            if (ls < MMPC_MAX_LS - 1) alpha *= 0.5;
+            if (accepted || nfilt == 0) break;
+            nfilt = 0;  // filter reset heuristic: the filter blocked every trial step
         }
         // ---- update
         LANES_BEGIN

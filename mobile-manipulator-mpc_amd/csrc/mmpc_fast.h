@@ -1,0 +1,1198 @@
+// mmpc_fast.h - performance path of the one-wavefront-per-problem interior-point MPC solver.
+//
+// Same algorithm, same results as mmpc_core.h (the generic path; see that file for the
+// reference citations), restructured for gfx950:
+//   * horizon N is a template parameter; (x_k,u_k) are stored interleaved ("XU", NV = nx+nu
+//     doubles per stage) so that a (stage, variable) pair is one linear index;
+//   * slack/multiplier state of every inequality row lives in REGISTERS:
+//       - box rows: lane <-> (stage, variable) pair, both sides (lo/hi) of NPASS pairs per lane;
+//       - circle / self-collision rows: lane <-> stage;
+//     LDS keeps only what is exchanged between lanes (trajectory, stage Hessians -> cost-to-go
+//     matrices, feedback gains, search direction) : ~38 KB for N=20 -> 4 problems per CU;
+//   * per-launch constants are copied into LDS once (no global/constant loads in the loop);
+//   * wave-wide reductions use cross-lane shuffles; the Riccati phases use per-lane index
+//     tables precomputed once.
+// Written in the same PHASE discipline as mmpc_core.h so that -DMMPC_EMU builds run it on the
+// host (tests only); lane-private state that survives a phase lives in `LS` (struct per lane)
+// and `WR` (reduction inputs).
+#pragma once
+#include "mmpc_core.h"
+
+#ifdef MMPC_EMU
+#define MMPC_LS ls_all[lane]
+#define MMPC_WR(i) wr_all[lane][i]
+#else
+#define MMPC_LS ls_one
+#define MMPC_WR(i) wr_one[i]
+#endif
+
+#define MMPC_MC_MAX 8    // largest number of circle rows the register-resident path is instantiated for
+
+// ---- light-weight fp64 math for the fast path -------------------------------------------------
+// sin/cos: Cody-Waite reduction by pi/2 (three-part constant, exact for |x| < ~1e6 rad: heading and
+// joint angles stay far below that) + the fdlibm kernel polynomials on [-pi/4, pi/4] (< 1 ulp).
+// The library sincos carries a Payne-Hanek path that costs ~700 instructions per call site.
+MMPC_DEV void mmpc_sincos(double x, double *sn, double *cs) {
+    const double n = rint(x * 6.36619772367581382433e-01);
+    double r = fma(-n, 1.57079632673412561417e+00, x);
+    r = fma(-n, 6.07710050630396597660e-11, r);
+    r = fma(-n, 2.02226624879595063154e-21, r);
+    const double z = r * r;
+    const double ps = fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08),
+                      2.75573137070700676789e-06), -1.98412698298579493134e-04), 8.33333333332248946124e-03),
+                      -1.66666666666666324348e-01);
+    const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09),
+                      -2.75573143513906633035e-07), 2.48015872894767294178e-05), -1.38888888888741095749e-03),
+                      4.16666666666666019037e-02);
+    const double s0 = fma(r * z, ps, r);
+    const double c0 = fma(z * z, pc, fma(-0.5, z, 1.0));
+    const int q = (int)n & 3;
+    const double sa = (q & 1) ? c0 : s0, ca = (q & 1) ? s0 : c0;
+    *sn = (q & 2) ? -sa : sa;
+    *cs = ((q + 1) & 2) ? -ca : ca;
+}
+#ifdef MMPC_EMU
+MMPC_DEV double mmpc_rcp(double x) { return 1.0 / x; }
+MMPC_DEV double mmpc_rsqrt(double x) { return 1.0 / sqrt(x); }
+MMPC_DEV double mmpc_powf(double x, float e) { return (double)exp2f(e * log2f((float)x)); }
+MMPC_DEV void mmpc_sched_fence() {}
+#else
+// v_rcp_f64 / v_rsq_f64 + Newton steps (<= 1-2 ulp); the IEEE division / sqrt sequences are ~3x longer
+MMPC_DEV double mmpc_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return fma(fma(-x, r, 1.0), r, r);
+}
+MMPC_DEV double mmpc_rsqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * fma(-0.5 * x * y, y, 1.5);
+    return y * fma(-0.5 * x * y, y, 1.5);
+}
+// x^e in single precision (only used by the filter's switching rule, a heuristic threshold)
+MMPC_DEV double mmpc_powf(double x, float e) { return (double)__builtin_amdgcn_exp2f(e * __builtin_amdgcn_logf((float)x)); }
+// keeps the scheduler from interleaving independent unrolled bodies (bounds the live registers)
+MMPC_DEV void mmpc_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+#endif
+// natural log of a product of mantissas m in (0,1]: renormalise to [sqrt(1/2), sqrt(2)), then
+// log m = 2 atanh(s), s = (m-1)/(m+1), |s| < 0.1716, odd series to s^21 (< 1e-17)
+MMPC_DEV double mmpc_log_mant(double m, int *ex) {
+    int e;
+    m = frexp(m, &e);
+    if (m < 0.70710678118654752440) { m *= 2.0; e -= 1; }
+    *ex += e;
+    const double s = (m - 1.0) * mmpc_rcp(m + 1.0), z = s * s;
+    double p = 1.0 / 21.0;
+    p = fma(p, z, 1.0 / 19.0); p = fma(p, z, 1.0 / 17.0); p = fma(p, z, 1.0 / 15.0); p = fma(p, z, 1.0 / 13.0);
+    p = fma(p, z, 1.0 / 11.0); p = fma(p, z, 1.0 / 9.0); p = fma(p, z, 1.0 / 7.0); p = fma(p, z, 1.0 / 5.0);
+    p = fma(p, z, 1.0 / 3.0); p = fma(p, z, 1.0);
+    return 2.0 * s * p;
+}
+// planar arm segments (as mmpc_arm_segments in mmpc_core.h) with the light-weight sincos
+MMPC_DEV void mmpc_arm_segments_fast(double q1, double q2, double q3, double dr[3], double dz[3]) {
+    double s1, c1, sA, cA, sB, cB;
+    mmpc_sincos(q1, &s1, &c1);
+    mmpc_sincos(q1 - q2, &sA, &cA);
+    mmpc_sincos(q1 - q2 - q3, &sB, &cB);
+    dr[0] = MMPC_A2 * s1 + MMPC_A3 * c1;
+    dz[0] = MMPC_A2 * c1 - MMPC_A3 * s1;
+    dr[1] = -MMPC_A3 * cA + MMPC_A5 * sA;
+    dz[1] = MMPC_A3 * sA + MMPC_A5 * cA;
+    dr[2] = MMPC_A6 * cB - MMPC_A7 * sB;
+    dz[2] = -MMPC_A6 * sB - MMPC_A7 * cB;
+}
+// state entries the forward kinematics depends on (x, y, psi, q1, q2, q3), as a constant expression
+MMPC_HD constexpr int mmpc_y(int a) { return a < 3 ? a : a + 3; }
+
+#define MMPC_B(x, q) (((x) >> (8 * (q))) & 255u)
+
+template <int KIND, int N>
+struct MmpcFastDims {
+    typedef MmpcDims<KIND> D;
+    static constexpr int NX = D::NX, NU = D::NU, NV = D::NV, NXX = D::NXX, NUU = D::NUU, NSELF = D::NSELF;
+    static constexpr int NS = N + 1;
+    static constexpr int NPAIR = NS * NV;
+    static constexpr int NPASS = (NPAIR + MMPC_WAVE - 1) / MMPC_WAVE;
+    static constexpr int NTC = 4 + NU;                              // columns of [A B] that are not unit vectors: 2..5 and the inputs
+    static constexpr int TW = NTC + 1;                              // row of T_ext: those columns of P[A B], then pc = p + P c
+    static constexpr int R1E = NX * TW;
+    static constexpr int R1P = (R1E + MMPC_WAVE - 1) / MMPC_WAVE;
+    static constexpr int R2E = NXX + NU * NX + NUU + NV;            // F | G | Hh | g
+    static constexpr int R2P = (R2E + MMPC_WAVE - 1) / MMPC_WAVE;
+};
+
+struct MmpcFastLayout {
+    int XU, S, LAM, XUREF, ULAST, OBS, CST, CV, CD, TRG, HXX, QXU, HUXL, HUUL, HUX02, HUUD, SN, KK, KF, DXU, DS, DLAM,
+        PF, TT, MM, FILT, MISC, total;
+};
+// constants block (CST) offsets
+#define MMPC_C_XLIM 0      // [2][9]
+#define MMPC_C_ULIM 18     // [2][5]
+#define MMPC_C_DULIM 28    // [2][5]
+#define MMPC_C_WQ 38       // diag(Q2)[9]
+#define MMPC_C_WP 47       // diag(P2)[9]
+#define MMPC_C_WR 56       // diag(R2)[5]
+#define MMPC_C_WW 61       // diag(W2)[5]
+#define MMPC_C_RW2 66      // RW2 [25] (full)
+#define MMPC_C_SIZE 92
+
+template <int KIND, int N>
+MMPC_HD MmpcFastLayout mmpc_fast_layout(int M, int obs_per_stage) {
+    typedef MmpcFastDims<KIND, N> F;
+    MmpcFastLayout L;
+    int o = 0;
+#define MMPC_CARVE(name, n) L.name = o; o += (n); o = (o + 1) & ~1;
+    MMPC_CARVE(XU, F::NS * F::NV) MMPC_CARVE(S, F::NS) MMPC_CARVE(LAM, F::NS * F::NX)
+    MMPC_CARVE(XUREF, F::NS * F::NV) MMPC_CARVE(ULAST, F::NS * F::NU) MMPC_CARVE(OBS, (obs_per_stage ? F::NS : 1) * M * 3)
+    MMPC_CARVE(CST, MMPC_C_SIZE) MMPC_CARVE(CV, F::NS * MMPC_NCV) MMPC_CARVE(CD, F::NS * F::NX) MMPC_CARVE(TRG, F::NS * 8)
+    MMPC_CARVE(HXX, F::NS * F::NXX) MMPC_CARVE(QXU, F::NS * F::NV) MMPC_CARVE(HUXL, F::NU * F::NX)
+    MMPC_CARVE(HUUL, F::NUU) MMPC_CARVE(HUX02, F::NS) MMPC_CARVE(HUUD, F::NS * F::NU) MMPC_CARVE(SN, 16)
+    MMPC_CARVE(KK, N * F::NU * F::NX) MMPC_CARVE(KF, N * F::NU) MMPC_CARVE(DXU, F::NS * F::NV) MMPC_CARVE(DS, F::NS)
+    MMPC_CARVE(DLAM, F::NS * F::NX) MMPC_CARVE(PF, F::NX * F::NX + F::NX * F::TW) L.TT = L.PF + F::NX * F::NX;
+    MMPC_CARVE(MM, F::R2E) MMPC_CARVE(FILT, 2 * MMPC_FCAP) MMPC_CARVE(MISC, 8)
+#undef MMPC_CARVE
+    L.total = o;
+    return L;
+}
+
+template <int KIND, int N, int MC>
+struct MmpcLaneState {
+    typedef MmpcFastDims<KIND, N> F;
+    // box pairs (stage, variable): index idx = lane + 64 p
+    double lo_t[F::NPASS], lo_z[F::NPASS], hi_t[F::NPASS], hi_z[F::NPASS];
+    // circle rows of stage `lane`
+    double ct[MC > 0 ? MC : 1], cz[MC > 0 ? MC : 1], cdt[MC > 0 ? MC : 1];
+    // self-collision rows of stage `lane`
+    double st[4], sz[4], sdt[4];
+    // s_k elimination data of stage `lane`
+    double hss, gss, vx[6];
+    // Riccati index tables
+    // Riccati index tables, four 8-bit fields per word (MMPC_B extracts field q)
+    unsigned r1_p[F::R1P], r1_c[F::R1P];             // PF offset, CV id
+    unsigned r2_t[F::R2P], r2_c[F::R2P];             // TT offset, CV id
+    unsigned r2_k[F::R2P];                           // kind | a<<8 | b<<16
+    unsigned r5_ij;                                  // i | j<<8
+    unsigned f_c, f_v, f_x;                          // forward roll-out row of [A B]: 4 terms + (5th col | 5th cv<<8 | (a+1)<<16)
+};
+
+#ifndef MMPC_EMU
+MMPC_DEV double mmpc_wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+MMPC_DEV double mmpc_wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = mmpc_max(v, __shfl_xor(v, o));
+    return v;
+}
+MMPC_DEV double mmpc_wave_min(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = mmpc_min(v, __shfl_xor(v, o));
+    return v;
+}
+#define MMPC_RED_SUM(i) mmpc_wave_sum(wr_one[i])
+#define MMPC_RED_MAX(i) mmpc_wave_max(wr_one[i])
+#define MMPC_RED_MIN(i) mmpc_wave_min(wr_one[i])
+#else
+// host emulation: butterfly in the same pairing order as the device shuffles, so that the
+// floating-point sums are bit-identical on every "lane"
+static inline double mmpc_emu_red(double (*wr)[8], int i, int op) {
+    double v[MMPC_WAVE], w[MMPC_WAVE];
+    for (int l = 0; l < MMPC_WAVE; l++) v[l] = wr[l][i];
+    for (int o = 32; o > 0; o >>= 1) {
+        for (int l = 0; l < MMPC_WAVE; l++) {
+            const double a = v[l], b = v[l ^ o];
+            w[l] = op == 0 ? a + b : (op == 1 ? (a > b ? a : b) : (a < b ? a : b));
+        }
+        for (int l = 0; l < MMPC_WAVE; l++) v[l] = w[l];
+    }
+    return v[0];
+}
+#define MMPC_RED_SUM(i) mmpc_emu_red(wr_all, i, 0)
+#define MMPC_RED_MAX(i) mmpc_emu_red(wr_all, i, 1)
+#define MMPC_RED_MIN(i) mmpc_emu_red(wr_all, i, 2)
+#endif
+
+// product-of-mantissas accumulator for sum(log t)
+struct MmpcLogAcc {
+    double mant; int ex;
+    MMPC_DEV void init() { mant = 1.0; ex = 0; }
+    MMPC_DEV void mul(double t) { int e; mant *= frexp(t, &e); ex += e; if (mant < 1e-200) { mant = frexp(mant, &e); ex += e; } }
+    MMPC_DEV double value() const { int e = ex; const double l = mmpc_log_mant(mant, &e); return l + (double)e * 0.69314718055994530942; }
+};
+
+template <int KIND, int N, int MC>
+MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds MMPC_EMU_ARG) {
+    typedef MmpcFastDims<KIND, N> F;
+    typedef MmpcTab<KIND> TB;
+    constexpr int NX = F::NX, NU = F::NU, NV = F::NV, NXX = F::NXX, NUU = F::NUU, NSELF = F::NSELF, NS = F::NS;
+    constexpr int NPASS = F::NPASS, NPAIR = F::NPAIR, R1E = F::R1E, R1P = F::R1P, R2E = F::R2E, R2P = F::R2P;
+    constexpr int TW = F::TW, NTC = F::NTC;
+    constexpr int M = MC;   // number of circle obstacles is a template parameter on this path
+    const MmpcFastLayout L = mmpc_fast_layout<KIND, N>(M, P.obs_per_stage);
+    double *XU = lds + L.XU, *S = lds + L.S, *LAM = lds + L.LAM, *XUREF = lds + L.XUREF, *ULAST = lds + L.ULAST,
+           *OBS = lds + L.OBS, *CST = lds + L.CST, *CV = lds + L.CV, *CD = lds + L.CD, *TRG = lds + L.TRG, *HXX = lds + L.HXX,
+           *QXU = lds + L.QXU, *HUXL = lds + L.HUXL, *HUUL = lds + L.HUUL, *HUX02 = lds + L.HUX02,
+           *HUUD = lds + L.HUUD, *SN = lds + L.SN, *KK = lds + L.KK, *KF = lds + L.KF, *DXU = lds + L.DXU,
+           *DS = lds + L.DS, *DLAM = lds + L.DLAM, *PF = lds + L.PF, *TT = lds + L.TT, *MM = lds + L.MM,
+           *FILT = lds + L.FILT, *MISC = lds + L.MISC;
+    double *const MF = MM, *const MG = MM + NXX, *const MH = MM + NXX + NU * NX, *const MGV = MM + NXX + NU * NX + NUU;
+    double *const RB = DXU;   // residual base r[k][v] (alias: dead while DXU is not)
+    const double dt = P.dt, Sw = P.S, tol = P.tol;
+#ifdef MMPC_EMU
+    static thread_local MmpcLaneState<KIND, N, MC> ls_all[MMPC_WAVE];
+    static thread_local double wr_all[MMPC_WAVE][8];
+#else
+    MmpcLaneState<KIND, N, MC> ls_one;
+    double wr_one[8];
+#endif
+    auto obs_ptr = [&](int k, int m) -> const double * { return OBS + ((P.obs_per_stage ? k * M : 0) + m) * 3; };
+    auto slack_idx = [&](int k) -> int { return k < N - 1 ? k : N - 1; };
+
+    // ------------------------------------------------------------------ load
+    LANES_BEGIN
+    for (int i = lane; i < NPAIR; i += MMPC_WAVE) {
+        const int k = i / NV, v = i % NV;
+        double val, ref;
+        if (v < NX) {
+            double x0 = io.x_init[v];
+            if (KIND == 0) x0 = mmpc_max(mmpc_min(x0, P.xlim[1][v]), P.xlim[0][v]);
+            val = (P.use_xguess && k >= 1) ? io.x_guess[k * NX + v] : x0;
+            ref = io.traj_ref[k * NX + v];
+        } else {
+            val = k < N ? io.u_last[k * NU + v - NX] : 0.0;
+            ref = k < N ? io.u_ref[k * NU + v - NX] : 0.0;
+        }
+        XU[i] = val;
+        XUREF[i] = ref;
+    }
+    for (int i = lane; i < NS * NU; i += MMPC_WAVE) ULAST[i] = i < N * NU ? io.u_last[i] : 0.0;
+    for (int i = lane; i < NS * NX; i += MMPC_WAVE) LAM[i] = 0.0;
+    for (int i = lane; i < NS; i += MMPC_WAVE) S[i] = 0.0;
+    for (int i = lane; i < (P.obs_per_stage ? NS : 1) * M * 3; i += MMPC_WAVE) OBS[i] = io.obs[i];
+    for (int i = lane; i < MMPC_C_SIZE; i += MMPC_WAVE) {
+        double v = 0.0;
+        if (i < 18) v = P.xlim[i / 9][i % 9];
+        else if (i < 28) v = P.ulim[(i - 18) / 5][(i - 18) % 5];
+        else if (i < 38) v = P.dulim[(i - 28) / 5][(i - 28) % 5];
+        else if (i < 47) { const int j = i - 38; v = j < NX ? P.Q2[j * NX + j] : 0.0; }
+        else if (i < 56) { const int j = i - 47; v = j < NX ? P.P2[j * NX + j] : 0.0; }
+        else if (i < 61) { const int j = i - 56; v = j < NU ? P.R2[j * NU + j] : 0.0; }
+        else if (i < 66) { const int j = i - 61; v = j < NU ? P.W2[j * NU + j] : 0.0; }
+        else if (i < 66 + 25) v = P.RW2[i - 66];
+        CST[i] = v;
+    }
+    // Riccati index tables (once)
+    {
+        auto &ls = MMPC_LS;
+        // column j of [A B] -> compact T column (or -1 when the column is a unit vector e_j)
+        auto tcol = [&](int j) -> int { return (j >= 2 && j <= 5) ? j - 2 : (j >= NX ? 4 + j - NX : -1); };
+        // offset of T_ext[r][col] relative to PF: plain columns come straight from P
+        auto text = [&](int r, int col) -> unsigned {
+            if (col == NV) return (unsigned)(NX * NX + r * TW + NTC);
+            const int c = tcol(col);
+            return c < 0 ? (unsigned)(r * NX + col) : (unsigned)(NX * NX + r * TW + c);
+        };
+#pragma unroll
+        for (int p = 0; p < R1P; p++) {
+            const int e = lane + MMPC_WAVE * p;
+            unsigned po = 0, co = 0;
+            if (e < R1E) {
+                const int i = e / TW, c = e % TW;
+                if (c < NTC) {
+                    const int j = c < 4 ? c + 2 : NX + c - 4;
+                    for (int q = 0; q < 4; q++) { po |= (unsigned)(i * NX + TB::crow(j, q)) << (8 * q); co |= (unsigned)TB::ccv(j, q) << (8 * q); }
+                } else { po = (unsigned)i; co = 0xffffffffu; }   // pc row i
+            }
+            ls.r1_p[p] = po; ls.r1_c[p] = co;
+        }
+#pragma unroll
+        for (int p = 0; p < R2P; p++) {
+            const int e = lane + MMPC_WAVE * p;
+            unsigned to = 0, co = 0, kk = 255u;
+            if (e < R2E) {
+                int row, col, kind, a = 0, b = 0;   // out = sum_q cv(row,q) * T_ext[crow(row,q)][col]
+                if (e < NXX) { kind = 0; row = kTriI[e]; col = kTriJ[e]; }
+                else if (e < NXX + NU * NX) { kind = 1; const int e2 = e - NXX; a = e2 / NX; b = e2 % NX; row = NX + a; col = b; }
+                else if (e < NXX + NU * NX + NUU) { kind = 2; const int e2 = e - NXX - NU * NX; a = kTriI[e2]; b = kTriJ[e2]; row = NX + a; col = NX + b; }
+                else { kind = 3; a = e - NXX - NU * NX - NUU; row = a; col = NV; }
+                for (int q = 0; q < 4; q++) { to |= text(TB::crow(row, q), col) << (8 * q); co |= (unsigned)TB::ccv(row, q) << (8 * q); }
+                kk = (unsigned)kind | ((unsigned)a << 8) | ((unsigned)b << 16);
+            }
+            ls.r2_t[p] = to; ls.r2_c[p] = co; ls.r2_k[p] = kk;
+        }
+        {
+            unsigned fc = 0, fv = 0, fx = 0;
+            if (lane < NX) {
+                for (int q = 0; q < 4; q++) { fc |= (unsigned)TB::rcol(lane, q) << (8 * q); fv |= (unsigned)TB::rcv(lane, q) << (8 * q); }
+                const int a = (lane == 3 || lane == 4) ? 0 : (lane >= 5 ? lane - 4 : -1);
+                fx = (unsigned)TB::rcol(lane, 4) | ((unsigned)TB::rcv(lane, 4) << 8) | ((unsigned)(a + 1) << 16);
+            }
+            ls.f_c = fc; ls.f_v = fv; ls.f_x = fx;
+        }
+        ls.r5_ij = lane < NXX ? ((unsigned)kTriI[lane] | ((unsigned)kTriJ[lane] << 8)) : 0u;
+    }
+    LANES_END
+
+    const bool diagw = true;  // dense weights are routed to the generic path by the host
+    (void)diagw;
+    // bounds of pair idx (k,v): returns activity of each side
+    auto pair_bounds = [&](int k, int v, double &lo, double &hi, bool &alo, bool &ahi) {
+        if (v < NX) {
+            lo = CST[MMPC_C_XLIM + v]; hi = CST[MMPC_C_XLIM + 9 + v];
+            const bool ex = k >= 1;
+            alo = ex && mmpc_finite(lo); ahi = ex && mmpc_finite(hi);
+        } else {
+            const int a = v - NX;
+            const double ul = ULAST[k * NU + a];
+            lo = mmpc_max(CST[MMPC_C_ULIM + a], ul + CST[MMPC_C_DULIM + a]);
+            hi = mmpc_min(CST[MMPC_C_ULIM + 5 + a], ul + CST[MMPC_C_DULIM + 5 + a]);
+            const bool ex = k < N;
+            alo = ex && mmpc_finite(lo); ahi = ex && mmpc_finite(hi);
+        }
+    };
+    // cost weight (diagonal, already doubled) of variable v at stage k;  second = W2 weight (inputs)
+    auto w_diag = [&](int k, int v) -> double {
+        if (v < NX) return CST[(k < N ? MMPC_C_WQ : MMPC_C_WP) + v];
+        return k < N ? CST[MMPC_C_WR + v - NX] : 0.0;
+    };
+
+    double mu = P.mu_init;
+    // ------------------------------------------------------------------ slack / multiplier init
+    LANES_BEGIN
+    auto &ls = MMPC_LS;
+#pragma unroll
+    for (int p = 0; p < NPASS; p++) {
+        mmpc_sched_fence();
+        const int idx = lane + MMPC_WAVE * p;
+        ls.lo_t[p] = 1.0; ls.lo_z[p] = 0.0; ls.hi_t[p] = 1.0; ls.hi_z[p] = 0.0;
+        if (idx < NPAIR) {
+            const int k = idx / NV, v = idx % NV;
+            double lo, hi; bool alo, ahi;
+            pair_bounds(k, v, lo, hi, alo, ahi);
+            const double val = XU[idx];
+            if (alo) { ls.lo_t[p] = mmpc_max(val - lo, 1e-2); ls.lo_z[p] = mu / ls.lo_t[p]; }
+            if (ahi) { ls.hi_t[p] = mmpc_max(hi - val, 1e-2); ls.hi_z[p] = mu / ls.hi_t[p]; }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < M; m++) { ls.ct[m] = 1.0; ls.cz[m] = 0.0; }
+#pragma unroll
+    for (int i = 0; i < 4; i++) { ls.st[i] = 1.0; ls.sz[i] = 0.0; }
+    if (lane < NS) {
+        const int k = lane;
+        const double *xk = XU + k * NV;
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            const double *o = obs_ptr(k, m);
+            const double dx = xk[0] - o[0], dy = xk[1] - o[1];
+            const double h = (o[2] + MMPC_BASE_R) - sqrt(dx * dx + dy * dy) - S[k];
+            ls.ct[m] = mmpc_max(-h, 1e-2); ls.cz[m] = mu / ls.ct[m];
+        }
+        if (NSELF) {
+            double dr[3], dz[3], sn, cs;
+            mmpc_sincos(xk[2], &sn, &cs);
+            mmpc_arm_segments_fast(xk[NX - 3], xk[NX - 2], xk[NX - 1], dr, dz);
+#pragma unroll
+            for (int i = 0; i < NSELF; i++) {
+                const double h = mmpc_self_row(i, xk[0], xk[1], cs, sn, dr, dz, nullptr) - S[slack_idx(k)];
+                ls.st[i] = mmpc_max(-h, 1e-2); ls.sz[i] = mu / ls.st[i];
+            }
+        }
+    }
+    // count active rows (for the KKT error scaling)
+    double cnt = 0.0;
+#pragma unroll
+    for (int p = 0; p < NPASS; p++) cnt += (ls.lo_z[p] != 0.0 ? 1.0 : 0.0) + (ls.hi_z[p] != 0.0 ? 1.0 : 0.0);
+    if (lane < NS) cnt += (double)(M + NSELF);
+    MMPC_WR(0) = cnt;
+    LANES_END
+    const double nrows_act = MMPC_RED_SUM(0);
+
+    int status = 1, it = 0, nfilt = 0, filt_init = 0;
+    double E0 = 0.0, th_max = 0.0, th_min = 0.0;
+
+#pragma unroll 1
+    for (it = 0; it <= P.max_iter; it++) {
+        // ============================================================ E1 (stage lanes)
+        LANES_BEGIN
+        auto &ls = MMPC_LS;
+        double e_p = 0.0, tzmax = 0.0, tzmin = 1e300, zsum = 0.0, phi = 0.0, th = 0.0;
+        if (lane < NS) {
+            const int k = lane;
+            const double *xk = XU + k * NV;
+            const double sk = S[k];
+            double sn, cs;
+            mmpc_sincos(xk[2], &sn, &cs);
+            double rb[NV];
+#pragma unroll
+            for (int j = 0; j < NV; j++) rb[j] = 0.0;
+            if (k >= 1) {
+#pragma unroll
+                for (int j = 0; j < NX; j++) rb[j] = LAM[k * NX + j];
+            }
+            double *cv = CV + k * MMPC_NCV;
+            if (k < N) {
+                const double *uk = xk + NX;
+                const double a32 = -dt * uk[0] * sn, a42 = dt * uk[0] * cs, a43 = dt * xk[5], a34 = -dt * xk[5],
+                             a35 = -dt * xk[4], a45 = dt * xk[3], b30 = dt * cs, b40 = dt * sn;
+                cv[0] = 0.0; cv[1] = 1.0; cv[2] = dt; cv[3] = a32; cv[4] = a42; cv[5] = a43; cv[6] = a34; cv[7] = a35;
+                cv[8] = a45; cv[9] = b30; cv[10] = b40;
+                const double *xn1 = xk + NV;
+                double c[NX];
+                c[0] = xk[0] + dt * xk[3] - xn1[0]; c[1] = xk[1] + dt * xk[4] - xn1[1]; c[2] = xk[2] + dt * xk[5] - xn1[2];
+                c[3] = xk[3] + dt * (uk[0] * cs - xk[4] * xk[5]) - xn1[3];
+                c[4] = xk[4] + dt * (uk[0] * sn + xk[3] * xk[5]) - xn1[4];
+                c[5] = xk[5] + dt * uk[1] - xn1[5];
+                if (KIND == 0) { c[6] = xk[6] + dt * uk[2] - xn1[6]; c[7] = xk[7] + dt * uk[3] - xn1[7]; c[8] = xk[8] + dt * uk[4] - xn1[8]; }
+                const double *ln = LAM + (k + 1) * NX;
+#pragma unroll
+                for (int j = 0; j < NX; j++) { CD[k * NX + j] = c[j]; e_p = mmpc_max(e_p, fabs(c[j])); th += fabs(c[j]); zsum += fabs(ln[j]); }
+                // - A^T lam_{k+1}, - B^T lam_{k+1}  (sparse, base.py:19-26)
+                rb[0] -= ln[0]; rb[1] -= ln[1];
+                rb[2] -= ln[2] + a32 * ln[3] + a42 * ln[4];
+                rb[3] -= ln[3] + dt * ln[0] + a43 * ln[4];
+                rb[4] -= ln[4] + dt * ln[1] + a34 * ln[3];
+                rb[5] -= ln[5] + dt * ln[2] + a35 * ln[3] + a45 * ln[4];
+                rb[NX + 0] -= b30 * ln[3] + b40 * ln[4];
+                rb[NX + 1] -= dt * ln[5];
+                if (KIND == 0) {
+                    rb[6] -= ln[6]; rb[7] -= ln[7]; rb[8] -= ln[8];
+                    rb[NX + 2] -= dt * ln[6]; rb[NX + 3] -= dt * ln[7]; rb[NX + 4] -= dt * ln[8];
+                }
+            }
+            double rds = 2 * Sw * sk, selfz = 0.0;
+            phi += Sw * sk * sk;
+            MmpcLogAcc la; la.init();
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                const double *o = obs_ptr(k, m);
+                const double dx = xk[0] - o[0], dy = xk[1] - o[1], m2 = dx * dx + dy * dy, id = mmpc_rsqrt(m2), d = m2 * id;
+                const double nxv = dx * id, nyv = dy * id;
+                const double h = (o[2] + MMPC_BASE_R) - d - sk;
+                const double t = ls.ct[m], z = ls.cz[m];
+                rb[0] -= nxv * z; rb[1] -= nyv * z; rds -= z;
+                e_p = mmpc_max(e_p, fabs(h + t)); th += fabs(h + t); la.mul(t);
+                tzmax = mmpc_max(tzmax, t * z); tzmin = mmpc_min(tzmin, t * z); zsum += z;
+            }
+            if (NSELF) {
+                double dr[3], dz[3];
+                mmpc_arm_segments_fast(xk[NX - 3], xk[NX - 2], xk[NX - 1], dr, dz);
+                TRG[k * 8 + 0] = sn; TRG[k * 8 + 1] = cs;
+#pragma unroll
+                for (int a = 0; a < 3; a++) { TRG[k * 8 + 2 + a] = dr[a]; TRG[k * 8 + 5 + a] = dz[a]; }
+                const double sks = S[slack_idx(k)];
+                double sw = 0.0, sit = 0.0, swr = 0.0, swg[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int i = 0; i < NSELF; i++) {
+                    double g6[6];
+                    const double h = mmpc_self_row(i, xk[0], xk[1], cs, sn, dr, dz, g6) - sks;
+                    const double t = ls.st[i], z = ls.sz[i];
+#pragma unroll
+                    for (int a = 0; a < 6; a++) rb[mmpc_y(a)] += g6[a] * z;
+                    selfz += z;
+                    e_p = mmpc_max(e_p, fabs(h + t)); th += fabs(h + t); la.mul(t);
+                    tzmax = mmpc_max(tzmax, t * z); tzmin = mmpc_min(tzmin, t * z); zsum += z;
+                    if (k == N) {
+                        const double it_ = mmpc_rcp(t), w = z * it_;
+                        sw += w; sit += it_; swr += w * (h + t);
+#pragma unroll
+                        for (int a = 0; a < 6; a++) swg[a] += w * g6[a];
+                    }
+                }
+                if (k == N) {   // terminal self rows belong to s_{N-1} (Q1): hand their sums to lane N-1
+                    SN[0] = sw; SN[1] = sit; SN[2] = swr; SN[3] = selfz;
+#pragma unroll
+                    for (int a = 0; a < 6; a++) SN[4 + a] = swg[a];
+                }
+            }
+            if (k < N) rds -= selfz;
+            phi -= mu * la.value();
+            DS[k] = rds;
+#pragma unroll
+            for (int j = 0; j < NV; j++) RB[k * NV + j] = rb[j];
+        }
+        MMPC_WR(1) = e_p; MMPC_WR(2) = tzmax; MMPC_WR(3) = tzmin; MMPC_WR(4) = zsum; MMPC_WR(5) = phi; MMPC_WR(6) = th;
+        if (lane == 0) MISC[0] = 0.0;
+        if (NSELF == 0 && lane == 0) { for (int a = 0; a < 10; a++) SN[a] = 0.0; }
+        LANES_END
+        // ============================================================ E1 (pair lanes) + s residual
+        LANES_BEGIN
+        auto &ls = MMPC_LS;
+        double e_d = 0.0, e_p = MMPC_WR(1), tzmax = MMPC_WR(2), tzmin = MMPC_WR(3), zsum = MMPC_WR(4), phi = MMPC_WR(5), th = MMPC_WR(6);
+        MmpcLogAcc la; la.init();
+#pragma unroll
+        for (int p = 0; p < NPASS; p++) {
+            mmpc_sched_fence();
+            const int idx = lane + MMPC_WAVE * p;
+            if (idx < NPAIR) {
+                const int k = idx / NV, v = idx % NV;
+                double lo, hi; bool alo, ahi;
+                pair_bounds(k, v, lo, hi, alo, ahi);
+                const double val = XU[idx];
+                // cost gradient / value (diagonal weights): mpc_wholebody_qref.py:192-201,240-242
+                double e = val - XUREF[idx];
+                if (KIND == 1 && v == 2) e = mmpc_angle_diff(val, XUREF[idx]);
+                const double wq = w_diag(k, v);
+                double g = wq * e;
+                phi += 0.5 * wq * e * e;
+                if (v >= NX && k < N) {
+                    const double e2 = val - ULAST[k * NU + v - NX], ww = CST[MMPC_C_WW + v - NX];
+                    g += ww * e2; phi += 0.5 * ww * e2 * e2;
+                }
+                double r = RB[idx] + g;
+                if (alo) {
+                    const double t = ls.lo_t[p], z = ls.lo_z[p], rh = (lo - val) + t;
+                    r -= z; e_p = mmpc_max(e_p, fabs(rh)); th += fabs(rh); la.mul(t);
+                    tzmax = mmpc_max(tzmax, t * z); tzmin = mmpc_min(tzmin, t * z); zsum += z;
+                }
+                if (ahi) {
+                    const double t = ls.hi_t[p], z = ls.hi_z[p], rh = (val - hi) + t;
+                    r += z; e_p = mmpc_max(e_p, fabs(rh)); th += fabs(rh); la.mul(t);
+                    tzmax = mmpc_max(tzmax, t * z); tzmin = mmpc_min(tzmin, t * z); zsum += z;
+                }
+                RB[idx] = g;   // keep the plain cost gradient for the assembly / directional derivative
+                const bool isvar = v < NX ? (k >= 1) : (k < N);
+                if (isvar) e_d = mmpc_max(e_d, fabs(r));
+            }
+        }
+        phi -= mu * la.value();
+        if (lane < NS) e_d = mmpc_max(e_d, fabs(DS[lane] - (lane == N - 1 ? SN[3] : 0.0)));
+        MMPC_WR(0) = e_d; MMPC_WR(1) = e_p; MMPC_WR(2) = tzmax; MMPC_WR(3) = tzmin; MMPC_WR(4) = zsum; MMPC_WR(5) = phi; MMPC_WR(6) = th;
+        LANES_END
+        const double err_d = MMPC_RED_MAX(0), err_p = MMPC_RED_MAX(1), tzmax = MMPC_RED_MAX(2), tzmin = MMPC_RED_MIN(3),
+                     zsum = MMPC_RED_SUM(4), phi0_raw = MMPC_RED_SUM(5), th0 = MMPC_RED_SUM(6);
+        double sd = zsum / (nrows_act + (double)(NS * NX));
+        sd = (sd > 100.0 ? sd : 100.0) / 100.0;
+        E0 = mmpc_max(mmpc_max(err_d / sd, err_p), tzmax / sd);
+        if (!(E0 == E0) || !mmpc_finite(E0)) { status = 2; break; }
+        if (E0 <= tol) { status = 0; break; }
+        if (it == P.max_iter) break;
+        const double mu_eval = mu;
+        {
+            bool changed = false;
+            for (;;) {
+                const double compmu = mmpc_max(fabs(tzmax - mu), fabs(tzmin - mu));
+                const double Emu = mmpc_max(mmpc_max(err_d / sd, err_p), compmu / sd);
+                if (!(Emu <= 10.0 * mu && mu > tol / 10)) break;
+                mu = mmpc_max(tol / 10, mmpc_min(0.2 * mu, mu * sqrt(mu)));
+                changed = true;
+            }
+            if (changed) filt_init = 0;
+        }
+        // phi0 was accumulated with the barrier weight mu_eval; if mu changed, it is re-evaluated below
+        // together with the first trial (see merit pass with alpha = 0).
+        const bool need_phi0 = mu != mu_eval;
+
+        // ============================================================ Newton direction
+        int failed = 0;
+#pragma unroll 1
+        for (int attempt = 0; attempt < 2; attempt++) {
+            const bool exact = attempt == 0;
+            // ---- A1 (stage lanes): stage Hessian incl. elimination of s_k
+            LANES_BEGIN
+            auto &ls = MMPC_LS;
+            if (lane < NS) {
+                const int k = lane;
+                double hxx[NXX], qx[NX];
+#pragma unroll
+                for (int e = 0; e < NXX; e++) hxx[e] = 0.0;
+#pragma unroll
+                for (int j = 0; j < NX; j++) { hxx[j * (j + 1) / 2 + j] = CST[(k < N ? MMPC_C_WQ : MMPC_C_WP) + j]; qx[j] = RB[k * NV + j]; }
+                double h02 = 0.0;
+                if (k < N && exact) {
+                    const double *cv = CV + k * MMPC_NCV;
+                    const double l3 = LAM[(k + 1) * NX + 3], l4 = LAM[(k + 1) * NX + 4];
+                    hxx[5] += l3 * cv[4] - l4 * cv[3];
+                    hxx[19] += dt * l3;
+                    hxx[18] -= dt * l4;
+                    h02 = -(-l3 * cv[10] + l4 * cv[9]);
+                }
+                double hss = 2 * Sw, gss = 2 * Sw * S[k], vx[6] = {0, 0, 0, 0, 0, 0};
+                const double px = XU[k * NV], py = XU[k * NV + 1], sk = S[k];
+#pragma unroll
+                for (int m = 0; m < M; m++) {
+                    // row geometry is re-derived from x_k (cheaper than keeping it in registers)
+                    const double *o = obs_ptr(k, m);
+                    const double ddx = px - o[0], ddy = py - o[1], m2 = ddx * ddx + ddy * ddy, id = mmpc_rsqrt(m2), d = m2 * id;
+                    const double g0 = -ddx * id, g1 = -ddy * id, hv = (o[2] + MMPC_BASE_R) - d - sk;
+                    const double t = ls.ct[m], z = ls.cz[m], it_ = mmpc_rcp(t), w = z * it_;
+                    const double zh = mu * it_ + w * (hv + t);
+                    hxx[0] += w * g0 * g0; hxx[1] += w * g1 * g0; hxx[2] += w * g1 * g1;
+                    if (exact) { const double zi = z * id; hxx[0] -= zi * (1 - g0 * g0); hxx[1] += zi * g0 * g1; hxx[2] -= zi * (1 - g1 * g1); }
+                    qx[0] += g0 * zh; qx[1] += g1 * zh;
+                    hss += w; gss -= zh; vx[0] += w * g0; vx[1] += w * g1;
+                }
+                if (NSELF) {
+                    const double sn = TRG[k * 8], cs = TRG[k * 8 + 1], sks = S[slack_idx(k)];
+                    double dr[3], dz[3];
+#pragma unroll
+                    for (int a = 0; a < 3; a++) { dr[a] = TRG[k * 8 + 2 + a]; dz[a] = TRG[k * 8 + 5 + a]; }
+#pragma unroll
+                    for (int i = 0; i < NSELF; i++) {
+                        double g6[6];
+                        const double hv = mmpc_self_row(i, px, py, cs, sn, dr, dz, g6) - sks;
+                        const double t = ls.st[i], z = ls.sz[i], it_ = mmpc_rcp(t), w = z * it_;
+                        const double zh = mu * it_ + w * (hv + t);
+#pragma unroll
+                        for (int a = 0; a < 6; a++) {
+                            const double wa = w * g6[a];
+#pragma unroll
+                            for (int b = 0; b <= a; b++) hxx[mmpc_y(a) * (mmpc_y(a) + 1) / 2 + mmpc_y(b)] += wa * g6[b];
+                            qx[mmpc_y(a)] += g6[a] * zh;
+                            if (k < N) vx[a] += wa;
+                        }
+                        if (k < N) { hss += w; gss -= zh; }
+                    }
+                }
+                if (k == N - 1 && NSELF) {
+                    // Q1: terminal self rows -> s_{N-1}.  a = v + A^T vN, b = B^T vN, gamma = g_s - vN.c
+                    const double hssN = SN[0], gssN = -(mu * SN[1] + SN[2]);
+                    hss += hssN; gss += gssN;
+                    const double ih = mmpc_rcp(hss);
+                    double vf[NX], a[NX], b[NU];
+#pragma unroll
+                    for (int j = 0; j < NX; j++) { vf[j] = 0.0; a[j] = 0.0; }
+#pragma unroll
+                    for (int q = 0; q < 6; q++) { vf[mmpc_y(q)] = SN[4 + q]; a[mmpc_y(q)] = vx[q]; }
+                    const double *cv = CV + k * MMPC_NCV;
+                    a[0] += vf[0]; a[1] += vf[1];
+                    a[2] += vf[2] + cv[3] * vf[3] + cv[4] * vf[4];
+                    a[3] += vf[3] + dt * vf[0] + cv[5] * vf[4];
+                    a[4] += vf[4] + dt * vf[1] + cv[6] * vf[3];
+                    a[5] += vf[5] + dt * vf[2] + cv[7] * vf[3] + cv[8] * vf[4];
+                    b[0] = cv[9] * vf[3] + cv[10] * vf[4];
+                    b[1] = dt * vf[5];
+                    if (KIND == 0) { a[6] += vf[6]; a[7] += vf[7]; a[8] += vf[8]; b[2] = dt * vf[6]; b[3] = dt * vf[7]; b[4] = dt * vf[8]; }
+                    double gam = gss;
+#pragma unroll
+                    for (int j = 0; j < NX; j++) gam -= vf[j] * CD[k * NX + j];
+                    // store the un-eliminated block first, then apply the dense rank-one term in LDS
+#pragma unroll
+                    for (int e = 0; e < NXX; e++) HXX[k * NXX + e] = hxx[e];
+#pragma unroll
+                    for (int i = 0; i < NX; i++) {
+#pragma unroll
+                        for (int j = 0; j <= i; j++) HXX[k * NXX + i * (i + 1) / 2 + j] -= a[i] * a[j] * ih;
+                        QXU[k * NV + i] = qx[i] + a[i] * gam * ih;
+                    }
+#pragma unroll
+                    for (int c = 0; c < NU; c++) {
+#pragma unroll
+                        for (int j = 0; j < NX; j++) HUXL[c * NX + j] = -b[c] * a[j] * ih;
+#pragma unroll
+                        for (int d = 0; d <= c; d++) HUUL[c * (c + 1) / 2 + d] = -b[c] * b[d] * ih;
+                        QXU[k * NV + NX + c] = RB[k * NV + NX + c] + b[c] * gam * ih;
+                    }
+                } else {
+                    if (k == N - 1) {
+                        for (int c = 0; c < NU * NX; c++) HUXL[c] = 0.0;
+                        for (int c = 0; c < NUU; c++) HUUL[c] = 0.0;
+                    }
+                    const double ih = mmpc_rcp(hss);
+                    constexpr int ny = NSELF ? 6 : 2;
+#pragma unroll
+                    for (int a = 0; a < ny; a++) {
+#pragma unroll
+                        for (int b = 0; b <= a; b++) hxx[mmpc_y(a) * (mmpc_y(a) + 1) / 2 + mmpc_y(b)] -= vx[a] * vx[b] * ih;
+                        qx[mmpc_y(a)] += vx[a] * gss * ih;
+                    }
+                    if (k < N) {
+#pragma unroll
+                        for (int c = 0; c < NU; c++) QXU[k * NV + NX + c] = RB[k * NV + NX + c];
+                    }
+#pragma unroll
+                    for (int e = 0; e < NXX; e++) HXX[k * NXX + e] = hxx[e];
+#pragma unroll
+                    for (int j = 0; j < NX; j++) QXU[k * NV + j] = qx[j];
+                }
+                ls.hss = hss; ls.gss = gss;
+#pragma unroll
+                for (int a = 0; a < 6; a++) ls.vx[a] = vx[a];
+                HUX02[k] = h02;
+#pragma unroll
+                for (int c = 0; c < NU; c++) HUUD[k * NU + c] = 0.0;
+            }
+            LANES_END
+            // ---- A1 (pair lanes): barrier terms of the box rows (diagonal entries, unique owners)
+            LANES_BEGIN
+            auto &ls = MMPC_LS;
+#pragma unroll
+            for (int p = 0; p < NPASS; p++) {
+                mmpc_sched_fence();
+                const int idx = lane + MMPC_WAVE * p;
+                if (idx < NPAIR) {
+                    const int k = idx / NV, v = idx % NV;
+                    double lo, hi; bool alo, ahi;
+                    pair_bounds(k, v, lo, hi, alo, ahi);
+                    const double val = XU[idx];
+                    double wsum = 0.0, gsum = 0.0;
+                    if (alo) { const double t = ls.lo_t[p], z = ls.lo_z[p], it_ = mmpc_rcp(t), w = z * it_; wsum += w; gsum -= mu * it_ + w * ((lo - val) + t); }
+                    if (ahi) { const double t = ls.hi_t[p], z = ls.hi_z[p], it_ = mmpc_rcp(t), w = z * it_; wsum += w; gsum += mu * it_ + w * ((val - hi) + t); }
+                    if (alo || ahi) {
+                        QXU[idx] += gsum;
+                        if (v < NX) HXX[k * NXX + v * (v + 1) / 2 + v] += wsum;
+                        else HUUD[k * NU + v - NX] += wsum;
+                    }
+                }
+            }
+            LANES_END
+            // ---- R0: full copy of P_N
+            LANES_BEGIN
+            for (int e = lane; e < NX * NX; e += MMPC_WAVE) {
+                const int i = e / NX, j = e % NX;
+                PF[e] = HXX[N * NXX + (i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i)];
+            }
+            LANES_END
+#pragma unroll 1
+            for (int k = N - 1; k >= 0; k--) {
+                const double *cv = CV + k * MMPC_NCV;
+                // R1: T_ext = [ (P [A B])(:, non-unit columns) | p + P c ]   (loads first, then arithmetic)
+                LANES_BEGIN
+                auto &ls = MMPC_LS;
+#pragma unroll
+                for (int p = 0; p < R1P; p++) {
+                    const int e = lane + MMPC_WAVE * p;
+                    if (e < R1E) {
+                        const unsigned po = ls.r1_p[p], co = ls.r1_c[p];
+                        double v;
+                        if (co != 0xffffffffu) {
+                            const double p0 = PF[MMPC_B(po, 0)], p1 = PF[MMPC_B(po, 1)], p2 = PF[MMPC_B(po, 2)], p3 = PF[MMPC_B(po, 3)];
+                            const double c0 = cv[MMPC_B(co, 0)], c1 = cv[MMPC_B(co, 1)], c2 = cv[MMPC_B(co, 2)], c3 = cv[MMPC_B(co, 3)];
+                            mmpc_sched_fence();
+                            v = p0 * c0 + p1 * c1 + p2 * c2 + p3 * c3;
+                        } else {
+                            const int i = (int)po;
+                            double pr[NX], cd[NX];
+                            const double p0 = QXU[(k + 1) * NV + i];
+#pragma unroll
+                            for (int m = 0; m < NX; m++) { pr[m] = PF[i * NX + m]; cd[m] = CD[k * NX + m]; }
+                            mmpc_sched_fence();
+                            v = p0;
+#pragma unroll
+                            for (int m = 0; m < NX; m++) v += pr[m] * cd[m];
+                        }
+                        TT[e] = v;
+                    }
+                }
+                LANES_END
+                // R2: [F G^T; G Hh] = [A B]^T T + stage Hessian, [gx; gu] = q + [A B]^T pc
+                LANES_BEGIN
+                auto &ls = MMPC_LS;
+#pragma unroll
+                for (int p = 0; p < R2P; p++) {
+                    const int e = lane + MMPC_WAVE * p;
+                    if (e < R2E) {
+                        const unsigned to = ls.r2_t[p], co = ls.r2_c[p], kk = ls.r2_k[p];
+                        const double t0 = PF[MMPC_B(to, 0)], t1 = PF[MMPC_B(to, 1)], t2 = PF[MMPC_B(to, 2)], t3 = PF[MMPC_B(to, 3)];
+                        const double c0 = cv[MMPC_B(co, 0)], c1 = cv[MMPC_B(co, 1)], c2 = cv[MMPC_B(co, 2)], c3 = cv[MMPC_B(co, 3)];
+                        const int kind = (int)MMPC_B(kk, 0), a = (int)MMPC_B(kk, 1), b = (int)MMPC_B(kk, 2);
+                        double base;
+                        if (kind == 0) base = HXX[k * NXX + e];
+                        else if (kind == 1) base = (k == N - 1 ? HUXL[e - NXX] : 0.0) + ((a == 0 && b == 2) ? HUX02[k] : 0.0);
+                        else if (kind == 2) base = CST[MMPC_C_RW2 + a * NU + b] + (a == b ? HUUD[k * NU + a] : 0.0) + (k == N - 1 ? HUUL[e - NXX - NU * NX] : 0.0);
+                        else base = QXU[k * NV + a];
+                        mmpc_sched_fence();
+                        MM[e] = base + c0 * t0 + c1 * t1 + c2 * t2 + c3 * t3;
+                    }
+                }
+                LANES_END
+                // R3/R4: Cholesky of Hh in registers (every solving lane), one right-hand side per lane
+                LANES_BEGIN
+                if (lane <= NX) {
+                    double Hm[NUU], rhs[NU];
+#pragma unroll
+                    for (int e = 0; e < NUU; e++) Hm[e] = MH[e];
+#pragma unroll
+                    for (int a = 0; a < NU; a++) rhs[a] = lane < NX ? MG[a * NX + lane] : MGV[NX + a];
+                    mmpc_sched_fence();
+                    double Lc[NUU];   // lower factor, inverse pivots on the diagonal
+                    bool ok = true;
+#pragma unroll
+                    for (int j = 0; j < NU; j++) {
+                        double d = Hm[j * (j + 1) / 2 + j];
+#pragma unroll
+                        for (int q = 0; q < j; q++) d -= Lc[j * (j + 1) / 2 + q] * Lc[j * (j + 1) / 2 + q];
+                        if (!(d > 0.0) || !mmpc_finite(d)) { ok = false; d = 1.0; }
+                        const double il = mmpc_rsqrt(d);
+                        Lc[j * (j + 1) / 2 + j] = il;
+#pragma unroll
+                        for (int i = j + 1; i < NU; i++) {
+                            double v = Hm[i * (i + 1) / 2 + j];
+#pragma unroll
+                            for (int q = 0; q < j; q++) v -= Lc[i * (i + 1) / 2 + q] * Lc[j * (j + 1) / 2 + q];
+                            Lc[i * (i + 1) / 2 + j] = v * il;
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < NU; i++) {
+                        double v = rhs[i];
+#pragma unroll
+                        for (int q = 0; q < i; q++) v -= Lc[i * (i + 1) / 2 + q] * rhs[q];
+                        rhs[i] = v * Lc[i * (i + 1) / 2 + i];
+                    }
+#pragma unroll
+                    for (int i = NU - 1; i >= 0; i--) {
+                        double v = rhs[i];
+#pragma unroll
+                        for (int q = i + 1; q < NU; q++) v -= Lc[q * (q + 1) / 2 + i] * rhs[q];
+                        rhs[i] = v * Lc[i * (i + 1) / 2 + i];
+                    }
+#pragma unroll
+                    for (int a = 0; a < NU; a++) {
+                        if (lane < NX) KK[(k * NU + a) * NX + lane] = -rhs[a];
+                        else KF[k * NU + a] = -rhs[a];
+                    }
+                    if (!ok && lane == 0) MISC[0] = 1.0;
+                }
+                LANES_END
+                if (MISC[0] != 0.0) { failed = 1; break; }
+                // R5: P_k = F + G^T K,  p_k = gx + G^T kf
+                LANES_BEGIN
+                auto &ls = MMPC_LS;
+                if (lane < NXX + NX) {
+                    const bool isP = lane < NXX;
+                    const int i = isP ? (int)MMPC_B(ls.r5_ij, 0) : lane - NXX, j = (int)MMPC_B(ls.r5_ij, 1);
+                    double g[NU], kk[NU];
+                    const double f0 = isP ? MF[lane] : MGV[i];
+#pragma unroll
+                    for (int a = 0; a < NU; a++) { g[a] = MG[a * NX + i]; kk[a] = isP ? KK[(k * NU + a) * NX + j] : KF[k * NU + a]; }
+                    mmpc_sched_fence();
+                    double v = f0;
+#pragma unroll
+                    for (int a = 0; a < NU; a++) v += g[a] * kk[a];
+                    if (isP) { HXX[k * NXX + lane] = v; PF[i * NX + j] = v; PF[j * NX + i] = v; }
+                    else QXU[k * NV + i] = v;
+                }
+                LANES_END
+            }
+            if (!failed) break;
+            if (attempt == 1) break;
+            failed = 0;
+            LANES_BEGIN
+            if (lane == 0) MISC[0] = 0.0;
+            LANES_END
+        }
+        if (failed) { status = 2; break; }
+        // ---- forward roll-out, one phase per stage: lane i < NX computes dx_{k+1}[i]; the lanes whose
+        //      dynamics row carries an input also produce that input step (base.py:19-26)
+        LANES_BEGIN
+        for (int j = lane; j < NV; j += MMPC_WAVE) DXU[j] = 0.0;
+        LANES_END
+#pragma unroll 1
+        for (int k = 0; k < N; k++) {
+            LANES_BEGIN
+            auto &ls = MMPC_LS;
+            if (lane < NX) {
+                const int i = lane;
+                const double *cv = CV + k * MMPC_NCV;
+                // which input enters row i: rows 3,4 -> u0; 5 -> u1; 6.. -> u2..   (-1: none)
+                const int a = (int)MMPC_B(ls.f_x, 2) - 1, aa = a < 0 ? 0 : a;
+                double dx[NX], kr[NX], cf[5];
+#pragma unroll
+                for (int j = 0; j < NX; j++) { dx[j] = DXU[k * NV + j]; kr[j] = KK[(k * NU + aa) * NX + j]; }
+                const double kf0 = KF[k * NU + aa], c0 = CD[k * NX + i];
+#pragma unroll
+                for (int q = 0; q < 4; q++) cf[q] = cv[MMPC_B(ls.f_v, q)];
+                cf[4] = cv[MMPC_B(ls.f_x, 1)];
+                double xs[5];
+#pragma unroll
+                for (int q = 0; q < 4; q++) { const int c = (int)MMPC_B(ls.f_c, q); xs[q] = DXU[k * NV + (c < NX ? c : 0)]; }
+                { const int c = (int)MMPC_B(ls.f_x, 0); xs[4] = DXU[k * NV + (c < NX ? c : 0)]; }
+                mmpc_sched_fence();
+                double du = kf0;
+#pragma unroll
+                for (int j = 0; j < NX; j++) du += kr[j] * dx[j];
+                if (a >= 0 && i != 4) DXU[k * NV + NX + a] = du;
+                double v = c0;
+#pragma unroll
+                for (int q = 0; q < 4; q++) v += cf[q] * ((int)MMPC_B(ls.f_c, q) < NX ? xs[q] : du);
+                v += cf[4] * ((int)MMPC_B(ls.f_x, 0) < NX ? xs[4] : du);
+                DXU[(k + 1) * NV + i] = v;
+            }
+            LANES_END
+        }
+        // ---- D1: multiplier step and slack-variable step (stage lanes)
+        LANES_BEGIN
+        auto &ls = MMPC_LS;
+        if (lane < NS) {
+            const int k = lane;
+            const double *dx = DXU + k * NV;
+#pragma unroll
+            for (int i = 0; i < NX; i++) {
+                double v = QXU[k * NV + i];
+#pragma unroll
+                for (int j = 0; j < NX; j++) v += HXX[k * NXX + (i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i)] * dx[j];
+                DLAM[k * NX + i] = -v - LAM[k * NX + i];
+            }
+            double vdx = 0.0;
+            constexpr int ny = NSELF ? 6 : 2;
+#pragma unroll
+            for (int a = 0; a < ny; a++) vdx += ls.vx[a] * dx[mmpc_y(a)];
+            if (k == N - 1 && NSELF) {
+#pragma unroll
+                for (int a = 0; a < 6; a++) vdx += SN[4 + a] * DXU[N * NV + mmpc_y(a)];
+            }
+            DS[k] = -(ls.gss - vdx) * mmpc_rcp(ls.hss);
+            if (k == N) { for (int c = 0; c < NU; c++) DXU[N * NV + NX + c] = 0.0; }
+        }
+        LANES_END
+        // ---- D2: row steps, fraction-to-boundary, directional derivative
+        const double tau = mmpc_max(0.99, 1.0 - mu);
+        LANES_BEGIN
+        auto &ls = MMPC_LS;
+        double ap = 1.0, ad = 1.0, dphi = 0.0;
+        if (lane < NS) {
+            const int k = lane;
+            const double *dx = DXU + k * NV;
+            const double dsk = DS[k], dsks = DS[slack_idx(k)];
+            const double px = XU[k * NV], py = XU[k * NV + 1], sk = S[k];
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                const double *o = obs_ptr(k, m);
+                const double ddx = px - o[0], ddy = py - o[1], m2 = ddx * ddx + ddy * ddy, id = mmpc_rsqrt(m2), d = m2 * id;
+                const double hv = (o[2] + MMPC_BASE_R) - d - sk;
+                const double t = ls.ct[m], z = ls.cz[m];
+                const double jd = -(ddx * dx[0] + ddy * dx[1]) * id - dsk;
+                const double dtv = -(hv + t) - jd, it_ = mmpc_rcp(t), dzv = mu * it_ - z - z * it_ * dtv;
+                ls.cdt[m] = dtv;
+                if (dtv < 0) ap = mmpc_min(ap, -tau * t * mmpc_rcp(dtv));
+                if (dzv < 0) ad = mmpc_min(ad, -tau * z * mmpc_rcp(dzv));
+                dphi -= mu * dtv * it_;
+            }
+            double sn = 0.0, cs = 0.0, dr[3] = {0, 0, 0}, dz[3] = {0, 0, 0};
+            if (NSELF) {
+                sn = TRG[k * 8]; cs = TRG[k * 8 + 1];
+#pragma unroll
+                for (int a = 0; a < 3; a++) { dr[a] = TRG[k * 8 + 2 + a]; dz[a] = TRG[k * 8 + 5 + a]; }
+            }
+            const double sks = S[slack_idx(k)];
+#pragma unroll
+            for (int i = 0; i < NSELF; i++) {
+                double g6[6];
+                const double hv = mmpc_self_row(i, px, py, cs, sn, dr, dz, g6) - sks;
+                const double t = ls.st[i], z = ls.sz[i];
+                double jd = -dsks;
+#pragma unroll
+                for (int a = 0; a < 6; a++) jd += g6[a] * dx[mmpc_y(a)];
+                const double dtv = -(hv + t) - jd, it_ = mmpc_rcp(t), dzv = mu * it_ - z - z * it_ * dtv;
+                ls.sdt[i] = dtv;
+                if (dtv < 0) ap = mmpc_min(ap, -tau * t * mmpc_rcp(dtv));
+                if (dzv < 0) ad = mmpc_min(ad, -tau * z * mmpc_rcp(dzv));
+                dphi -= mu * dtv * it_;
+            }
+            dphi += 2 * Sw * S[k] * dsk;
+        }
+#pragma unroll
+        for (int p = 0; p < NPASS; p++) {
+            mmpc_sched_fence();
+            const int idx = lane + MMPC_WAVE * p;
+            if (idx < NPAIR) {
+                const int k = idx / NV, v = idx % NV;
+                double lo, hi; bool alo, ahi;
+                pair_bounds(k, v, lo, hi, alo, ahi);
+                const double val = XU[idx], dv = DXU[idx];
+                double e = val - XUREF[idx];
+                if (KIND == 1 && v == 2) e = mmpc_angle_diff(val, XUREF[idx]);
+                double g = w_diag(k, v) * e;
+                if (v >= NX && k < N) g += CST[MMPC_C_WW + v - NX] * (val - ULAST[k * NU + v - NX]);
+                dphi += g * dv;
+                if (alo) {
+                    const double t = ls.lo_t[p], z = ls.lo_z[p], dtv = -((lo - val) + t) + dv, it_ = mmpc_rcp(t), dzv = mu * it_ - z - z * it_ * dtv;
+                    if (dtv < 0) ap = mmpc_min(ap, -tau * t * mmpc_rcp(dtv));
+                    if (dzv < 0) ad = mmpc_min(ad, -tau * z * mmpc_rcp(dzv));
+                    dphi -= mu * dtv * it_;
+                }
+                if (ahi) {
+                    const double t = ls.hi_t[p], z = ls.hi_z[p], dtv = -((val - hi) + t) - dv, it_ = mmpc_rcp(t), dzv = mu * it_ - z - z * it_ * dtv;
+                    if (dtv < 0) ap = mmpc_min(ap, -tau * t * mmpc_rcp(dtv));
+                    if (dzv < 0) ad = mmpc_min(ad, -tau * z * mmpc_rcp(dzv));
+                    dphi -= mu * dtv * it_;
+                }
+            }
+        }
+        MMPC_WR(0) = ap; MMPC_WR(1) = ad; MMPC_WR(2) = dphi;
+        LANES_END
+        const double ap = MMPC_RED_MIN(0), ad = MMPC_RED_MIN(1), dphi = MMPC_RED_SUM(2);
+
+        // ---- merit of a trial point w + alpha dw (stage lanes + pair lanes in one phase)
+        auto merit_pass = [&](double alpha, double &phi_out, double &th_out) {
+            LANES_BEGIN
+            auto &ls = MMPC_LS;
+            double phi = 0.0, th = 0.0;
+            MmpcLogAcc la; la.init();
+            if (lane < NS) {
+                const int k = lane;
+                double xk[NX];
+#pragma unroll
+                for (int j = 0; j < NX; j++) xk[j] = XU[k * NV + j] + alpha * DXU[k * NV + j];
+                const double sk = S[k] + alpha * DS[k];
+                const int ks = slack_idx(k);
+                const double sks = S[ks] + alpha * DS[ks];
+                phi += Sw * sk * sk;
+                double sn, cs;
+                mmpc_sincos(xk[2], &sn, &cs);
+                if (k < N) {
+                    double uk[NU];
+#pragma unroll
+                    for (int a = 0; a < NU; a++) uk[a] = XU[k * NV + NX + a] + alpha * DXU[k * NV + NX + a];
+                    const double *x1 = XU + (k + 1) * NV, *d1 = DXU + (k + 1) * NV;
+                    th += fabs(xk[0] + dt * xk[3] - (x1[0] + alpha * d1[0]));
+                    th += fabs(xk[1] + dt * xk[4] - (x1[1] + alpha * d1[1]));
+                    th += fabs(xk[2] + dt * xk[5] - (x1[2] + alpha * d1[2]));
+                    th += fabs(xk[3] + dt * (uk[0] * cs - xk[4] * xk[5]) - (x1[3] + alpha * d1[3]));
+                    th += fabs(xk[4] + dt * (uk[0] * sn + xk[3] * xk[5]) - (x1[4] + alpha * d1[4]));
+                    th += fabs(xk[5] + dt * uk[1] - (x1[5] + alpha * d1[5]));
+                    if (KIND == 0) {
+                        th += fabs(xk[6] + dt * uk[2] - (x1[6] + alpha * d1[6]));
+                        th += fabs(xk[7] + dt * uk[3] - (x1[7] + alpha * d1[7]));
+                        th += fabs(xk[8] + dt * uk[4] - (x1[8] + alpha * d1[8]));
+                    }
+                }
+#pragma unroll
+                for (int m = 0; m < M; m++) {
+                    const double *o = obs_ptr(k, m);
+                    const double dx = xk[0] - o[0], dy = xk[1] - o[1];
+                    const double h = (o[2] + MMPC_BASE_R) - sqrt(dx * dx + dy * dy) - sk;
+                    const double tv = ls.ct[m] + alpha * ls.cdt[m];
+                    th += fabs(h + tv); la.mul(tv);
+                }
+                if (NSELF) {
+                    double dr[3], dz[3];
+                    mmpc_arm_segments_fast(xk[NX - 3], xk[NX - 2], xk[NX - 1], dr, dz);
+#pragma unroll
+                    for (int i = 0; i < NSELF; i++) {
+                        const double h = mmpc_self_row(i, xk[0], xk[1], cs, sn, dr, dz, nullptr) - sks;
+                        const double tv = ls.st[i] + alpha * ls.sdt[i];
+                        th += fabs(h + tv); la.mul(tv);
+                    }
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < NPASS; p++) {
+                mmpc_sched_fence();
+                const int idx = lane + MMPC_WAVE * p;
+                if (idx < NPAIR) {
+                    const int k = idx / NV, v = idx % NV;
+                    double lo, hi; bool alo, ahi;
+                    pair_bounds(k, v, lo, hi, alo, ahi);
+                    const double v0 = XU[idx], dv = DXU[idx], val = v0 + alpha * dv;
+                    double e = val - XUREF[idx];
+                    if (KIND == 1 && v == 2) e = mmpc_angle_diff(val, XUREF[idx]);
+                    phi += 0.5 * w_diag(k, v) * e * e;
+                    if (v >= NX && k < N) { const double e2 = val - ULAST[k * NU + v - NX]; phi += 0.5 * CST[MMPC_C_WW + v - NX] * e2 * e2; }
+                    if (alo) {
+                        const double t0 = ls.lo_t[p], tv = t0 + alpha * (-((lo - v0) + t0) + dv);
+                        th += fabs((lo - val) + tv); la.mul(tv);
+                    }
+                    if (ahi) {
+                        const double t0 = ls.hi_t[p], tv = t0 + alpha * (-((v0 - hi) + t0) - dv);
+                        th += fabs((val - hi) + tv); la.mul(tv);
+                    }
+                }
+            }
+            phi -= mu * la.value();
+            MMPC_WR(0) = phi; MMPC_WR(1) = th;
+            LANES_END
+            phi_out = MMPC_RED_SUM(0);
+            th_out = MMPC_RED_SUM(1);
+        };
+        double phi0 = phi0_raw;
+        if (!filt_init) { nfilt = 0; th_max = 1e4 * mmpc_max(1.0, th0); th_min = 1e-4 * mmpc_max(1.0, th0); filt_init = 1; }
+
+        // ---- filter line search (+ filter reset heuristic).  Trial -1 (only when mu changed after the
+        //      evaluation) re-evaluates the barrier objective at alpha = 0 with the new mu.
+        double alpha = ap;
+        int lspass = 0, lsi = need_phi0 ? -1 : 0;
+#pragma unroll 1
+        for (;;) {
+            double phi, th;
+            merit_pass(lsi < 0 ? 0.0 : alpha, phi, th);
+            if (lsi < 0) { phi0 = phi; lsi = 0; continue; }
+            bool okf = th < th_max;
+            for (int i = 0; i < nfilt && okf; i++) if (th >= FILT[2 * i] && phi >= FILT[2 * i + 1]) okf = false;
+            const bool ftype = dphi < 0 && th0 <= th_min && alpha * mmpc_powf(-dphi, 2.3f) > mmpc_powf(th0, 1.1f);
+            bool accepted = false, augment = false;
+            if (okf) {
+                if (ftype) accepted = phi <= phi0 + 1e-8 * alpha * dphi + 1e-14 * fabs(phi0);
+                else if (th <= (1 - 1e-5) * th0 || phi <= phi0 - 1e-5 * th0) { accepted = true; augment = true; }
+            }
+            if (augment) {
+                int slot = nfilt;
+                if (nfilt >= MMPC_FCAP) { slot = 0; for (int i = 1; i < MMPC_FCAP; i++) if (FILT[2 * i] > FILT[2 * slot]) slot = i; }
+                else nfilt++;
+                LANES_BEGIN
+                if (lane == 0) { FILT[2 * slot] = (1 - 1e-5) * th0; FILT[2 * slot + 1] = phi0 - 1e-5 * th0; }
+                LANES_END
+            }
+            if (accepted) break;
+            if (lsi < MMPC_MAX_LS - 1) { alpha *= 0.5; lsi++; continue; }
+            // every trial of this pass was rejected
+            if (lspass == 0 && nfilt > 0) { nfilt = 0; lspass = 1; lsi = 0; alpha = ap; continue; }   // filter reset heuristic
+            break;
+        }
+        // ---- update
+        LANES_BEGIN
+        auto &ls = MMPC_LS;
+        if (lane < NS) {
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                const double t = ls.ct[m], z = ls.cz[m], dtv = ls.cdt[m];
+                const double it_ = mmpc_rcp(t), dzv = mu * it_ - z - z * it_ * dtv;
+                ls.ct[m] = t + alpha * dtv; ls.cz[m] = z + ad * dzv;
+            }
+#pragma unroll
+            for (int i = 0; i < NSELF; i++) {
+                const double t = ls.st[i], z = ls.sz[i], dtv = ls.sdt[i];
+                const double it_ = mmpc_rcp(t), dzv = mu * it_ - z - z * it_ * dtv;
+                ls.st[i] = t + alpha * dtv; ls.sz[i] = z + ad * dzv;
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < NPASS; p++) {
+            mmpc_sched_fence();
+            const int idx = lane + MMPC_WAVE * p;
+            if (idx < NPAIR) {
+                const int k = idx / NV, v = idx % NV;
+                double lo, hi; bool alo, ahi;
+                pair_bounds(k, v, lo, hi, alo, ahi);
+                const double val = XU[idx], dv = DXU[idx];
+                if (alo) {
+                    const double t = ls.lo_t[p], z = ls.lo_z[p], dtv = -((lo - val) + t) + dv, it_ = mmpc_rcp(t), dzv = mu * it_ - z - z * it_ * dtv;
+                    ls.lo_t[p] = t + alpha * dtv; ls.lo_z[p] = z + ad * dzv;
+                }
+                if (ahi) {
+                    const double t = ls.hi_t[p], z = ls.hi_z[p], dtv = -((val - hi) + t) - dv, it_ = mmpc_rcp(t), dzv = mu * it_ - z - z * it_ * dtv;
+                    ls.hi_t[p] = t + alpha * dtv; ls.hi_z[p] = z + ad * dzv;
+                }
+            }
+        }
+        LANES_END
+        LANES_BEGIN
+        for (int i = lane; i < NPAIR; i += MMPC_WAVE) if (i >= NX) XU[i] += alpha * DXU[i];   // x_0 is data
+        for (int i = lane; i < NS * NX; i += MMPC_WAVE) if (i >= NX) LAM[i] += alpha * DLAM[i];
+        for (int i = lane; i < NS; i += MMPC_WAVE) S[i] += alpha * DS[i];
+        LANES_END
+    }
+
+    // ------------------------------------------------------------------ results
+    LANES_BEGIN
+    double f = 0.0;
+    for (int idx = lane; idx < NPAIR; idx += MMPC_WAVE) {
+        const int k = idx / NV, v = idx % NV;
+        const double val = XU[idx];
+        double e = val - XUREF[idx];
+        if (KIND == 1 && v == 2) e = mmpc_angle_diff(val, XUREF[idx]);
+        f += 0.5 * w_diag(k, v) * e * e;
+        if (v >= NX && k < N) { const double e2 = val - ULAST[k * NU + v - NX]; f += 0.5 * CST[MMPC_C_WW + v - NX] * e2 * e2; }
+        if (v < NX) io.X[k * NX + v] = val;
+        else if (k < N) io.U[k * NU + v - NX] = val;
+    }
+    for (int i = lane; i < NS; i += MMPC_WAVE) { io.s[i] = S[i]; f += Sw * S[i] * S[i]; }
+    MMPC_WR(0) = f;
+    LANES_END
+    const double cost = MMPC_RED_SUM(0);
+    LANES_BEGIN
+    if (lane == 0) { *io.status = status; *io.iters = it; *io.cost = cost; *io.err = E0; }
+    LANES_END
+}

@@ -4,11 +4,13 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <new>
 
 #include "../../include/mmpc.h"
 #include "mmpc_core.h"
+#include "mmpc_fast.h"
 
 template <int KIND>
 __global__ __launch_bounds__(MMPC_WAVE) void mmpc_solve_kernel(
@@ -40,6 +42,40 @@ __global__ __launch_bounds__(MMPC_WAVE) void mmpc_solve_kernel(
     mmpc_solve_one<KIND>(P, io, lds);
 }
 
+template <int KIND, int N, int MC>
+__global__ __launch_bounds__(MMPC_WAVE) void mmpc_fast_kernel(
+    const MmpcParams *__restrict__ Pp, int B, const double *__restrict__ x_init, const double *__restrict__ traj_ref,
+    const double *__restrict__ u_ref, const double *__restrict__ u_last, const double *__restrict__ x_guess,
+    const double *__restrict__ obs, double *__restrict__ X, double *__restrict__ U, double *__restrict__ s,
+    int *__restrict__ status, int *__restrict__ iters, double *__restrict__ cost, double *__restrict__ err) {
+    extern __shared__ double lds[];
+    typedef MmpcDims<KIND> D;
+    const int b = (int)blockIdx.x;
+    if (b >= B) return;
+    const MmpcParams &P = *Pp;
+    const int M = MC;
+    const size_t so = (size_t)(P.obs_per_stage ? N + 1 : 1) * M * 3;
+    MmpcIO io;
+    io.x_init = x_init + (size_t)b * D::NX;
+    io.traj_ref = traj_ref + (size_t)b * (N + 1) * D::NX;
+    io.u_ref = u_ref + (size_t)b * N * D::NU;
+    io.u_last = u_last + (size_t)b * N * D::NU;
+    io.x_guess = x_guess ? x_guess + (size_t)b * (N + 1) * D::NX : nullptr;
+    io.obs = obs + (size_t)b * so;
+    io.X = X + (size_t)b * (N + 1) * D::NX;
+    io.U = U + (size_t)b * N * D::NU;
+    io.s = s + (size_t)b * (N + 1);
+    io.status = status + b;
+    io.iters = iters + b;
+    io.cost = cost + b;
+    io.err = err + b;
+    mmpc_solve_fast<KIND, N, MC>(P, io, lds);
+}
+
+// (kind, N, M) triples with a specialised kernel; everything else runs the generic kernel.
+// BASELINE configs C3/C4 (0,20,5), C5 (0,30,8), C2 (1,15,3); the reference demo (0,20,3).
+#define MMPC_FAST_LIST(X) X(0, 20, 5) X(0, 30, 8) X(0, 20, 3) X(1, 15, 3)
+
 // out_u0[b][a] = U[b][0][a]
 __global__ void mmpc_gather_u0(int B, int NU, int stride, const double *__restrict__ U, double *__restrict__ u0) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -51,6 +87,9 @@ struct mmpc_handle_s {
     MmpcParams hp;          // host copy
     MmpcParams *dp;         // device copy
     int nx, nu, lds_bytes;
+    int fast;               // 1: specialised kernel exists for (kind, N, M)
+    int fast_lds_bytes;
+    int diag;               // weights are diagonal (required by the specialised kernel)
     int warm;               // 1 once a solve has filled u_latest (x_guess)
     // device-side state and staging (capacity max_batch)
     double *d_x_init, *d_traj, *d_uref, *d_obs, *d_ulatest, *d_xguess, *d_X, *d_U, *d_s, *d_cost, *d_err, *d_u0;
@@ -87,14 +126,24 @@ static void default_weights(mmpc_handle h) {
     p.S = 1e5;
 }
 
+static void update_diag(mmpc_handle h) {
+    const MmpcParams &p = h->hp;
+    const int nx = h->nx, nu = h->nu;
+    int d = 1;
+    for (int i = 0; i < nx; i++) for (int j = 0; j < nx; j++) if (i != j && (p.Q2[i * nx + j] != 0.0 || p.P2[i * nx + j] != 0.0)) d = 0;
+    for (int i = 0; i < nu; i++) for (int j = 0; j < nu; j++) if (i != j && (p.R2[i * nu + j] != 0.0 || p.W2[i * nu + j] != 0.0)) d = 0;
+    h->diag = d;
+}
+
 static int upload_params(mmpc_handle h) {
+    update_diag(h);
     HIPCHK(h, hipMemcpy(h->dp, &h->hp, sizeof(MmpcParams), hipMemcpyHostToDevice));
     return MMPC_OK;
 }
 
 extern "C" const char *mmpc_version(void) { return "mmpc 0.1 (gfx950)"; }
 extern "C" const char *mmpc_last_error(mmpc_handle h) { return h ? h->err : "null handle"; }
-extern "C" int mmpc_lds_bytes(mmpc_handle h) { return h ? h->lds_bytes : MMPC_E_ARG; }
+extern "C" int mmpc_lds_bytes(mmpc_handle h) { return h ? ((h->fast && h->diag) ? h->fast_lds_bytes : h->lds_bytes) : MMPC_E_ARG; }
 
 extern "C" int mmpc_create(const mmpc_config *cfg, mmpc_handle *out) {
     if (!cfg || !out) return MMPC_E_ARG;
@@ -129,6 +178,17 @@ extern "C" int mmpc_create(const mmpc_config *cfg, mmpc_handle *out) {
         HIPCHK(h, hipFuncSetAttribute((const void *)mmpc_solve_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes));
     else
         HIPCHK(h, hipFuncSetAttribute((const void *)mmpc_solve_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes));
+    h->fast = 0; h->fast_lds_bytes = 0;
+    {
+#define MMPC_X(K, NN, MM)                                                                                            \
+        if (cfg->kind == K && cfg->N == NN && cfg->M == MM) {                                                                       \
+            h->fast = 1;                                                                                               \
+            h->fast_lds_bytes = mmpc_fast_layout<K, NN>(MM, p.obs_per_stage).total * (int)sizeof(double);         \
+            HIPCHK(h, hipFuncSetAttribute((const void *)mmpc_fast_kernel<K, NN, MM>, hipFuncAttributeMaxDynamicSharedMemorySize, h->fast_lds_bytes)); \
+        }
+        MMPC_FAST_LIST(MMPC_X)
+#undef MMPC_X
+    }
     const size_t B = (size_t)cfg->max_batch, N = (size_t)cfg->N, nx = (size_t)h->nx, nu = (size_t)h->nu;
     const size_t nobs = (size_t)(p.obs_per_stage ? N + 1 : 1) * (size_t)cfg->M * 3;
     HIPCHK(h, hipMalloc(&h->dp, sizeof(MmpcParams)));
@@ -201,7 +261,15 @@ static int launch(mmpc_handle h, int B, const double *x_init, const double *traj
         h->hp.use_xguess = want;
         HIPCHK(h, hipMemcpyAsync(h->dp, &h->hp, sizeof(MmpcParams), hipMemcpyHostToDevice, st));
     }
-    if (h->cfg.kind == MMPC_KIND_WHOLEBODY)
+    const bool use_fast = h->fast && h->diag && !getenv("MMPC_FORCE_GENERIC");
+    if (use_fast) {
+#define MMPC_X(K, NN, MM)                                                                                              \
+        if (h->cfg.kind == K && h->cfg.N == NN && h->cfg.M == MM)                                                                          \
+            hipLaunchKernelGGL((mmpc_fast_kernel<K, NN, MM>), dim3(B), dim3(MMPC_WAVE), h->fast_lds_bytes, st, h->dp, B, x_init, traj, \
+                               uref, ulast, xguess, obs, X, U, s, status, iters, cost, err);
+        MMPC_FAST_LIST(MMPC_X)
+#undef MMPC_X
+    } else if (h->cfg.kind == MMPC_KIND_WHOLEBODY)
         hipLaunchKernelGGL(mmpc_solve_kernel<0>, dim3(B), dim3(MMPC_WAVE), h->lds_bytes, st, h->dp, B, x_init, traj, uref,
                            ulast, xguess, obs, X, U, s, status, iters, cost, err);
     else

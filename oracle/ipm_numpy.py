@@ -29,7 +29,7 @@ from . import nlp
 
 class Options:
     tol = 1e-8
-    mu_init = 0.1
+    mu_init = 1.0
     max_iter = 200
     kappa_eps = 10.0
     kappa_mu = 0.2
@@ -37,15 +37,19 @@ class Options:
     tau_min = 0.99
     t_init_min = 1e-2
     eta = 1e-4
-    max_ls = 25
+    max_ls = 20
     reg0 = 1e-6
     exact_hessian = True
     curv_dyn = True
     curv_circ = True
-    curv_self = True
+    curv_self = False
     piv_frac = 0.0
     nu_lam = 0.0
     filter = True
+    inertia = True
+    delta0 = 1e-4
+    delta_min = 1e-20
+    delta_max = 1e10
 
 
 def _rows_for_stage(prob, k):
@@ -166,6 +170,7 @@ def solve(prob: nlp.Problem, U0=None, X0=None, opt: Options = None, verbose=Fals
     RW2 = (p.R + p.R.T) + (p.W + p.W.T)
     status = 1
     nu_merit = 1.0
+    delta_last = 0.0
     filt = None
     nfail = 0
     it = 0
@@ -219,15 +224,15 @@ def solve(prob: nlp.Problem, U0=None, X0=None, opt: Options = None, verbose=Fals
             nu_merit = 1.0
             filt = None
         # ---------------- stage QP assembly + Riccati ----------------------
-        def factor(use_exact):
+        def factor(use_exact, delta=0.0):
             Hxx = []; Hux = []; Huu = []; qx = []; qu = []
             hss = 2 * p.S * np.ones(N + 1)
             gss = gs.copy()
             vx = np.zeros((N + 1, nx))        # sum_i w_i J_i,x for rows bound to s_k from stage k
             vxN = np.zeros(nx)                # Q1: stage-N self rows bound to s_{N-1}
             for k in range(N + 1):
-                H = (Q2 if k < N else P2).copy()
-                Hu = RW2.copy() if k < N else None
+                H = (Q2 if k < N else P2) + delta * np.eye(nx)
+                Hu = RW2 + delta * np.eye(nu) if k < N else None
                 Hc = np.zeros((nu, nx)) if k < N else None
                 g = gX[k].copy()
                 gu = gU[k].copy() if k < N else None
@@ -294,8 +299,19 @@ def solve(prob: nlp.Problem, U0=None, X0=None, opt: Options = None, verbose=Fals
             return Pm, pv, K, kf, hss, gss, vx, vxN
         fac = factor(opt.exact_hessian) if opt.exact_hessian else None
         nreg = 0
+        if fac is None and opt.exact_hessian and opt.inertia:
+            # IPOPT-style inertia correction: exact Hessian + delta*I, delta growing until the
+            # stage-wise factorisation has only positive pivots
+            delta = opt.delta0 if delta_last == 0.0 else max(opt.delta_min, delta_last / 3.0)
+            while fac is None and delta <= opt.delta_max:
+                nreg += 1
+                fac = factor(True, delta)
+                if fac is None:
+                    delta = delta * (100.0 if delta_last == 0.0 else 8.0)
+            if fac is not None:
+                delta_last = delta
         if fac is None:
-            nreg = 1 if opt.exact_hessian else 0
+            nreg += 1 if opt.exact_hessian else 0
             fac = factor(False)
         Pm, pv, K, kf, hss, gss, vx, vxN = fac
         dX = np.zeros_like(X); dU = np.zeros_like(U)
@@ -351,22 +367,28 @@ def solve(prob: nlp.Problem, U0=None, X0=None, opt: Options = None, verbose=Fals
                 filt = []
                 th_max = 1e4 * max(1.0, th0)
                 th_min = 1e-4 * max(1.0, th0)
-            for ls in range(opt.max_ls):
-                Xn = X + alpha * dX; Un = U + alpha * dU; sn = s + alpha * ds
-                tn = [t[k] + alpha * dt[k] for k in range(N + 1)]
-                phi, th = _merit_parts(prob, rows, Xn, Un, sn, tn, mu)
-                ok_f = th < th_max and all(not (th >= fj[0] and phi >= fj[1]) for fj in filt)
-                ftype = (dphi < 0 and th0 <= th_min and alpha * (-dphi) ** 2.3 > th0 ** 1.1)
-                if ok_f:
-                    if ftype:
-                        if phi <= phi0 + 1e-8 * alpha * dphi + 1e-14 * abs(phi0):
+            for lspass in range(2):
+                alpha = ap
+                for ls in range(opt.max_ls):
+                    Xn = X + alpha * dX; Un = U + alpha * dU; sn = s + alpha * ds
+                    tn = [t[k] + alpha * dt[k] for k in range(N + 1)]
+                    phi, th = _merit_parts(prob, rows, Xn, Un, sn, tn, mu)
+                    ok_f = th < th_max and all(not (th >= fj[0] and phi >= fj[1]) for fj in filt)
+                    ftype = (dphi < 0 and th0 <= th_min and alpha * (-dphi) ** 2.3 > th0 ** 1.1)
+                    if ok_f:
+                        if ftype:
+                            if phi <= phi0 + 1e-8 * alpha * dphi + 1e-14 * abs(phi0):
+                                accepted = True
+                                break
+                        elif th <= (1 - 1e-5) * th0 or phi <= phi0 - 1e-5 * th0:
                             accepted = True
+                            _filter_add(filt, ((1 - 1e-5) * th0, phi0 - 1e-5 * th0))
                             break
-                    elif th <= (1 - 1e-5) * th0 or phi <= phi0 - 1e-5 * th0:
-                        accepted = True
-                        filt.append(((1 - 1e-5) * th0, phi0 - 1e-5 * th0))
-                        break
-                alpha *= 0.5
+                    if ls < opt.max_ls - 1:
+                        alpha *= 0.5
+                if accepted or not filt:
+                    break
+                filt.clear()      # filter reset heuristic: the filter blocked every trial step
             dm = dphi
         else:
             if th0 > 1e-14:
@@ -395,6 +417,18 @@ def solve(prob: nlp.Problem, U0=None, X0=None, opt: Options = None, verbose=Fals
         lam = lam + alpha * (lam_new - lam)
     return dict(X=X, U=U, s=s, status=status, iters=it, cost=nlp.cost(prob, X, U, s), E0=E0,
                 lam=lam, mu=mu, nfail=nfail)
+
+
+FCAP = 16
+
+
+def _filter_add(filt, ent):
+    """fixed-capacity filter: when full, the entry with the largest theta is replaced"""
+    if len(filt) < FCAP:
+        filt.append(ent)
+    else:
+        im = max(range(FCAP), key=lambda i: (filt[i][0], -i))
+        filt[im] = ent
 
 
 def _chol_reg(H, reg0):

@@ -553,30 +553,35 @@ int mmpc_oracle_solve(const oracle_cfg *cfg, const double *x_init, const double 
         merit_parts(w, w->X, w->U, w->s, w->t, mu, &phi0, &th0);
         if (!filt_init) { nfilt = 0; th_max = 1e4 * fmax(1.0, th0); th_min = 1e-4 * fmax(1.0, th0); filt_init = 1; }
         double alpha = ap; int accepted = 0;
-        for (int ls = 0; ls < 20; ls++) {
-            for (int k = 0; k <= N; k++) {
-                for (int j = 0; j < nx; j++) Xn[k][j] = w->X[k][j] + alpha * w->dX[k][j];
-                if (k < N) for (int j = 0; j < nu; j++) Un[k][j] = w->U[k][j] + alpha * w->dU[k][j];
-                sn[k] = w->s[k] + alpha * w->ds[k];
-                for (int r = 0; r < w->nrow; r++) if (w->act[k][r]) tn[k][r] = w->t[k][r] + alpha * w->dt_[k][r];
-            }
-            double phi, th;
-            merit_parts(w, Xn, Un, sn, tn, mu, &phi, &th);
-            int okf = th < th_max;
-            for (int i = 0; i < nfilt && okf; i++) if (th >= filt[i].th && phi >= filt[i].phi) okf = 0;
-            int ftype = dphi < 0 && th0 <= th_min && alpha * pow(-dphi, 2.3) > pow(th0, 1.1);
-            if (okf) {
-                if (ftype) {
-                    if (phi <= phi0 + 1e-8 * alpha * dphi + 1e-14 * fabs(phi0)) { accepted = 1; break; }
-                } else if (th <= (1 - 1e-5) * th0 || phi <= phi0 - 1e-5 * th0) {
-                    accepted = 1;
-                    fent ne = {(1 - 1e-5) * th0, phi0 - 1e-5 * th0};
-                    if (nfilt < FCAP) filt[nfilt++] = ne;
-                    else { int im = 0; for (int i = 1; i < FCAP; i++) if (filt[i].th > filt[im].th) im = i; filt[im] = ne; }
-                    break;
+        for (int lspass = 0; lspass < 2 && !accepted; lspass++) {
+            alpha = ap;
+            for (int ls = 0; ls < 20; ls++) {
+                for (int k = 0; k <= N; k++) {
+                    for (int j = 0; j < nx; j++) Xn[k][j] = w->X[k][j] + alpha * w->dX[k][j];
+                    if (k < N) for (int j = 0; j < nu; j++) Un[k][j] = w->U[k][j] + alpha * w->dU[k][j];
+                    sn[k] = w->s[k] + alpha * w->ds[k];
+                    for (int r = 0; r < w->nrow; r++) if (w->act[k][r]) tn[k][r] = w->t[k][r] + alpha * w->dt_[k][r];
                 }
+                double phi, th;
+                merit_parts(w, Xn, Un, sn, tn, mu, &phi, &th);
+                int okf = th < th_max;
+                for (int i = 0; i < nfilt && okf; i++) if (th >= filt[i].th && phi >= filt[i].phi) okf = 0;
+                int ftype = dphi < 0 && th0 <= th_min && alpha * pow(-dphi, 2.3) > pow(th0, 1.1);
+                if (okf) {
+                    if (ftype) {
+                        if (phi <= phi0 + 1e-8 * alpha * dphi + 1e-14 * fabs(phi0)) { accepted = 1; break; }
+                    } else if (th <= (1 - 1e-5) * th0 || phi <= phi0 - 1e-5 * th0) {
+                        accepted = 1;
+                        fent ne = {(1 - 1e-5) * th0, phi0 - 1e-5 * th0};
+                        if (nfilt < FCAP) filt[nfilt++] = ne;
+                        else { int im = 0; for (int i = 1; i < FCAP; i++) if (filt[i].th > filt[im].th) im = i; filt[im] = ne; }
+                        break;
+                    }
+                }
+                if (ls < 19) alpha *= 0.5;
             }
-            if (ls < 19) alpha *= 0.5;
+            if (accepted || nfilt == 0) break;
+            nfilt = 0; /* filter reset heuristic: the filter blocked every trial step */
         }
         nf += !accepted;
         /* ---- update */

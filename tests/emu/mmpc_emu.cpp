@@ -5,7 +5,7 @@
 // against the oracle before anything is launched on a GPU.  `reverse` runs the lanes of every
 // phase in the opposite order: a result that changes exposes an intra-phase data race.
 #define MMPC_EMU 1
-#include "../../mobile-manipulator-mpc_amd/csrc/mmpc_core.h"
+#include "../../mobile-manipulator-mpc_amd/csrc/mmpc_fast.h"
 #include <stdlib.h>
 #include <string.h>
 
@@ -36,6 +36,51 @@ static void run(const MmpcParams *P, int B, const double *x_init, const double *
         mmpc_solve_one<KIND>(*P, io, lds, emu);
         free(lds);
     }
+}
+
+template <int KIND, int N, int MC>
+static void run_fast(const MmpcParams *P, int B, const double *x_init, const double *traj_ref, const double *u_ref,
+                     const double *u_last, const double *x_guess, const double *obs, double *X, double *U, double *s,
+                     int *status, int *iters, double *cost, double *err, int reverse) {
+    typedef MmpcDims<KIND> D;
+    const int M = MC;
+    MmpcFastLayout L = mmpc_fast_layout<KIND, N>(M, P->obs_per_stage);
+    const size_t so = (size_t)(P->obs_per_stage ? N + 1 : 1) * M * 3;
+    for (int b = 0; b < B; b++) {
+        double *lds = (double *)malloc(sizeof(double) * L.total);
+        for (int i = 0; i < L.total; i++) lds[i] = NAN;
+        MmpcIO io;
+        io.x_init = x_init + (size_t)b * D::NX;
+        io.traj_ref = traj_ref + (size_t)b * (N + 1) * D::NX;
+        io.u_ref = u_ref + (size_t)b * N * D::NU;
+        io.u_last = u_last + (size_t)b * N * D::NU;
+        io.x_guess = x_guess ? x_guess + (size_t)b * (N + 1) * D::NX : nullptr;
+        io.obs = obs + (size_t)b * so;
+        io.X = X + (size_t)b * (N + 1) * D::NX;
+        io.U = U + (size_t)b * N * D::NU;
+        io.s = s + (size_t)b * (N + 1);
+        io.status = status + b; io.iters = iters + b; io.cost = cost + b; io.err = err + b;
+        MmpcEmu emu = reverse ? MmpcEmu{63, -1, -1} : MmpcEmu{0, 64, 1};
+        mmpc_solve_fast<KIND, N, MC>(*P, io, lds, emu);
+        free(lds);
+    }
+}
+
+// fast path (template on the horizon): returns -1 when this (kind, N, M) has no fast instantiation
+extern "C" int mmpc_emu_solve_fast(int kind, const MmpcParams *P, int B, const double *x_init, const double *traj_ref,
+                                   const double *u_ref, const double *u_last, const double *x_guess, const double *obs,
+                                   double *X, double *U, double *s, int *status, int *iters, double *cost, double *err,
+                                   int reverse) {
+#define MMPC_FAST_CASE(K, NN, MM) if (kind == K && P->N == NN && P->M == MM) { run_fast<K, NN, MM>(P, B, x_init, traj_ref, u_ref, u_last, x_guess, obs, X, U, s, status, iters, cost, err, reverse); return 0; }
+    MMPC_FAST_CASE(0, 20, 5) MMPC_FAST_CASE(0, 20, 3) MMPC_FAST_CASE(0, 30, 8) MMPC_FAST_CASE(0, 20, 0) MMPC_FAST_CASE(1, 15, 3)
+#undef MMPC_FAST_CASE
+    return -1;
+}
+extern "C" int mmpc_emu_fast_lds_doubles(int kind, int N, int M, int obs_per_stage) {
+    if (kind == 0 && N == 20) return mmpc_fast_layout<0, 20>(M, obs_per_stage).total;
+    if (kind == 0 && N == 30) return mmpc_fast_layout<0, 30>(M, obs_per_stage).total;
+    if (kind == 1 && N == 15) return mmpc_fast_layout<1, 15>(M, obs_per_stage).total;
+    return -1;
 }
 
 extern "C" int mmpc_emu_solve(int kind, const MmpcParams *P, int B, const double *x_init, const double *traj_ref,

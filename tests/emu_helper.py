@@ -8,6 +8,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SRC = os.path.join(_HERE, "emu", "mmpc_emu.cpp")
 _CORE = os.path.join(_HERE, "..", "mobile-manipulator-mpc_amd", "csrc", "mmpc_core.h")
+_FAST = os.path.join(_HERE, "..", "mobile-manipulator-mpc_amd", "csrc", "mmpc_fast.h")
 
 
 class MmpcParams(C.Structure):
@@ -21,7 +22,7 @@ class MmpcParams(C.Structure):
 
 def build(asan=False):
     out = os.path.join(_HERE, "emu", "_build", "libmmpc_emu_asan.so" if asan else "libmmpc_emu.so")
-    newest = max(os.path.getmtime(_SRC), os.path.getmtime(_CORE))
+    newest = max(os.path.getmtime(_SRC), os.path.getmtime(_CORE), os.path.getmtime(_FAST))
     if not os.path.exists(out) or os.path.getmtime(out) < newest:
         os.makedirs(os.path.dirname(out), exist_ok=True)
         flags = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer"] if asan else ["-O2"]
@@ -53,7 +54,7 @@ def _p(a):
     return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
 
 
-def solve_batch(par, x_init, traj_ref, u_ref, u_last, obs, x_guess=None, reverse=False, asan=False, **kw):
+def solve_batch(par, x_init, traj_ref, u_ref, u_last, obs, x_guess=None, reverse=False, asan=False, fast=False, **kw):
     lib = C.CDLL(build(asan))
     assert lib.mmpc_emu_params_size() == C.sizeof(MmpcParams)
     x_init = np.ascontiguousarray(x_init, float); traj_ref = np.ascontiguousarray(traj_ref, float)
@@ -67,8 +68,11 @@ def solve_batch(par, x_init, traj_ref, u_ref, u_last, obs, x_guess=None, reverse
     prm = make_params(par, M, obs.ndim == 4, x_guess is not None, **kw)
     X = np.zeros((B, N + 1, nx)); U = np.zeros((B, N, nu)); s = np.zeros((B, N + 1))
     status = np.zeros(B, np.int32); iters = np.zeros(B, np.int32); cost = np.zeros(B); err = np.zeros(B)
-    lib.mmpc_emu_solve(0 if par.kind == "wholebody" else 1, C.byref(prm), B, _p(x_init), _p(traj_ref), _p(u_ref),
+    fn = lib.mmpc_emu_solve_fast if fast else lib.mmpc_emu_solve
+    rc = fn(0 if par.kind == "wholebody" else 1, C.byref(prm), B, _p(x_init), _p(traj_ref), _p(u_ref),
                        _p(u_last), _p(x_guess), _p(obs), _p(X), _p(U), _p(s),
                        status.ctypes.data_as(C.POINTER(C.c_int)), iters.ctypes.data_as(C.POINTER(C.c_int)),
                        _p(cost), _p(err), int(reverse))
+    if rc != 0:
+        raise RuntimeError('no fast instantiation for this configuration')
     return dict(X=X, U=U, s=s, status=status, iters=iters, cost=cost, err=err)
