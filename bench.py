@@ -46,7 +46,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8192, help="GLOBAL batch (BASELINE metric: 8192)")
     ap.add_argument("--horizon", type=int, default=20)
     ap.add_argument("--obstacles", type=int, default=5)
-    ap.add_argument("--cpu-sample", type=int, default=2048, help="instances timed on the host cores (rank 0, N=1)")
+    ap.add_argument("--cpu-sample", type=int, default=8192, help="instances timed on the host cores (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
@@ -159,7 +159,7 @@ def main():
                        "batch_per_gpu": Bl, "parallelism": "batch-sharded x%d%s" % (world, " + all-gather(X,U,s)" if world > 1 else "")},
             "solver": {"converged_frac": n_conv / Bg, "mean_iters": mean_iters, "max_iters": it_max,
                        "max_scaled_kkt": err_max, "lds_bytes_per_problem": eng.lds_bytes},
-            "roofline": {"bound": "mfma", "kernel": "mmpc_solve_kernel<0>", "achieved": achieved_tf,
+            "roofline": {"bound": "mfma", "kernel": "mmpc_fast_kernel<0,20,5>" if (N, M) == (20, 5) else "mmpc_solve_kernel<0>", "achieved": achieved_tf,
                          "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tf / FP64_PEAK_TFLOPS,
                          "traffic": None, "kernel_ms": k_ms,
                          "flops_per_iter": riccati_flops_per_iter(N, nx, nu, M, 4),
@@ -167,7 +167,8 @@ def main():
         }
         if world == 1 and not args.no_cpu:
             from oracle import coracle, nlp
-            cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            cores = min(avail, 16)          # the GPU box gives one GPU a 16-core CPU share
             ns = min(args.cpu_sample, Bg)
             par = nlp.WholeBodyParams(N=N)
             xi = np.clip(d["x_init"][:ns], par.xlim[0], par.xlim[1])

@@ -12,10 +12,10 @@ from oracle import nlp, coracle, synth
 import emu_helper
 
 
-def _cmp(par, d, obs, ul, x_guess=None, X0=None):
+def _cmp(par, d, obs, ul, x_guess=None, X0=None, fast=False):
     r = coracle.solve_batch(par, d["x_init"], d["traj_ref"], d["u_ref"], ul, obs, X0=X0, nthreads=4)
-    e = emu_helper.solve_batch(par, d["x_init"], d["traj_ref"], d["u_ref"], ul, obs, x_guess=x_guess)
-    e2 = emu_helper.solve_batch(par, d["x_init"], d["traj_ref"], d["u_ref"], ul, obs, x_guess=x_guess, reverse=True)
+    e = emu_helper.solve_batch(par, d["x_init"], d["traj_ref"], d["u_ref"], ul, obs, x_guess=x_guess, fast=fast)
+    e2 = emu_helper.solve_batch(par, d["x_init"], d["traj_ref"], d["u_ref"], ul, obs, x_guess=x_guess, reverse=True, fast=fast)
     assert (r["status"] == 0).all() and (e["status"] == 0).all()
     assert (r["iters"] == e["iters"]).mean() > 0.9
     assert np.abs(r["X"] - e["X"]).max() < 1e-6 and np.abs(r["U"] - e["U"]).max() < 1e-6
@@ -24,30 +24,56 @@ def _cmp(par, d, obs, ul, x_guess=None, X0=None):
     return r, e
 
 
-def test_emu_wholebody_c3():
+@pytest.mark.parametrize("fast", [False, True])
+def test_emu_wholebody_c3(fast):
+    """generic kernel (mmpc_core.h) and specialised kernel (mmpc_fast.h) on config C3"""
     B = 24
     d = synth.make_batch(B)
-    _cmp(nlp.WholeBodyParams(), d, d["obs"], np.zeros((B, 20, 5)))
+    _cmp(nlp.WholeBodyParams(), d, d["obs"], np.zeros((B, 20, 5)), fast=fast)
 
 
-def test_emu_base_c2_and_warm_start():
+@pytest.mark.parametrize("fast", [False, True])
+def test_emu_base_c2_and_warm_start(fast):
     B = 16
     d = synth.make_batch(B, N=15, M=3, kind="base", config_id=2)
     par = nlp.BaseParams(N=15)
-    r, _ = _cmp(par, d, d["obs"], np.zeros((B, 15, 2)))
+    r, _ = _cmp(par, d, d["obs"], np.zeros((B, 15, 2)), fast=fast)
     d2 = dict(d)
     d2["x_init"] = np.array([coracle.f("base", 0.1, d["x_init"][b], r["U"][b, 0]) for b in range(B)])
-    _cmp(par, d2, d["obs"], r["U"], x_guess=r["X"], X0=r["X"])     # mpc_base.py:200-201
+    _cmp(par, d2, d["obs"], r["U"], x_guess=r["X"], X0=r["X"], fast=fast)     # mpc_base.py:200-201
 
 
-def test_emu_wholebody_c5_moving_obstacles():
+@pytest.mark.parametrize("fast", [False, True])
+def test_emu_wholebody_warm_tick_and_demo_obstacle_count(fast):
+    """second tick (U init = U_last = previous optimum) and the demo's M=3 (demo_wholebody_qref.py:40-44)"""
+    B = 8
+    par = nlp.WholeBodyParams()
+    d = synth.make_batch(B)
+    r = coracle.solve_batch(par, d["x_init"], d["traj_ref"], d["u_ref"], np.zeros((B, 20, 5)), d["obs"])
+    d2 = dict(d)
+    d2["x_init"] = np.array([coracle.f("wholebody", 0.1, np.clip(d["x_init"][b], par.xlim[0], par.xlim[1]), r["U"][b, 0]) for b in range(B)])
+    _cmp(par, d2, d["obs"], r["U"], fast=fast)
+    d3 = synth.make_batch(B, N=20, M=3, config_id=9)
+    _cmp(par, d3, d3["obs"], np.zeros((B, 20, 5)), fast=fast)
+
+
+@pytest.mark.parametrize("fast", [False, True])
+def test_emu_wholebody_c5_moving_obstacles(fast):
     B = 6
     d = synth.make_batch(B, N=30, M=8, config_id=5, moving=True)
     obs = np.zeros((B, 31, 8, 3))
     for k in range(31):
         obs[:, k, :, :2] = d["obs"][:, :, :2] + d["obs_vel"] * k * 0.1
         obs[:, k, :, 2] = d["obs"][:, :, 2]
-    _cmp(nlp.WholeBodyParams(N=30), d, obs, np.zeros((B, 30, 5)))
+    _cmp(nlp.WholeBodyParams(N=30), d, obs, np.zeros((B, 30, 5)), fast=fast)
+
+
+def test_emu_hard_instances_converge():
+    """instances of the 8192 batch that need the filter-reset heuristic / many iterations"""
+    d = synth.make_batch(8192)
+    idx = np.array([1363, 1644, 3269])
+    dd = {k: v[idx] for k, v in d.items()}
+    _cmp(nlp.WholeBodyParams(), dd, dd["obs"], np.zeros((3, 20, 5)), fast=True)
 
 
 def test_emu_edge_sizes():
@@ -65,6 +91,8 @@ def test_emu_under_asan():
             "from oracle import nlp, synth\n"
             "d=synth.make_batch(3)\n"
             "e=emu_helper.solve_batch(nlp.WholeBodyParams(),d['x_init'],d['traj_ref'],d['u_ref'],np.zeros((3,20,5)),d['obs'],asan=True)\n"
+            "assert (e['status']==0).all()\n"
+            "e=emu_helper.solve_batch(nlp.WholeBodyParams(),d['x_init'],d['traj_ref'],d['u_ref'],np.zeros((3,20,5)),d['obs'],asan=True,fast=True)\n"
             "assert (e['status']==0).all()\n"
             "d=synth.make_batch(2,N=15,M=3,kind='base')\n"
             "e=emu_helper.solve_batch(nlp.BaseParams(N=15),d['x_init'],d['traj_ref'],d['u_ref'],np.zeros((2,15,2)),d['obs'],asan=True)\n"
