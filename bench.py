@@ -84,9 +84,11 @@ def main():
     traj, uref, obs = t(d["traj_ref"]), t(d["u_ref"]), t(d["obs"])
     ulast = torch.zeros((Bl, N, nu), dtype=torch.float64, device=dev)   # cold start: u_latest = 0 (:298-299)
     out = eng.solve_batch_device(x_init, traj, uref, ulast, obs)
-    gathered = None
+    from mmpc_amd import sharding
+    assert (lo, hi) == sharding.shard_bounds(Bg, world, rank)
+    gathered = packed = None
     if world > 1:
-        rec = 310 if (N, nx, nu) == (20, 9, 5) else (N + 1) * nx + N * nu + N + 1
+        rec = sharding.record_len(N, nx, nu)
         packed = torch.empty((Bl, rec), dtype=torch.float64, device=dev)
         gathered = torch.empty((Bg, rec), dtype=torch.float64, device=dev)
 
@@ -94,10 +96,8 @@ def main():
         eng.solve_batch_device(x_init, traj, uref, ulast, obs, out=out)
         if world > 1:
             # the one collective of the path: all-gather of the solved (X,U,s) over xGMI (RCCL)
-            packed[:, :(N + 1) * nx] = out["X"].reshape(Bl, -1)
-            packed[:, (N + 1) * nx:(N + 1) * nx + N * nu] = out["U"].reshape(Bl, -1)
-            packed[:, (N + 1) * nx + N * nu:] = out["s"]
-            dist.all_gather_into_tensor(gathered, packed)
+            sharding.pack_solution(out["X"], out["U"], out["s"], out=packed)
+            sharding.allgather_solutions(packed, Bg, dist, gathered=gathered)
 
     for _ in range(args.warmup):
         step()
@@ -113,10 +113,8 @@ def main():
         eng.solve_batch_device(x_init, traj, uref, ulast, obs, out=out)
         ev1.record()
         if world > 1:
-            packed[:, :(N + 1) * nx] = out["X"].reshape(Bl, -1)
-            packed[:, (N + 1) * nx:(N + 1) * nx + N * nu] = out["U"].reshape(Bl, -1)
-            packed[:, (N + 1) * nx + N * nu:] = out["s"]
-            dist.all_gather_into_tensor(gathered, packed)
+            sharding.pack_solution(out["X"], out["U"], out["s"], out=packed)
+            sharding.allgather_solutions(packed, Bg, dist, gathered=gathered)
         ev1.synchronize()
         kernel_ms += ev0.elapsed_time(ev1)
     torch.cuda.synchronize()
