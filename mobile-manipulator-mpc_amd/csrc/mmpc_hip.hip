@@ -17,11 +17,13 @@ __global__ __launch_bounds__(MMPC_WAVE) void mmpc_solve_kernel(
     const MmpcParams *__restrict__ Pp, int B, const double *__restrict__ x_init, const double *__restrict__ traj_ref,
     const double *__restrict__ u_ref, const double *__restrict__ u_last, const double *__restrict__ x_guess,
     const double *__restrict__ obs, double *__restrict__ X, double *__restrict__ U, double *__restrict__ s,
-    int *__restrict__ status, int *__restrict__ iters, double *__restrict__ cost, double *__restrict__ err) {
+    int *__restrict__ status, int *__restrict__ iters, double *__restrict__ cost, double *__restrict__ err,
+    const int *__restrict__ order) {
     extern __shared__ double lds[];
     typedef MmpcDims<KIND> D;
-    const int b = (int)blockIdx.x;
-    if (b >= B) return;
+    if ((int)blockIdx.x >= B) return;
+    // longest-first schedule hint: workgroup i solves instance order[i] (a permutation; results do not depend on it)
+    const int b = order ? order[blockIdx.x] : (int)blockIdx.x;
     const MmpcParams &P = *Pp;
     const int N = P.N, M = P.M;
     const size_t so = (size_t)(P.obs_per_stage ? N + 1 : 1) * M * 3;
@@ -47,11 +49,13 @@ __global__ __launch_bounds__(MMPC_WAVE) void mmpc_fast_kernel(
     const MmpcParams *__restrict__ Pp, int B, const double *__restrict__ x_init, const double *__restrict__ traj_ref,
     const double *__restrict__ u_ref, const double *__restrict__ u_last, const double *__restrict__ x_guess,
     const double *__restrict__ obs, double *__restrict__ X, double *__restrict__ U, double *__restrict__ s,
-    int *__restrict__ status, int *__restrict__ iters, double *__restrict__ cost, double *__restrict__ err) {
+    int *__restrict__ status, int *__restrict__ iters, double *__restrict__ cost, double *__restrict__ err,
+    const int *__restrict__ order) {
     extern __shared__ double lds[];
     typedef MmpcDims<KIND> D;
-    const int b = (int)blockIdx.x;
-    if (b >= B) return;
+    if ((int)blockIdx.x >= B) return;
+    // longest-first schedule hint: workgroup i solves instance order[i] (a permutation; results do not depend on it)
+    const int b = order ? order[blockIdx.x] : (int)blockIdx.x;
     const MmpcParams &P = *Pp;
     const int M = MC;
     const size_t so = (size_t)(P.obs_per_stage ? N + 1 : 1) * M * 3;
@@ -76,6 +80,21 @@ __global__ __launch_bounds__(MMPC_WAVE) void mmpc_fast_kernel(
 // BASELINE configs C3/C4 (0,20,5), C5 (0,30,8), C2 (1,15,3); the reference demo (0,20,3).
 #define MMPC_FAST_LIST(X) X(0, 20, 5) X(0, 30, 8) X(0, 20, 3) X(1, 15, 3)
 
+// Longest-processing-time-first order for the NEXT launch: instances sorted by descending iteration count of
+// this one (counting sort, 256 bins, one workgroup).  Kernel time is bounded by the slowest instance; starting
+// the slow ones first removes the tail.  In receding-horizon use consecutive ticks have correlated difficulty.
+__global__ __launch_bounds__(1024) void mmpc_lpt_order(int B, const int *__restrict__ iters, int *__restrict__ order) {
+    __shared__ int hist[256], start[256];
+    const int t = (int)threadIdx.x;
+    if (t < 256) hist[t] = 0;
+    __syncthreads();
+    for (int i = t; i < B; i += 1024) { int v = iters[i]; v = v < 0 ? 0 : (v > 255 ? 255 : v); atomicAdd(&hist[v], 1); }
+    __syncthreads();
+    if (t == 0) { int acc = 0; for (int v = 255; v >= 0; v--) { start[v] = acc; acc += hist[v]; } }
+    __syncthreads();
+    for (int i = t; i < B; i += 1024) { int v = iters[i]; v = v < 0 ? 0 : (v > 255 ? 255 : v); order[atomicAdd(&start[v], 1)] = i; }
+}
+
 // out_u0[b][a] = U[b][0][a]
 __global__ void mmpc_gather_u0(int B, int NU, int stride, const double *__restrict__ U, double *__restrict__ u0) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -94,6 +113,8 @@ struct mmpc_handle_s {
     // device-side state and staging (capacity max_batch)
     double *d_x_init, *d_traj, *d_uref, *d_obs, *d_ulatest, *d_xguess, *d_X, *d_U, *d_s, *d_cost, *d_err, *d_u0;
     int *d_status, *d_iters;
+    int *d_order;           // LPT schedule hint from the previous launch (valid for order_B instances)
+    int order_B;
     char err[512];
 };
 
@@ -206,6 +227,8 @@ extern "C" int mmpc_create(const mmpc_config *cfg, mmpc_handle *out) {
     HIPCHK(h, hipMalloc(&h->d_u0, B * nu * 8));
     HIPCHK(h, hipMalloc(&h->d_status, B * 4));
     HIPCHK(h, hipMalloc(&h->d_iters, B * 4));
+    HIPCHK(h, hipMalloc(&h->d_order, B * 4));
+    h->order_B = 0;
     HIPCHK(h, hipMemset(h->d_ulatest, 0, B * N * nu * 8));
     int rc = upload_params(h);
     if (rc) return rc;
@@ -216,7 +239,7 @@ extern "C" int mmpc_create(const mmpc_config *cfg, mmpc_handle *out) {
 extern "C" int mmpc_destroy(mmpc_handle h) {
     if (!h) return MMPC_E_ARG;
     void *ptrs[] = {h->dp, h->d_x_init, h->d_traj, h->d_uref, h->d_obs, h->d_ulatest, h->d_xguess, h->d_X, h->d_U,
-                    h->d_s, h->d_cost, h->d_err, h->d_u0, h->d_status, h->d_iters};
+                    h->d_s, h->d_cost, h->d_err, h->d_u0, h->d_status, h->d_iters, h->d_order};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete h;
     return MMPC_OK;
@@ -249,6 +272,7 @@ extern "C" int mmpc_reset(mmpc_handle h) {
     const size_t n = (size_t)h->cfg.max_batch * h->cfg.N * h->nu * 8;
     HIPCHK(h, hipMemset(h->d_ulatest, 0, n));
     h->warm = 0;
+    h->order_B = 0;
     return MMPC_OK;
 }
 
@@ -262,20 +286,25 @@ static int launch(mmpc_handle h, int B, const double *x_init, const double *traj
         HIPCHK(h, hipMemcpyAsync(h->dp, &h->hp, sizeof(MmpcParams), hipMemcpyHostToDevice, st));
     }
     const bool use_fast = h->fast && h->diag && !getenv("MMPC_FORCE_GENERIC");
+    const int *order = (h->order_B == B && B <= h->cfg.max_batch && !getenv("MMPC_NO_LPT")) ? h->d_order : nullptr;
     if (use_fast) {
 #define MMPC_X(K, NN, MM)                                                                                              \
         if (h->cfg.kind == K && h->cfg.N == NN && h->cfg.M == MM)                                                                          \
             hipLaunchKernelGGL((mmpc_fast_kernel<K, NN, MM>), dim3(B), dim3(MMPC_WAVE), h->fast_lds_bytes, st, h->dp, B, x_init, traj, \
-                               uref, ulast, xguess, obs, X, U, s, status, iters, cost, err);
+                               uref, ulast, xguess, obs, X, U, s, status, iters, cost, err, order);
         MMPC_FAST_LIST(MMPC_X)
 #undef MMPC_X
     } else if (h->cfg.kind == MMPC_KIND_WHOLEBODY)
         hipLaunchKernelGGL(mmpc_solve_kernel<0>, dim3(B), dim3(MMPC_WAVE), h->lds_bytes, st, h->dp, B, x_init, traj, uref,
-                           ulast, xguess, obs, X, U, s, status, iters, cost, err);
+                           ulast, xguess, obs, X, U, s, status, iters, cost, err, order);
     else
         hipLaunchKernelGGL(mmpc_solve_kernel<1>, dim3(B), dim3(MMPC_WAVE), h->lds_bytes, st, h->dp, B, x_init, traj, uref,
-                           ulast, xguess, obs, X, U, s, status, iters, cost, err);
+                           ulast, xguess, obs, X, U, s, status, iters, cost, err, order);
     HIPCHK(h, hipGetLastError());
+    if (B <= h->cfg.max_batch && B > 256 && !getenv("MMPC_NO_LPT")) {
+        hipLaunchKernelGGL(mmpc_lpt_order, dim3(1), dim3(1024), 0, st, B, iters, h->d_order);
+        h->order_B = B;
+    }
     return MMPC_OK;
 }
 
