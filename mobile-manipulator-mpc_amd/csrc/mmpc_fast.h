@@ -417,7 +417,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
         // ============================================================ E1 (stage lanes)
         LANES_BEGIN
         auto &ls = MMPC_LS;
-        double e_p = 0.0, tzmax = 0.0, tzmin = 1e300, zsum = 0.0, phi = 0.0, th = 0.0;
+        double e_p = 0.0, tzmax = 0.0, tzmin = 1e300, zsum = 0.0, phi = 0.0, th = 0.0, slog = 0.0;
         if (lane < NS) {
             const int k = lane;
             const double *xk = XU + k * NV;
@@ -507,12 +507,12 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                 }
             }
             if (k < N) rds -= selfz;
-            phi -= mu * la.value();
+            slog = la.value();
             DS[k] = rds;
 #pragma unroll
             for (int j = 0; j < NV; j++) RB[k * NV + j] = rb[j];
         }
-        MMPC_WR(1) = e_p; MMPC_WR(2) = tzmax; MMPC_WR(3) = tzmin; MMPC_WR(4) = zsum; MMPC_WR(5) = phi; MMPC_WR(6) = th;
+        MMPC_WR(1) = e_p; MMPC_WR(2) = tzmax; MMPC_WR(3) = tzmin; MMPC_WR(4) = zsum; MMPC_WR(5) = phi; MMPC_WR(6) = th; MMPC_WR(7) = slog;
         if (lane == 0) MISC[0] = 0.0;
         if (NSELF == 0 && lane == 0) { for (int a = 0; a < 10; a++) SN[a] = 0.0; }
         LANES_END
@@ -556,19 +556,18 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                 if (isvar) e_d = mmpc_max(e_d, fabs(r));
             }
         }
-        phi -= mu * la.value();
+        MMPC_WR(7) += la.value();   // sum of log t over all rows (the barrier term is applied after the mu update)
         if (lane < NS) e_d = mmpc_max(e_d, fabs(DS[lane] - (lane == N - 1 ? SN[3] : 0.0)));
         MMPC_WR(0) = e_d; MMPC_WR(1) = e_p; MMPC_WR(2) = tzmax; MMPC_WR(3) = tzmin; MMPC_WR(4) = zsum; MMPC_WR(5) = phi; MMPC_WR(6) = th;
         LANES_END
         const double err_d = MMPC_RED_MAX(0), err_p = MMPC_RED_MAX(1), tzmax = MMPC_RED_MAX(2), tzmin = MMPC_RED_MIN(3),
-                     zsum = MMPC_RED_SUM(4), phi0_raw = MMPC_RED_SUM(5), th0 = MMPC_RED_SUM(6);
+                     zsum = MMPC_RED_SUM(4), cost0 = MMPC_RED_SUM(5), th0 = MMPC_RED_SUM(6), sumlog = MMPC_RED_SUM(7);
         double sd = zsum / (nrows_act + (double)(NS * NX));
         sd = (sd > 100.0 ? sd : 100.0) / 100.0;
         E0 = mmpc_max(mmpc_max(err_d / sd, err_p), tzmax / sd);
         if (!(E0 == E0) || !mmpc_finite(E0)) { status = 2; break; }
         if (E0 <= tol) { status = 0; break; }
         if (it == P.max_iter) break;
-        const double mu_eval = mu;
         {
             bool changed = false;
             for (;;) {
@@ -580,9 +579,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
             }
             if (changed) filt_init = 0;
         }
-        // phi0 was accumulated with the barrier weight mu_eval; if mu changed, it is re-evaluated below
-        // together with the first trial (see merit pass with alpha = 0).
-        const bool need_phi0 = mu != mu_eval;
+        const double phi0 = cost0 - mu * sumlog;   // barrier objective at the current point for the (possibly new) mu
 
         // ============================================================ Newton direction
         int failed = 0;
@@ -1097,18 +1094,15 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
             phi_out = MMPC_RED_SUM(0);
             th_out = MMPC_RED_SUM(1);
         };
-        double phi0 = phi0_raw;
         if (!filt_init) { nfilt = 0; th_max = 1e4 * mmpc_max(1.0, th0); th_min = 1e-4 * mmpc_max(1.0, th0); filt_init = 1; }
 
-        // ---- filter line search (+ filter reset heuristic).  Trial -1 (only when mu changed after the
-        //      evaluation) re-evaluates the barrier objective at alpha = 0 with the new mu.
+        // ---- filter line search (+ filter reset heuristic)
         double alpha = ap;
-        int lspass = 0, lsi = need_phi0 ? -1 : 0;
+        int lspass = 0, lsi = 0;
 #pragma unroll 1
         for (;;) {
             double phi, th;
-            merit_pass(lsi < 0 ? 0.0 : alpha, phi, th);
-            if (lsi < 0) { phi0 = phi; lsi = 0; continue; }
+            merit_pass(alpha, phi, th);
             bool okf = th < th_max;
             for (int i = 0; i < nfilt && okf; i++) if (th >= FILT[2 * i] && phi >= FILT[2 * i + 1]) okf = false;
             const bool ftype = dphi < 0 && th0 <= th_min && alpha * mmpc_powf(-dphi, 2.3f) > mmpc_powf(th0, 1.1f);
