@@ -119,7 +119,7 @@ struct MmpcDims {
 struct MmpcLayout {
     int X, U, S, LAM, XREF, UREF, ULAST, OBS, T, Z, HR, DTR, GC, HC, GSF, CV, CD, GX, GU, HXX, QX, HUXL, HUUL,
         HUX02, HUUD, QU, HSS, GSS, VX, VXN, KK, KF, DX, DU, DS, DLAM, PF, TT, PC, MF, MG, MH, MGX, MGU, RED, FILT,
-        MISC, total;
+        MISC, PNU, PNUS, KFV, GNU, FWV, NUEQ, total;
     int R, NR;
 };
 
@@ -146,6 +146,9 @@ MMPC_HD MmpcLayout mmpc_layout(int N, int M, int obs_per_stage) {
     MMPC_CARVE(PF, D::NX * D::NX) MMPC_CARVE(TT, D::NX * D::NV) MMPC_CARVE(PC, D::NX) MMPC_CARVE(MF, D::NXX)
     MMPC_CARVE(MG, D::NU * D::NX) MMPC_CARVE(MH, D::NUU) MMPC_CARVE(MGX, D::NX) MMPC_CARVE(MGU, D::NU)
     MMPC_CARVE(RED, 8 * MMPC_WAVE) MMPC_CARVE(FILT, 2 * MMPC_FCAP) MMPC_CARVE(MISC, 8)
+    // terminal xy equality (interface_wholebody_qref.py:166-167): multiplier sensitivities
+    MMPC_CARVE(PNU, D::NX * 2) MMPC_CARVE(PNUS, NS * D::NX * 2) MMPC_CARVE(KFV, N * D::NU * 2) MMPC_CARVE(GNU, D::NV * 2)
+    MMPC_CARVE(FWV, 2 * 3 * D::NX) MMPC_CARVE(NUEQ, 4)
 #undef MMPC_CARVE
     L.total = o;
     return L;
@@ -252,7 +255,9 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
            *VXN = lds + L.VXN, *KK = lds + L.KK, *KF = lds + L.KF, *DX = lds + L.DX, *DU = lds + L.DU,
            *DS = lds + L.DS, *DLAM = lds + L.DLAM, *PF = lds + L.PF, *TT = lds + L.TT, *PC = lds + L.PC,
            *MF = lds + L.MF, *MG = lds + L.MG, *MH = lds + L.MH, *MGX = lds + L.MGX, *MGU = lds + L.MGU,
-           *RED = lds + L.RED, *FILT = lds + L.FILT, *MISC = lds + L.MISC;
+           *RED = lds + L.RED, *FILT = lds + L.FILT, *MISC = lds + L.MISC, *PNU = lds + L.PNU, *PNUS = lds + L.PNUS,
+           *KFV = lds + L.KFV, *GNU = lds + L.GNU, *FWV = lds + L.FWV, *NUEQ = lds + L.NUEQ;
+    const bool teq = P.terminal_xy_eq != 0;
     const int SL_UHI = NU, SL_XLO = 2 * NU, SL_XHI = 2 * NU + NX, SL_C = 2 * NU + 2 * NX, SL_S = SL_C + M;
     const double dt = P.dt, Sw = P.S, tol = P.tol;
 
@@ -292,6 +297,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
         U[i] = io.u_last[i];  // :303,:310
     }
     for (int i = lane; i < NS; i += MMPC_WAVE) S[i] = 0.0;  // :304
+    if (lane < 4) NUEQ[lane] = 0.0;
     for (int i = lane; i < (P.obs_per_stage ? NS : 1) * M * 3; i += MMPC_WAVE) OBS[i] = io.obs[i];
     LANES_END
 
@@ -448,6 +454,13 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
             }
             if (k < N) rds -= selfz; else MISC[1] = selfz;
             DS[k] = rds;  // stage-local part of the s-stationarity residual (finished in E1b)
+            if (teq && k == N) {   // X[N,:2] == X_ref[N,:2] with multiplier nu
+                for (int j = 0; j < 2; j++) {
+                    rdx[j] += NUEQ[j];
+                    e_p = mmpc_max(e_p, fabs(xk[j] - XREF[N * NX + j]));
+                    zsum += fabs(NUEQ[j]);
+                }
+            }
             if (k >= 1) for (int i = 0; i < NX; i++) e_d = mmpc_max(e_d, fabs(rdx[i]));
             if (k < N) for (int a = 0; a < NU; a++) e_d = mmpc_max(e_d, fabs(rdu[a]));
         }
@@ -611,6 +624,10 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                 const int i = e / NX, j = e % NX;
                 PF[e] = HXX[N * NXX + (i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i)];
             }
+            if (teq && lane < NX * 2) {   // p^nu_N = E^T, E = [I2 0]
+                const double v = (lane / 2 == lane % 2) ? 1.0 : 0.0;
+                PNU[lane] = v; PNUS[N * NX * 2 + lane] = v;
+            }
             LANES_END
             // ---- Riccati recursion (block LDL^T of the stage-wise KKT matrix)
             for (int k = N - 1; k >= 0; k--) {
@@ -656,11 +673,18 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                         if (j < NX) MGX[j] = v; else MGU[j - NX] = v;
                     }
                 }
+                if (teq)
+                    for (int e = lane; e < NV * 2; e += MMPC_WAVE) {   // g^nu = [A B]^T p^nu_{k+1}
+                        const int j = e / 2, c = e % 2;
+                        double v = 0.0;
+                        for (int q = 0; q < 4; q++) v += cv[TB::ccv(j, q)] * PNU[TB::crow(j, q) * 2 + c];
+                        GNU[e] = v;
+                    }
                 LANES_END
                 // R3/R4: Cholesky of Hh (every solving lane redundantly, in registers), then one
                 //        right-hand side per lane: K = -Hh^{-1} G (NX columns), kf = -Hh^{-1} gu
                 LANES_BEGIN
-                if (lane <= NX) {
+                if (lane <= NX + (teq ? 2 : 0)) {
                     double Lc[NUU];
                     bool ok = true;
 #pragma unroll
@@ -681,7 +705,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                     }
                     double rhs[NU];
 #pragma unroll
-                    for (int a = 0; a < NU; a++) rhs[a] = lane < NX ? MG[a * NX + lane] : MGU[a];
+                    for (int a = 0; a < NU; a++) rhs[a] = lane < NX ? MG[a * NX + lane] : (lane == NX ? MGU[a] : GNU[(NX + a) * 2 + lane - NX - 1]);
 #pragma unroll
                     for (int i = 0; i < NU; i++) {
                         double v = rhs[i];
@@ -699,7 +723,8 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
 #pragma unroll
                     for (int a = 0; a < NU; a++) {
                         if (lane < NX) KK[(k * NU + a) * NX + lane] = -rhs[a];
-                        else KF[k * NU + a] = -rhs[a];
+                        else if (lane == NX) KF[k * NU + a] = -rhs[a];
+                        else KFV[(k * NU + a) * 2 + lane - NX - 1] = -rhs[a];
                     }
                     if (!ok && lane == 0) MISC[0] = 1.0;
                 }
@@ -707,6 +732,13 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                 if (MISC[0] != 0.0) { failed = 1; break; }
                 // R5: P_k = F + G^T K,  p_k = gx + G^T kf   (overwrite the stage blocks)
                 LANES_BEGIN
+                if (teq)
+                    for (int e = lane; e < NX * 2; e += MMPC_WAVE) {   // p^nu_k = g^nu_x + G^T kf^nu
+                        const int i = e / 2, c = e % 2;
+                        double v = GNU[i * 2 + c];
+                        for (int a = 0; a < NU; a++) v += MG[a * NX + i] * KFV[(k * NU + a) * 2 + c];
+                        PNU[e] = v; PNUS[k * NX * 2 + e] = v;
+                    }
                 for (int e = lane; e < NXX + NX; e += MMPC_WAVE) {
                     if (e < NXX) {
                         const int i = kTriI[e], j = kTriJ[e];
@@ -732,6 +764,48 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
         }
         if (failed) { status = 2; break; }
 
+        if (teq) {
+            // the direction is affine in the two terminal multipliers: roll out the nu = 0 solution and the two
+            // sensitivities (same gains K), solve E dx_N = e (2x2), fold nu into the feed-forward terms
+            LANES_BEGIN
+            for (int j = lane; j < 2 * 3 * NX; j += MMPC_WAVE) FWV[j] = 0.0;
+            LANES_END
+            for (int k = 0; k < N; k++) {
+                const double *src = FWV + (k & 1) * 3 * NX;
+                double *dst = FWV + ((k + 1) & 1) * 3 * NX;
+                LANES_BEGIN
+                if (lane < 3 * NX) {
+                    const int c = lane / NX, i = lane % NX;
+                    const double *cv = CV + k * MMPC_NCV;
+                    const double *d = src + c * NX;
+                    double v = c == 0 ? CD[k * NX + i] : 0.0;
+                    for (int q = 0; q < 5; q++) {
+                        const int col = TB::rcol(i, q);
+                        double x;
+                        if (col < NX) x = d[col];
+                        else {
+                            const int a = col - NX;
+                            x = c == 0 ? KF[k * NU + a] : KFV[(k * NU + a) * 2 + c - 1];
+                            for (int j = 0; j < NX; j++) x += KK[(k * NU + a) * NX + j] * d[j];
+                        }
+                        v += cv[TB::rcv(i, q)] * x;
+                    }
+                    dst[c * NX + i] = v;
+                }
+                LANES_END
+            }
+            {
+                const double *fin = FWV + (N & 1) * 3 * NX;
+                const double e0 = XREF[N * NX + 0] - X[N * NX + 0] - fin[0], e1 = XREF[N * NX + 1] - X[N * NX + 1] - fin[1];
+                const double d00 = fin[NX + 0], d10 = fin[NX + 1], d01 = fin[2 * NX + 0], d11 = fin[2 * NX + 1];
+                const double det = d00 * d11 - d01 * d10;
+                const double nu0 = (e0 * d11 - d01 * e1) / det, nu1 = (d00 * e1 - e0 * d10) / det;
+                LANES_BEGIN
+                if (lane == 0) { NUEQ[2] = nu0; NUEQ[3] = nu1; }
+                for (int e = lane; e < N * NU; e += MMPC_WAVE) KF[e] += KFV[e * 2] * nu0 + KFV[e * 2 + 1] * nu1;
+                LANES_END
+            }
+        }
         // ---- forward roll-out of the linearised dynamics
         LANES_BEGIN
         for (int j = lane; j < NX; j += MMPC_WAVE) DX[j] = 0.0;
@@ -764,6 +838,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                 double v = QX[k * NX + i];
                 for (int j = 0; j < NX; j++)
                     v += HXX[k * NXX + (i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i)] * dx[j];
+                if (teq) v += PNUS[(k * NX + i) * 2] * NUEQ[2] + PNUS[(k * NX + i) * 2 + 1] * NUEQ[3];
                 DLAM[k * NX + i] = -v - LAM[k * NX + i];
             }
             double vdx = 0.0;
@@ -845,6 +920,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                 th += fabs(hr[m] + tv);
                 acc(tv);
             }
+            if (teq && k == N) for (int j = 0; j < 2; j++) th += fabs(xk[j] - XREF[N * NX + j]);
             phi_k = f - mu * (log(mant) + (double)ex * 0.69314718055994530942);
             th_k = th;
         };
@@ -960,6 +1036,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
             if (i >= NX) { X[i] += alpha * DX[i]; LAM[i] += alpha * DLAM[i]; }
         for (int i = lane; i < N * NU; i += MMPC_WAVE) U[i] += alpha * DU[i];
         for (int i = lane; i < NS; i += MMPC_WAVE) S[i] += alpha * DS[i];
+        if (teq && lane < 2) NUEQ[lane] += alpha * (NUEQ[2 + lane] - NUEQ[lane]);
         LANES_END
     }
 

@@ -164,7 +164,7 @@ static int upload_params(mmpc_handle h) {
 
 extern "C" const char *mmpc_version(void) { return "mmpc 0.1 (gfx950)"; }
 extern "C" const char *mmpc_last_error(mmpc_handle h) { return h ? h->err : "null handle"; }
-extern "C" int mmpc_lds_bytes(mmpc_handle h) { return h ? ((h->fast && h->diag) ? h->fast_lds_bytes : h->lds_bytes) : MMPC_E_ARG; }
+extern "C" int mmpc_lds_bytes(mmpc_handle h) { return h ? ((h->fast && h->diag && !h->hp.terminal_xy_eq) ? h->fast_lds_bytes : h->lds_bytes) : MMPC_E_ARG; }
 
 extern "C" int mmpc_create(const mmpc_config *cfg, mmpc_handle *out) {
     if (!cfg || !out) return MMPC_E_ARG;
@@ -261,9 +261,9 @@ extern "C" int mmpc_set_weights(mmpc_handle h, const double *Q, const double *R,
 
 extern "C" int mmpc_set_terminal_xy_equality(mmpc_handle h, int on) {
     if (!h) return MMPC_E_ARG;
-    if (on) return fail(h, MMPC_E_UNSUPPORTED, "terminal xy equality (interface_wholebody_qref.py:166-167) %s%s", "is not implemented yet");
-    h->hp.terminal_xy_eq = 0;
-    return MMPC_OK;
+    h->hp.terminal_xy_eq = on ? 1 : 0;   // handled by the generic kernel (the specialised kernels do not carry it)
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    return upload_params(h);
 }
 
 extern "C" int mmpc_reset(mmpc_handle h) {
@@ -285,7 +285,7 @@ static int launch(mmpc_handle h, int B, const double *x_init, const double *traj
         h->hp.use_xguess = want;
         HIPCHK(h, hipMemcpyAsync(h->dp, &h->hp, sizeof(MmpcParams), hipMemcpyHostToDevice, st));
     }
-    const bool use_fast = h->fast && h->diag && !getenv("MMPC_FORCE_GENERIC");
+    const bool use_fast = h->fast && h->diag && !h->hp.terminal_xy_eq && !getenv("MMPC_FORCE_GENERIC");
     const int *order = (h->order_B == B && B <= h->cfg.max_batch && !getenv("MMPC_NO_LPT")) ? h->d_order : nullptr;
     if (use_fast) {
 #define MMPC_X(K, NN, MM)                                                                                              \

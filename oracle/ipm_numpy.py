@@ -46,7 +46,7 @@ class Options:
     piv_frac = 0.0
     nu_lam = 0.0
     filter = True
-    inertia = True
+    inertia = False
     delta0 = 1e-4
     delta_min = 1e-20
     delta_max = 1e10
@@ -137,6 +137,8 @@ def _merit_parts(prob, rows, X, U, s, t, mu):
     f = nlp.cost(prob, X, U, s)
     c = _defects(prob, X, U)
     th = np.abs(c).sum() + np.abs(X[0] - prob.x_init).sum()
+    if p.terminal_xy_equality:
+        th += np.abs(X[p.N, :2] - prob.traj_ref[p.N, :2]).sum()
     bar = 0.0
     for k in range(p.N + 1):
         for i, r in enumerate(rows[k]):
@@ -171,6 +173,7 @@ def solve(prob: nlp.Problem, U0=None, X0=None, opt: Options = None, verbose=Fals
     status = 1
     nu_merit = 1.0
     delta_last = 0.0
+    nu_eq = np.zeros(2)
     filt = None
     nfail = 0
     it = 0
@@ -194,12 +197,16 @@ def solve(prob: nlp.Problem, U0=None, X0=None, opt: Options = None, verbose=Fals
             rdx[k] -= A.T @ lam[k + 1]
             rdu[k] -= B.T @ lam[k + 1]
         rdx[0] = 0.0   # x_0 is fixed data; its multiplier absorbs the residual
+        ceq = np.zeros(2)
+        if p.terminal_xy_equality:
+            rdx[N][:2] += nu_eq
+            ceq = X[N, :2] - prob.traj_ref[N, :2]
         rh = [np.array([e[0] for e in ev[k]]) + t[k] for k in range(N + 1)]
         err_d = max(np.abs(rdx).max(), np.abs(rdu).max(), np.abs(rds).max())
-        err_p = max(np.abs(c).max() if N else 0.0, max(np.abs(r).max() for r in rh))
+        err_p = max(np.abs(c).max() if N else 0.0, max(np.abs(r).max() for r in rh), np.abs(ceq).max())
         comp0 = max((t[k] * z[k]).max() for k in range(N + 1))
         compmu = max(np.abs(t[k] * z[k] - mu).max() for k in range(N + 1))
-        zsum = sum(z[k].sum() for k in range(N + 1)) + np.abs(lam).sum()
+        zsum = sum(z[k].sum() for k in range(N + 1)) + np.abs(lam).sum() + np.abs(nu_eq).sum()
         sd = max(100.0, zsum / (nrows + lam.size)) / 100.0
         E0 = max(err_d / sd, err_p, comp0 / sd)
         Emu = max(err_d / sd, err_p, compmu / sd)
@@ -278,6 +285,8 @@ def solve(prob: nlp.Problem, U0=None, X0=None, opt: Options = None, verbose=Fals
             Pm = [None] * (N + 1); pv = [None] * (N + 1)
             K = [None] * N; kf = [None] * N
             Pm[N] = Hxx[N]; pv[N] = qx[N]
+            pvv = [None] * (N + 1); kfv = [None] * N
+            pvv[N] = np.zeros((nx, 2)); pvv[N][0, 0] = 1.0; pvv[N][1, 1] = 1.0    # E^T, E = [I2 0] (terminal xy equality)
             for k in range(N - 1, -1, -1):
                 A, B = AB[k]
                 PA = Pm[k + 1] @ A
@@ -293,10 +302,12 @@ def solve(prob: nlp.Problem, U0=None, X0=None, opt: Options = None, verbose=Fals
                     return None
                 K[k] = -_cho_solve(L, G)
                 kf[k] = -_cho_solve(L, gu_)
+                kfv[k] = -_cho_solve(L, B.T @ pvv[k + 1])
+                pvv[k] = A.T @ pvv[k + 1] + G.T @ kfv[k]
                 Pm[k] = F + G.T @ K[k]
                 Pm[k] = 0.5 * (Pm[k] + Pm[k].T)
                 pv[k] = gx_ + G.T @ kf[k]
-            return Pm, pv, K, kf, hss, gss, vx, vxN
+            return Pm, pv, K, kf, hss, gss, vx, vxN, pvv, kfv
         fac = factor(opt.exact_hessian) if opt.exact_hessian else None
         nreg = 0
         if fac is None and opt.exact_hessian and opt.inertia:
@@ -313,7 +324,20 @@ def solve(prob: nlp.Problem, U0=None, X0=None, opt: Options = None, verbose=Fals
         if fac is None:
             nreg += 1 if opt.exact_hessian else 0
             fac = factor(False)
-        Pm, pv, K, kf, hss, gss, vx, vxN = fac
+        Pm, pv, K, kf, hss, gss, vx, vxN, pvv, kfv = fac
+        nu_new = np.zeros(2)
+        if p.terminal_xy_equality:
+            # interface_wholebody_qref.py:166-167: X[N,:2] == X_ref[N,:2].  The two multipliers enter the terminal
+            # gradient linearly, so the direction is affine in them: roll out the nu = 0 solution and the two
+            # sensitivities with the SAME feedback gains, then solve the 2x2 system E dx_N = e.
+            d0 = np.zeros(nx); Dv = np.zeros((nx, 2))
+            for k in range(N):
+                A, B = AB[k]
+                u0 = K[k] @ d0 + kf[k]; Uv = K[k] @ Dv + kfv[k]
+                d0 = A @ d0 + B @ u0 + c[k]; Dv = A @ Dv + B @ Uv
+            e = prob.traj_ref[N, :2] - X[N, :2]
+            nu_new = np.linalg.solve(Dv[:2, :], e - d0[:2])
+            kf = [kf[k] + kfv[k] @ nu_new for k in range(N)]
         dX = np.zeros_like(X); dU = np.zeros_like(U)
         dX[0] = prob.x_init - X[0]
         for k in range(N):
@@ -322,7 +346,7 @@ def solve(prob: nlp.Problem, U0=None, X0=None, opt: Options = None, verbose=Fals
             dX[k + 1] = A @ dX[k] + B @ dU[k] + c[k]
         lam_new = np.zeros_like(lam)
         for k in range(1, N + 1):
-            lam_new[k] = -(Pm[k] @ dX[k] + pv[k])
+            lam_new[k] = -(Pm[k] @ dX[k] + pv[k] + pvv[k] @ nu_new)
         # ---------------- recover ds, dt, dz ------------------------------
         ds = np.zeros(N + 1)
         for k in range(N + 1):
@@ -415,6 +439,7 @@ def solve(prob: nlp.Problem, U0=None, X0=None, opt: Options = None, verbose=Fals
             t[k] = t[k] + alpha * dt[k]
             z[k] = z[k] + ad * dz[k]
         lam = lam + alpha * (lam_new - lam)
+        nu_eq = nu_eq + alpha * (nu_new - nu_eq)
     return dict(X=X, U=U, s=s, status=status, iters=it, cost=nlp.cost(prob, X, U, s), E0=E0,
                 lam=lam, mu=mu, nfail=nfail)
 

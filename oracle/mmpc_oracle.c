@@ -173,6 +173,7 @@ typedef struct {
     double Hxx[NSM][NXM][NXM], Hux[NSM][NUM][NXM], Huu[NSM][NUM][NUM], qx[NSM][NXM], qu[NSM][NUM];
     double hss[NSM], gss[NSM], vx[NSM][NXM], vxN[NXM];
     double K[NSM][NUM][NXM], kf[NSM][NUM];
+    double pvv[NSM][NXM][2], kfv[NSM][NUM][2], nu_eq[2], nu_new[2];   /* terminal xy equality (interface_wholebody_qref.py:166-167) */
     double dX[NSM][NXM], dU[NSM][NUM], ds[NSM], lamn[NSM][NXM];
     double dt_[NSM][RMX], dz[NSM][RMX];
     double Q2[NXM][NXM], P2[NXM][NXM], RW2[NUM][NUM];
@@ -270,6 +271,7 @@ static void merit_parts(work *w, double X[NSM][NXM], double U[NSM][NUM], const d
         f_dyn(w->cfg->kind, w->cfg->dt, X[k], U[k], xn);
         for (int j = 0; j < w->nx; j++) theta += fabs(xn[j] - X[k + 1][j]);
     }
+    if (w->cfg->terminal_xy_eq) for (int j = 0; j < 2; j++) theta += fabs(X[w->N][j] - w->xref[w->N * w->nx + j]);
     for (int k = 0; k <= w->N; k++)
         for (int r = 0; r < w->nrow; r++)
             if (w->act[k][r]) { theta += fabs(h[k][r] + t[k][r]); bar -= mu * log(t[k][r]); }
@@ -365,6 +367,8 @@ static int factor(work *w, double mu, int use_exact) {
             }
     }
     /* Riccati: P_k, p_k overwrite Hxx[k], qx[k] */
+    memset(w->pvv[N], 0, sizeof(w->pvv[N]));
+    w->pvv[N][0][0] = 1.0; w->pvv[N][1][1] = 1.0; /* E^T, E = [I2 0] */
     for (int k = N - 1; k >= 0; k--) {
         double (*P)[NXM] = w->Hxx[k + 1]; double *p = w->qx[k + 1];
         double PA[NXM][NXM], PB[NXM][NUM], pc[NXM];
@@ -391,6 +395,19 @@ static int factor(work *w, double mu, int use_exact) {
             for (int i = 0; i < nu; i++) w->K[k][i][j] = -col[i];
         }
         { double col[NUM]; for (int i = 0; i < nu; i++) col[i] = gu[i]; chol_solve(L, nu, col); for (int i = 0; i < nu; i++) w->kf[k][i] = -col[i]; }
+        if (c->terminal_xy_eq)
+            for (int cc = 0; cc < 2; cc++) {   /* sensitivities of the direction w.r.t. the two terminal multipliers */
+                double col[NUM];
+                for (int i = 0; i < nu; i++) { double v = 0; for (int l = 0; l < nx; l++) v += w->B[k][l][i] * w->pvv[k + 1][l][cc]; col[i] = v; }
+                chol_solve(L, nu, col);
+                for (int i = 0; i < nu; i++) w->kfv[k][i][cc] = -col[i];
+                for (int i = 0; i < nx; i++) {
+                    double v = 0;
+                    for (int l = 0; l < nx; l++) v += w->A[k][l][i] * w->pvv[k + 1][l][cc];
+                    for (int l = 0; l < nu; l++) v += G[l][i] * w->kfv[k][l][cc];
+                    w->pvv[k][i][cc] = v;
+                }
+            }
         double Pn[NXM][NXM];
         for (int i = 0; i < nx; i++) {
             for (int j = 0; j < nx; j++) { double v = F[i][j]; for (int l = 0; l < nu; l++) v += G[l][i] * w->K[k][l][j]; Pn[i][j] = v; }
@@ -487,6 +504,12 @@ int mmpc_oracle_solve(const oracle_cfg *cfg, const double *x_init, const double 
                 for (int i = 0; i < nu; i++) { double v = 0; for (int j = 0; j < nx; j++) v += w->B[k][j][i] * w->lam[k + 1][j]; rdu[k][i] -= v; }
                 for (int j = 0; j < nx; j++) { if (fabs(w->c[k][j]) > err_p) err_p = fabs(w->c[k][j]); zsum += fabs(w->lam[k + 1][j]); }
             }
+            if (cfg->terminal_xy_eq)
+                for (int j = 0; j < 2; j++) {
+                    rdx[N][j] += w->nu_eq[j];
+                    double ce = fabs(w->X[N][j] - w->xref[N * nx + j]); if (ce > err_p) err_p = ce;
+                    zsum += fabs(w->nu_eq[j]);
+                }
             for (int k = 0; k <= N; k++) {
                 if (k > 0) for (int i = 0; i < nx; i++) if (fabs(rdx[k][i]) > err_d) err_d = fabs(rdx[k][i]);
                 if (k < N) for (int i = 0; i < nu; i++) if (fabs(rdu[k][i]) > err_d) err_d = fabs(rdu[k][i]);
@@ -511,6 +534,30 @@ int mmpc_oracle_solve(const oracle_cfg *cfg, const double *x_init, const double 
         if (changed) filt_init = 0;
         /* ---- Newton direction */
         if (!factor(w, mu, 1)) if (!factor(w, mu, 0)) { status = 2; break; }
+        w->nu_new[0] = w->nu_new[1] = 0;
+        if (cfg->terminal_xy_eq) {
+            double d0[NXM] = {0}, Dv[NXM][2], u0[NUM], Uv[NUM][2], t0[NXM], Tv[NXM][2];
+            memset(Dv, 0, sizeof(Dv));
+            for (int k = 0; k < N; k++) {
+                for (int i = 0; i < nu; i++) {
+                    double v = w->kf[k][i], v0 = w->kfv[k][i][0], v1 = w->kfv[k][i][1];
+                    for (int j = 0; j < nx; j++) { v += w->K[k][i][j] * d0[j]; v0 += w->K[k][i][j] * Dv[j][0]; v1 += w->K[k][i][j] * Dv[j][1]; }
+                    u0[i] = v; Uv[i][0] = v0; Uv[i][1] = v1;
+                }
+                for (int i = 0; i < nx; i++) {
+                    double v = w->c[k][i], v0 = 0, v1 = 0;
+                    for (int j = 0; j < nx; j++) { v += w->A[k][i][j] * d0[j]; v0 += w->A[k][i][j] * Dv[j][0]; v1 += w->A[k][i][j] * Dv[j][1]; }
+                    for (int j = 0; j < nu; j++) { v += w->B[k][i][j] * u0[j]; v0 += w->B[k][i][j] * Uv[j][0]; v1 += w->B[k][i][j] * Uv[j][1]; }
+                    t0[i] = v; Tv[i][0] = v0; Tv[i][1] = v1;
+                }
+                memcpy(d0, t0, sizeof(d0)); memcpy(Dv, Tv, sizeof(Dv));
+            }
+            double e0 = w->xref[N * nx + 0] - w->X[N][0] - d0[0], e1 = w->xref[N * nx + 1] - w->X[N][1] - d0[1];
+            double det = Dv[0][0] * Dv[1][1] - Dv[0][1] * Dv[1][0];
+            w->nu_new[0] = (e0 * Dv[1][1] - Dv[0][1] * e1) / det;
+            w->nu_new[1] = (Dv[0][0] * e1 - e0 * Dv[1][0]) / det;
+            for (int k = 0; k < N; k++) for (int i = 0; i < nu; i++) w->kf[k][i] += w->kfv[k][i][0] * w->nu_new[0] + w->kfv[k][i][1] * w->nu_new[1];
+        }
         for (int j = 0; j < nx; j++) w->dX[0][j] = 0;
         for (int k = 0; k < N; k++) {
             for (int i = 0; i < nu; i++) { double v = w->kf[k][i]; for (int j = 0; j < nx; j++) v += w->K[k][i][j] * w->dX[k][j]; w->dU[k][i] = v; }
@@ -522,7 +569,9 @@ int mmpc_oracle_solve(const oracle_cfg *cfg, const double *x_init, const double 
             }
         }
         for (int k = 1; k <= N; k++) for (int i = 0; i < nx; i++) {
-            double v = w->qx[k][i]; for (int j = 0; j < nx; j++) v += w->Hxx[k][i][j] * w->dX[k][j]; w->lamn[k][i] = -v; }
+            double v = w->qx[k][i]; for (int j = 0; j < nx; j++) v += w->Hxx[k][i][j] * w->dX[k][j];
+            if (cfg->terminal_xy_eq) v += w->pvv[k][i][0] * w->nu_new[0] + w->pvv[k][i][1] * w->nu_new[1];
+            w->lamn[k][i] = -v; }
         for (int k = 0; k <= N; k++) {
             double vdx = 0; for (int j = 0; j < nx; j++) vdx += w->vx[k][j] * w->dX[k][j];
             if (k == N - 1) for (int j = 0; j < nx; j++) vdx += w->vxN[j] * w->dX[N][j];
@@ -585,6 +634,7 @@ int mmpc_oracle_solve(const oracle_cfg *cfg, const double *x_init, const double 
         }
         nf += !accepted;
         /* ---- update */
+        for (int j = 0; j < 2; j++) w->nu_eq[j] += alpha * (w->nu_new[j] - w->nu_eq[j]);
         for (int k = 0; k <= N; k++) {
             if (k > 0) for (int j = 0; j < nx; j++) { w->X[k][j] += alpha * w->dX[k][j]; w->lam[k][j] += alpha * (w->lamn[k][j] - w->lam[k][j]); }
             if (k < N) for (int j = 0; j < nu; j++) w->U[k][j] += alpha * w->dU[k][j];

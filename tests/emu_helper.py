@@ -31,10 +31,11 @@ def build(asan=False):
 
 
 def make_params(par, M, obs_per_stage=False, use_xguess=False, tol=1e-8, mu_init=1.0, max_iter=200):
+    """MmpcParams as the C ABI would build it from mmpc_config + weights (terminal_xy_eq from par)."""
     p = MmpcParams()
     nx, nu = par.nx, par.nu
     p.N, p.M, p.obs_per_stage, p.max_iter = par.N, M, int(obs_per_stage), max_iter
-    p.use_xguess, p.terminal_xy_eq = int(use_xguess), 0
+    p.use_xguess, p.terminal_xy_eq = int(use_xguess), int(bool(getattr(par, 'terminal_xy_equality', False)))
     p.dt, p.tol, p.mu_init, p.S = par.dt, tol, mu_init, float(np.ravel(par.S)[0])
     Q2 = par.Q + par.Q.T; P2 = par.P + par.P.T; R2 = par.R + par.R.T; W2 = par.W + par.W.T
     for i, v in enumerate(Q2.ravel()): p.Q2[i] = v

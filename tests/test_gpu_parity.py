@@ -104,6 +104,29 @@ def test_single_instance_reference_api(mm):
     assert abs(ctrl.angleDiff(-3.14, 3.14) - 0.0031853) < 1e-7
 
 
+def test_terminal_xy_equality_through_opti_facade(mm):
+    """The driver's `controller.opti.subject_to(controller.X[N,:2] == controller.X_ref[N,:2])`
+    (interface_wholebody_qref.py:166-167) switches the hard terminal equality on; reset() drops it again."""
+    B = 16
+    d = synth.make_batch(B)
+    par = nlp.WholeBodyParams()
+    x0 = np.clip(d["x_init"], par.xlim[0], par.xlim[1])
+    d["traj_ref"][:, :, :2] = x0[:, None, :2] + 0.5 * (d["traj_ref"][:, :, :2] - x0[:, None, :2])
+    ctrl = _wb(mm, 20, 5, B)
+    ctrl.opti.subject_to(ctrl.X[ctrl.N, :2] == ctrl.X_ref[ctrl.N, :2])
+    r = ctrl.solve_batch(d["x_init"], d["traj_ref"], d["u_ref"], d["obs"])
+    par.terminal_xy_equality = True
+    o = coracle.solve_batch(par, d["x_init"], d["traj_ref"], d["u_ref"], np.zeros((B, 20, 5)), d["obs"], nthreads=8)
+    assert (r["status"] == 0).all() and (o["status"] == 0).all()
+    assert np.abs(r["X"][:, 20, :2] - d["traj_ref"][:, 20, :2]).max() < 1e-9
+    assert np.abs(r["X"] - o["X"]).max() < TOL and np.abs(r["U"] - o["U"]).max() < TOL
+    with pytest.raises(NotImplementedError):
+        ctrl.opti.subject_to(ctrl.X[3, :2] == ctrl.X_ref[3, :2])
+    ctrl.reset()
+    r2 = ctrl.solve_batch(d["x_init"], d["traj_ref"], d["u_ref"], d["obs"])
+    assert np.abs(r2["X"][:, 20, :2] - d["traj_ref"][:, 20, :2]).max() > 1e-3      # soft tracking only
+
+
 def test_full_size_properties(mm):
     """BASELINE batch (8192): every instance converges to scaled KKT <= 1e-8, the solve is deterministic,
     dynamics are satisfied by the returned trajectory, bounds hold, and a permutation of the batch
