@@ -147,6 +147,12 @@ def main():
         fl = riccati_flops_per_iter(N, nx, nu, M, 4) * mean_iters * Bl
         achieved_tf = fl / (k_ms * 1e-3) / 1e12
         by = algorithmic_bytes_per_solve(N, nx, nu, M) * Bl
+        traffic = None
+        tpath = os.path.join(_ROOT, "profiles", "r01_pmc_traffic.json")
+        if world == 1 and (N, M, Bg) == (20, 5, 8192) and os.path.exists(tpath):
+            # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), collected
+            # separately with the same command and committed under profiles/ (bench.py cannot run the profiler itself)
+            traffic = json.load(open(tpath))["traffic_bytes_per_launch"]
         res = {
             "metric": "MPC solves/sec, whole-body N=%d batch=%d" % (N, Bg),
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -159,7 +165,7 @@ def main():
                        "max_scaled_kkt": err_max, "lds_bytes_per_problem": eng.lds_bytes},
             "roofline": {"bound": "mfma", "kernel": "mmpc_fast_kernel<0,20,5>" if (N, M) == (20, 5) else "mmpc_solve_kernel<0>", "achieved": achieved_tf,
                          "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tf / FP64_PEAK_TFLOPS,
-                         "traffic": None, "kernel_ms": k_ms,
+                         "traffic": traffic, "kernel_ms": k_ms,
                          "flops_per_iter": riccati_flops_per_iter(N, nx, nu, M, 4),
                          "hbm_achieved_GBs": by / (k_ms * 1e-3) / 1e9, "hbm_frac": by / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
