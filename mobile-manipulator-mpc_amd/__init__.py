@@ -17,7 +17,9 @@ from .robot_models.mobile_manipulator import MobileManipulator
 from .controllers.mpc_wholebody_qref import MPCWholeBody
 from .controllers.mpc_base import MPCBase
 from . import _capi
+from . import interface_wholebody_qref
+from .interface_wholebody_qref import BatchedRecedingHorizon
 from .build import build_extension
 
 __all__ = ["Obstacles", "Base", "ManipulatorPanda3DoF", "MobileManipulator", "MPCWholeBody", "MPCBase",
-           "build_extension", "_capi"]
+           "build_extension", "_capi", "BatchedRecedingHorizon", "interface_wholebody_qref"]

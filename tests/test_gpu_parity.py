@@ -172,6 +172,33 @@ def test_full_size_properties(mm):
     assert np.abs(X[:64] - o["X"]).max() < TOL
 
 
+def test_closed_loop_moving_obstacles_c5(mm):
+    """Config C5 in small: N=30, M=8 moving obstacles, warm-started receding horizon, 4 ticks; the same loop
+    driven by the CPU oracle must stay within 1e-5 of the GPU loop (errors compound through the plant step)."""
+    B, N, M = 16, 30, 8
+    d = synth.make_batch(B, N=N, M=M, config_id=5, moving=True)
+    par = nlp.WholeBodyParams(N=N)
+    ctrl = _wb(mm, N, M, B, obs_per_stage=True)
+    x_target = d["traj_ref"][:, 0] + (d["traj_ref"][:, N] - d["traj_ref"][:, 0]) * (50.0 / N)
+    loop = mm.BatchedRecedingHorizon(ctrl, np.clip(d["x_init"], par.xlim[0], par.xlim[1]), x_target, t_move=5.0,
+                                     obs=d["obs"], obs_vel=d["obs_vel"])
+    x = loop.x.copy()
+    ul = np.zeros((B, N, 5))
+    iw = mm.interface_wholebody_qref
+    for tick in range(4):
+        obs_now = loop.obstacles_now()
+        loc, lu = iw.calc_local_ref_traj(x, loop.traj_ref, loop.u_ref, N)
+        o = coracle.solve_batch(par, x, loc, lu, ul, obs_now, nthreads=8)
+        r = loop.step()
+        ok = o["status"] == 0
+        assert ok.mean() > 0.9
+        assert np.abs(r["U"][ok] - o["U"][ok]).max() < 1e-5
+        ul = o["U"]
+        x = np.array([coracle.f("wholebody", 0.1, np.clip(x[b], par.xlim[0], par.xlim[1]), o["U"][b, 0]) for b in range(B)])
+        loop.x = x.copy()     # keep both loops on the oracle's state so that one bad instance cannot drift
+    assert loop.tick == 4 and np.mean(loop.iters_log[-1]) < np.mean(loop.iters_log[0])   # warm start pays
+
+
 def test_bad_arguments_raise(mm):
     ctrl = _wb(mm, 20, 5, 4)
     d = synth.make_batch(8)
