@@ -53,6 +53,11 @@ typedef struct mmpc_config {
     double ulim[2][5]; /* [lo|hi][nu] */
     double xlim[2][9]; /* [lo|hi][nx]; psi entry +-INFINITY (mpc_base.py:16 stores 5 columns) */
     double dulim[2][5];
+    int L;             /* half-space ("manipulation") obstacles, 0..8: len(obstacle_manipulation_list)
+                          (mpc_wholebody_qref.py:10,39; demo_wholebody_qref.py:21-33); whole-body kind only */
+    double halfspace[8][6]; /* per obstacle: point (3), outward normal (3).  One row per (stage, arm sample point):
+                          -max_j n_j.((p_j - 0.03 n_j) - P_i) <= s_k, the INTENDED form of obsAvoidConvex (:57-89);
+                          the stale/free `constr` entries of the as-written L>=2 code path are not reproduced */
 } mmpc_config;
 
 typedef struct mmpc_handle_s *mmpc_handle;

@@ -16,7 +16,8 @@ class MmpcConfig(C.Structure):
     _fields_ = [("kind", C.c_int), ("N", C.c_int), ("M", C.c_int), ("obs_per_stage", C.c_int),
                 ("max_batch", C.c_int), ("device", C.c_int), ("max_iter", C.c_int),
                 ("dt", C.c_double), ("tol", C.c_double), ("mu_init", C.c_double),
-                ("ulim", (C.c_double * 5) * 2), ("xlim", (C.c_double * 9) * 2), ("dulim", (C.c_double * 5) * 2)]
+                ("ulim", (C.c_double * 5) * 2), ("xlim", (C.c_double * 9) * 2), ("dulim", (C.c_double * 5) * 2),
+                ("L", C.c_int), ("halfspace", (C.c_double * 6) * 8)]
 
 
 EXPORTS = ["mmpc_create", "mmpc_destroy", "mmpc_set_weights", "mmpc_set_terminal_xy_equality", "mmpc_reset",
@@ -66,7 +67,7 @@ class Engine:
     """Owns one mmpc_handle (one controller's NLP structure on one GPU)."""
 
     def __init__(self, kind, N, M, dt, ulim, xlim, dulim, max_batch=1, device=0, obs_per_stage=False,
-                 tol=1e-8, mu_init=1.0, max_iter=200):
+                 tol=1e-8, mu_init=1.0, max_iter=200, halfspaces=None):
         self.kind, self.N, self.M = kind, int(N), int(M)
         self.nx, self.nu = (9, 5) if kind == KIND_WHOLEBODY else (6, 2)
         self.max_batch, self.device, self.obs_per_stage = int(max_batch), int(device), bool(obs_per_stage)
@@ -81,6 +82,15 @@ class Engine:
                 cfg.dulim[r][j] = dulim[r, j] if j < self.nu else 0.0
             for j in range(9):
                 cfg.xlim[r][j] = xlim[r, j] if j < self.nx else 0.0
+        cfg.L = 0
+        if halfspaces is not None and len(halfspaces):
+            hs = np.asarray(halfspaces, float).reshape(-1, 6)
+            if hs.shape[0] > 8:
+                raise ValueError("at most 8 half-space obstacles")
+            cfg.L = hs.shape[0]
+            for j in range(cfg.L):
+                for a in range(6):
+                    cfg.halfspace[j][a] = hs[j, a]
         self._h = C.c_void_p()
         rc = lib().mmpc_create(C.byref(cfg), C.byref(self._h))
         if rc != 0:

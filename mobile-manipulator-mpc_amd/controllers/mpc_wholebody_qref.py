@@ -26,7 +26,8 @@ class MPCWholeBody:
                  xlim=np.array([[-100, -100, -INF, -2, -2, -PI, -PI / 2, -PI, 0],
                                 [100, 100, INF, 2, 2, PI, PI / 2, 0, 3 * PI / 2]]),
                  dulim=np.array([[-INF, -INF, -0.5, -0.5, -0.5], [INF, INF, 0.5, 0.5, 0.5]]),
-                 max_batch=1, device=0, obs_per_stage=False, n_obstacles=None, tol=1e-8, max_iter=200):
+                 max_batch=1, device=0, obs_per_stage=False, n_obstacles=None, tol=1e-8, max_iter=200,
+                 faithful_convex=None):
         self.N = N
         self.Q_value, self.R_value, self.P_value, self.S_value, self.W_value = Q, R, P, S, W
         self.dt = robot.dt
@@ -38,14 +39,21 @@ class MPCWholeBody:
         self.obstacle_manipulation_list = obstacle_manipulation_list
         self.endpoint_self_collision_radius = 0.05   # mpc_wholebody_qref.py:43
         self.obstacle_expand_dist = 0.03             # :44
-        if len(obstacle_manipulation_list) > 0:
-            raise NotImplementedError("half-space obstacles (mpc_wholebody_qref.py:57-89) are on the 'next' list")
+        # half-space ("manipulation") obstacles, mpc_wholebody_qref.py:57-89: one row per (stage, arm sample point),
+        # -max_j n_j.((p_j - 0.03 n_j) - P_i) <= s_k.  For L >= 2 the reference as written emits L rows per point that
+        # read stale / free `constr` entries; that behaviour is NOT reproduced, so the caller has to
+        # acknowledge the divergence with faithful_convex=False.  L = 1 is exact.
+        hs = [np.concatenate([np.asarray(pt, float).reshape(3), np.asarray(nrm, float).reshape(3)])
+              for pt, nrm in obstacle_manipulation_list]
+        if len(hs) >= 2 and faithful_convex is not False:
+            raise NotImplementedError("L >= 2 half-space obstacles: the as-written stale-`constr` coupling (quirk Q8) is "
+                                      "not reproduced; pass faithful_convex=False to use the intended max-over-planes rows")
         if abs(self.base_radius - 0.4) > 0 or abs(self.endpoint_self_collision_radius - 0.05) > 0:
             raise ValueError("the kernels bake base_radius 0.4 / self-collision radius 0.05 (base.py:15, :43)")
         self._M = len(obstacle_list) if n_obstacles is None else int(n_obstacles)
         self._engine = _capi.Engine(_capi.KIND_WHOLEBODY, N, self._M, self.dt, self.ulim, self.xlim, self.dulim,
                                     max_batch=max_batch, device=device, obs_per_stage=obs_per_stage, tol=tol,
-                                    max_iter=max_iter)
+                                    max_iter=max_iter, halfspaces=hs)
         self.max_batch = max_batch
         self.X, self.X_ref = Sym("X"), Sym("X_ref")
         self.reset()

@@ -54,6 +54,8 @@ struct MmpcParams {
     double RW2[25];          // (R+R^T)+(W+W^T), leading dimension NU
     double R2[25], W2[25];   // R+R^T, W+W^T
     double ulim[2][5], xlim[2][9], dulim[2][5];
+    int L;                   // half-space ("manipulation") obstacles (whole-body kind), 0..8
+    double hs[8][6];         // point (3), normal (3)   (demo_wholebody_qref.py:21-33)
 };
 
 // robot_models/manipulator_3DoF.py:18-22, mobile_manipulator.py:14-15, base.py:15,
@@ -119,18 +121,18 @@ struct MmpcDims {
 struct MmpcLayout {
     int X, U, S, LAM, XREF, UREF, ULAST, OBS, T, Z, HR, DTR, GC, HC, GSF, CV, CD, GX, GU, HXX, QX, HUXL, HUUL,
         HUX02, HUUD, QU, HSS, GSS, VX, VXN, KK, KF, DX, DU, DS, DLAM, PF, TT, PC, MF, MG, MH, MGX, MGU, RED, FILT,
-        MISC, PNU, PNUS, KFV, GNU, FWV, NUEQ, total;
+        MISC, PNU, PNUS, KFV, GNU, FWV, NUEQ, GHS, total;
     int R, NR;
 };
 
 template <int KIND>
-MMPC_HD MmpcLayout mmpc_layout(int N, int M, int obs_per_stage) {
+MMPC_HD MmpcLayout mmpc_layout(int N, int M, int obs_per_stage, int nhs = 0) {
     typedef MmpcDims<KIND> D;
     MmpcLayout L;
     int o = 0;
     const int NS = N + 1;
-    L.R = 2 * D::NU + 2 * D::NX + M + D::NSELF;
-    L.NR = M + D::NSELF;
+    L.R = 2 * D::NU + 2 * D::NX + M + D::NSELF + nhs;   // nhs = 6 half-space rows per stage when L > 0
+    L.NR = M + D::NSELF + nhs;
 #define MMPC_CARVE(name, n) L.name = o; o += (n); o = (o + 1) & ~1;
     MMPC_CARVE(X, NS * D::NX) MMPC_CARVE(U, N * D::NU) MMPC_CARVE(S, NS) MMPC_CARVE(LAM, NS * D::NX)
     MMPC_CARVE(XREF, NS * D::NX) MMPC_CARVE(UREF, N * D::NU) MMPC_CARVE(ULAST, N * D::NU)
@@ -148,7 +150,7 @@ MMPC_HD MmpcLayout mmpc_layout(int N, int M, int obs_per_stage) {
     MMPC_CARVE(RED, 8 * MMPC_WAVE) MMPC_CARVE(FILT, 2 * MMPC_FCAP) MMPC_CARVE(MISC, 8)
     // terminal xy equality (interface_wholebody_qref.py:166-167): multiplier sensitivities
     MMPC_CARVE(PNU, D::NX * 2) MMPC_CARVE(PNUS, NS * D::NX * 2) MMPC_CARVE(KFV, N * D::NU * 2) MMPC_CARVE(GNU, D::NV * 2)
-    MMPC_CARVE(FWV, 2 * 3 * D::NX) MMPC_CARVE(NUEQ, 4)
+    MMPC_CARVE(FWV, 2 * 3 * D::NX) MMPC_CARVE(NUEQ, 4) MMPC_CARVE(GHS, NS * nhs * 6)
 #undef MMPC_CARVE
     L.total = o;
     return L;
@@ -208,6 +210,40 @@ MMPC_DEV double mmpc_self_row(int i, double px, double py, double c, double s, c
     return MMPC_SELF_R - n;
 }
 
+// half-space row for arm sample point i of [j2/2, j2, (j2+j3)/2, j3, (j3+e)/2, e]
+// (mpc_wholebody_qref.py:57-89, 216-217):  h = -max_j n_j.((pi_j - 0.03 n_j) - P_i(x)).
+// One row per (stage, point): the intended formulation; the reference's L>=2 code path emits L rows that read
+// stale / free `constr` entries (quirk Q8) - not reproduced.  g6 = dh/d(x,y,psi,q1,q2,q3) or null.
+MMPC_DEV double mmpc_hs_row(const MmpcParams &P, int i, double px, double py, double c, double s, const double dr[3],
+                            const double dz[3], double *g6) {
+    const double al = (i == 0 || i == 2) ? 0.5 : (i == 1 ? 1.0 : 0.0);
+    const double be = (i == 2 || i == 4) ? 0.5 : (i == 3 ? 1.0 : 0.0);
+    const double ga = i == 4 ? 0.5 : (i == 5 ? 1.0 : 0.0);
+    const double sig = al + be + ga, cm0 = sig, cm1 = be + ga, cm2 = ga;
+    const double R = sig * MMPC_BX + cm0 * dr[0] + cm1 * dr[1] + cm2 * dr[2];
+    const double Z = sig * MMPC_BZ + cm0 * dz[0] + cm1 * dz[1] + cm2 * dz[2];
+    const double Pw0 = sig * px + R * c, Pw1 = sig * py + R * s, Pw2 = Z;
+    double best = 0.0;
+    int jb = -1;
+    for (int j = 0; j < P.L; j++) {
+        const double *h = P.hs[j];
+        const double v = h[3] * ((h[0] - 0.03 * h[3]) - Pw0) + h[4] * ((h[1] - 0.03 * h[4]) - Pw1) + h[5] * ((h[2] - 0.03 * h[5]) - Pw2);
+        if (jb < 0 || v > best) { best = v; jb = j; }
+    }
+    if (g6) {
+        const double n0 = P.hs[jb][3], n1 = P.hs[jb][4], n2 = P.hs[jb][5];
+        const double z0 = cm0 * dz[0], z1 = cm1 * dz[1], z2 = cm2 * dz[2];
+        const double r0 = cm0 * dr[0], r1 = cm1 * dr[1], r2 = cm2 * dr[2];
+        const double Rm0 = z0 + z1 + z2, Rm1 = -z1 - z2, Rm2 = -z2;
+        const double Zm0 = -(r0 + r1 + r2), Zm1 = r1 + r2, Zm2 = r2;
+        g6[0] = sig * n0; g6[1] = sig * n1; g6[2] = n0 * (-R * s) + n1 * (R * c);
+        g6[3] = (n0 * c + n1 * s) * Rm0 + n2 * Zm0;
+        g6[4] = (n0 * c + n1 * s) * Rm1 + n2 * Zm1;
+        g6[5] = (n0 * c + n1 * s) * Rm2 + n2 * Zm2;
+    }
+    return -best;
+}
+
 MMPC_DEV double mmpc_angle_diff(double a, double b) {  // mpc_base.py:56-94
     const double PI = 3.14159265358979323846;
     a = fmod(a + PI, 2 * PI) - PI;
@@ -244,7 +280,8 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
     typedef MmpcTab<KIND> TB;
     constexpr int NX = D::NX, NU = D::NU, NSELF = D::NSELF, NV = D::NV, NXX = D::NXX, NUU = D::NUU;
     const int N = P.N, M = P.M, NS = N + 1;
-    const MmpcLayout L = mmpc_layout<KIND>(N, M, P.obs_per_stage);
+    const int NHS = (KIND == 0 && P.L > 0) ? 6 : 0;
+    const MmpcLayout L = mmpc_layout<KIND>(N, M, P.obs_per_stage, NHS);
     const int R = L.R, NR = L.NR;
     double *X = lds + L.X, *U = lds + L.U, *S = lds + L.S, *LAM = lds + L.LAM, *XREF = lds + L.XREF,
            *UREF = lds + L.UREF, *ULAST = lds + L.ULAST, *OBS = lds + L.OBS, *T = lds + L.T, *Z = lds + L.Z,
@@ -256,9 +293,9 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
            *DS = lds + L.DS, *DLAM = lds + L.DLAM, *PF = lds + L.PF, *TT = lds + L.TT, *PC = lds + L.PC,
            *MF = lds + L.MF, *MG = lds + L.MG, *MH = lds + L.MH, *MGX = lds + L.MGX, *MGU = lds + L.MGU,
            *RED = lds + L.RED, *FILT = lds + L.FILT, *MISC = lds + L.MISC, *PNU = lds + L.PNU, *PNUS = lds + L.PNUS,
-           *KFV = lds + L.KFV, *GNU = lds + L.GNU, *FWV = lds + L.FWV, *NUEQ = lds + L.NUEQ;
+           *KFV = lds + L.KFV, *GNU = lds + L.GNU, *FWV = lds + L.FWV, *NUEQ = lds + L.NUEQ, *GHS = lds + L.GHS;
     const bool teq = P.terminal_xy_eq != 0;
-    const int SL_UHI = NU, SL_XLO = 2 * NU, SL_XHI = 2 * NU + NX, SL_C = 2 * NU + 2 * NX, SL_S = SL_C + M;
+    const int SL_UHI = NU, SL_XLO = 2 * NU, SL_XHI = 2 * NU + NX, SL_C = 2 * NU + 2 * NX, SL_S = SL_C + M, SL_H = SL_S + NSELF;
     const double dt = P.dt, Sw = P.S, tol = P.tol;
 
     // bound of a box slot r at stage k; returns false when the row does not exist
@@ -314,6 +351,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
             sincos(xk[2], &sn, &cs);
             mmpc_arm_segments(xk[NX - 3], xk[NX - 2], xk[NX - 1], dr, dz);
             for (int i = 0; i < NSELF; i++) hr[M + i] = mmpc_self_row(i, xk[0], xk[1], cs, sn, dr, dz, nullptr) - sks;
+            for (int i = 0; i < NHS; i++) hr[M + NSELF + i] = mmpc_hs_row(P, i, xk[0], xk[1], cs, sn, dr, dz, nullptr) - sk;
         }
     };
 
@@ -321,7 +359,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
     // ---------------------------------------------------------------- slack / multiplier init
     LANES_BEGIN
     for (int k = lane; k < NS; k += MMPC_WAVE) {
-        double hr[16 + 4];
+        double hr[16 + 4 + 6];
         nl_rows(k, X + k * NX, S[k], S[slack_idx(k)], hr);
         for (int r = 0; r < R; r++) {
             double h = 0.0, b;
@@ -451,6 +489,16 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                     e_p = mmpc_max(e_p, fabs(h + t));
                     tzmax = mmpc_max(tzmax, t * z); tzmin = mmpc_min(tzmin, t * z); zsum += z;
                 }
+                for (int i = 0; i < NHS; i++) {   // half-space rows, bound to s_k (s_N at the end, :268)
+                    double g6[6];
+                    const double h = mmpc_hs_row(P, i, xk[0], xk[1], cs, sn, dr, dz, g6) - S[k];
+                    HR[k * NR + M + NSELF + i] = h;
+                    const double t = T[k * R + SL_H + i], z = Z[k * R + SL_H + i];
+                    for (int a = 0; a < 6; a++) { GHS[(k * 6 + i) * 6 + a] = g6[a]; rdx[kY[a]] += g6[a] * z; }
+                    rds -= z;
+                    e_p = mmpc_max(e_p, fabs(h + t));
+                    tzmax = mmpc_max(tzmax, t * z); tzmin = mmpc_min(tzmin, t * z); zsum += z;
+                }
             }
             if (k < N) rds -= selfz; else MISC[1] = selfz;
             DS[k] = rds;  // stage-local part of the s-stationarity residual (finished in E1b)
@@ -567,6 +615,18 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                     }
                     if (k < N) { hss += w; gss -= zh; for (int a = 0; a < 6; a++) vx[a] += w * g6[a]; }
                     else { hssN += w; gssN -= zh; for (int a = 0; a < 6; a++) vN[a] += w * g6[a]; }
+                }
+                for (int i = 0; i < NHS; i++) {
+                    const double t = T[k * R + SL_H + i], z = Z[k * R + SL_H + i], w = z / t;
+                    const double zh = mu / t + w * (HR[k * NR + M + NSELF + i] + t);
+                    const double *g6 = GHS + (k * 6 + i) * 6;
+                    for (int a = 0; a < 6; a++) {
+                        const int ia = kY[a];
+                        for (int b = 0; b <= a; b++) hxx[ia * (ia + 1) / 2 + kY[b]] += w * g6[a] * g6[b];
+                        qx[ia] += g6[a] * zh;
+                        vx[a] += w * g6[a];
+                    }
+                    hss += w; gss -= zh;
                 }
                 HSS[k] = hss; GSS[k] = gss;
                 for (int a = 0; a < 6; a++) VX[k * 6 + a] = vx[a];
@@ -902,7 +962,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                 th += fabs(h + tv);
                 acc(tv);
             }
-            double hr[16 + 4];
+            double hr[16 + 4 + 6];
             {
                 for (int m = 0; m < M; m++) {
                     const double *o = obs_ptr(k, m);
@@ -913,6 +973,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                     double dr[3], dz[3];
                     mmpc_arm_segments(xk[NX - 3], xk[NX - 2], xk[NX - 1], dr, dz);
                     for (int i = 0; i < NSELF; i++) hr[M + i] = mmpc_self_row(i, xk[0], xk[1], cs, sn, dr, dz, nullptr) - sks;
+                    for (int i = 0; i < NHS; i++) hr[M + NSELF + i] = mmpc_hs_row(P, i, xk[0], xk[1], cs, sn, dr, dz, nullptr) - sk;
                 }
             }
             for (int m = 0; m < NR; m++) {
@@ -940,11 +1001,16 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                     const int m = r - SL_C;
                     h = HR[k * NR + m];
                     jd = GC[(k * M + m) * 2] * dx[0] + GC[(k * M + m) * 2 + 1] * dx[1] - DS[k];
-                } else {
+                } else if (r < SL_H) {
                     const int i = r - SL_S;
                     h = HR[k * NR + M + i];
                     jd = -DS[slack_idx(k)];
                     for (int a = 0; a < 6; a++) jd += GSF[(k * NSELF + i) * 6 + a] * dx[kY[a]];
+                } else {
+                    const int i = r - SL_H;
+                    h = HR[k * NR + M + NSELF + i];
+                    jd = -DS[k];
+                    for (int a = 0; a < 6; a++) jd += GHS[(k * 6 + i) * 6 + a] * dx[kY[a]];
                 }
                 const double t = T[k * R + r], z = Z[k * R + r];
                 const double dtv = -(h + t) - jd, dzv = mu / t - z - (z / t) * dtv;

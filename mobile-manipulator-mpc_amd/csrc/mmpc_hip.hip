@@ -171,6 +171,7 @@ extern "C" int mmpc_create(const mmpc_config *cfg, mmpc_handle *out) {
     *out = nullptr;
     if (cfg->kind != MMPC_KIND_WHOLEBODY && cfg->kind != MMPC_KIND_BASE) return MMPC_E_ARG;
     if (cfg->N < 1 || cfg->N > 63 || cfg->M < 0 || cfg->M > 16 || cfg->max_batch < 1) return MMPC_E_ARG;
+    if (cfg->L < 0 || cfg->L > 8 || (cfg->L > 0 && cfg->kind != MMPC_KIND_WHOLEBODY)) return MMPC_E_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) return MMPC_E_NODEVICE;
     mmpc_handle h = new (std::nothrow) mmpc_handle_s();
@@ -190,9 +191,12 @@ extern "C" int mmpc_create(const mmpc_config *cfg, mmpc_handle *out) {
         for (int j = 0; j < 5; j++) { p.ulim[r][j] = cfg->ulim[r][j]; p.dulim[r][j] = cfg->dulim[r][j]; }
         for (int j = 0; j < 9; j++) p.xlim[r][j] = cfg->xlim[r][j];
     }
+    p.L = cfg->L;
+    for (int j = 0; j < 8; j++) for (int a = 0; a < 6; a++) p.hs[j][a] = j < cfg->L ? cfg->halfspace[j][a] : 0.0;
+    const int nhs = (cfg->kind == MMPC_KIND_WHOLEBODY && cfg->L > 0) ? 6 : 0;
     default_weights(h);
-    const MmpcLayout L = cfg->kind == MMPC_KIND_WHOLEBODY ? mmpc_layout<0>(cfg->N, cfg->M, p.obs_per_stage)
-                                                          : mmpc_layout<1>(cfg->N, cfg->M, p.obs_per_stage);
+    const MmpcLayout L = cfg->kind == MMPC_KIND_WHOLEBODY ? mmpc_layout<0>(cfg->N, cfg->M, p.obs_per_stage, nhs)
+                                                          : mmpc_layout<1>(cfg->N, cfg->M, p.obs_per_stage, 0);
     h->lds_bytes = L.total * (int)sizeof(double);
     if (h->lds_bytes > 160 * 1024) return fail(h, MMPC_E_ARG, "problem needs %s bytes of LDS%s", "more than 163840");
     if (cfg->kind == MMPC_KIND_WHOLEBODY)
@@ -202,7 +206,7 @@ extern "C" int mmpc_create(const mmpc_config *cfg, mmpc_handle *out) {
     h->fast = 0; h->fast_lds_bytes = 0;
     {
 #define MMPC_X(K, NN, MM)                                                                                            \
-        if (cfg->kind == K && cfg->N == NN && cfg->M == MM) {                                                                       \
+        if (cfg->kind == K && cfg->N == NN && cfg->M == MM && cfg->L == 0) {                                                                       \
             h->fast = 1;                                                                                               \
             h->fast_lds_bytes = mmpc_fast_layout<K, NN>(MM, p.obs_per_stage).total * (int)sizeof(double);         \
             HIPCHK(h, hipFuncSetAttribute((const void *)mmpc_fast_kernel<K, NN, MM>, hipFuncAttributeMaxDynamicSharedMemorySize, h->fast_lds_bytes)); \

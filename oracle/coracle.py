@@ -14,7 +14,8 @@ class OracleCfg(C.Structure):
                 ("Q", C.c_double * 81), ("P", C.c_double * 81), ("R", C.c_double * 25), ("W", C.c_double * 25),
                 ("S", C.c_double),
                 ("ulim", (C.c_double * 5) * 2), ("xlim", (C.c_double * 9) * 2), ("dulim", (C.c_double * 5) * 2),
-                ("tol", C.c_double), ("mu_init", C.c_double), ("max_iter", C.c_int)]
+                ("tol", C.c_double), ("mu_init", C.c_double), ("max_iter", C.c_int),
+                ("L", C.c_int), ("hs", (C.c_double * 6) * 8)]
 
 
 def build(force=False):
@@ -35,7 +36,7 @@ def lib():
     return _lib
 
 
-def make_cfg(par, M, obs_per_stage=False, tol=1e-8, mu_init=1.0, max_iter=200):
+def make_cfg(par, M, obs_per_stage=False, tol=1e-8, mu_init=1.0, max_iter=200, hs=None):
     c = OracleCfg()
     c.kind = 0 if par.kind == "wholebody" else 1
     c.N, c.M, c.obs_per_stage = par.N, M, int(obs_per_stage)
@@ -56,6 +57,13 @@ def make_cfg(par, M, obs_per_stage=False, tol=1e-8, mu_init=1.0, max_iter=200):
         for j in range(nx):
             c.xlim[r][j] = par.xlim[r, j]
     c.tol, c.mu_init, c.max_iter = tol, mu_init, max_iter
+    c.L = 0
+    if hs is not None and len(hs):
+        hs = np.asarray(hs, float).reshape(-1, 6)
+        c.L = hs.shape[0]
+        for j in range(c.L):
+            for a in range(6):
+                c.hs[j][a] = hs[j, a]
     return c
 
 

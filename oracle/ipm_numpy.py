@@ -81,6 +81,9 @@ def _rows_for_stage(prob, k):
     if p.kind == "wholebody":
         for i in range(4):
             rows.append(("self", i, None))
+        if prob.hs is not None and len(prob.hs):
+            for i in range(6):
+                rows.append(("hs", i, None))
     return rows
 
 
@@ -112,6 +115,11 @@ def _eval_row(prob, k, row, X, U, s, order):
             return nlp.selfcol_row(X[k], j, 0) - s[ks], None, None, ks, None
         h, jx, H = nlp.selfcol_row(X[k], j, 2)
         return h - s[ks], jx, None, ks, H
+    if kind == "hs":
+        if order == 0:
+            return nlp.halfspace_row(X[k], j, prob.hs, 0) - s[k], None, None, k, None
+        h, jx = nlp.halfspace_row(X[k], j, prob.hs, 1)
+        return h - s[k], jx, None, k, None
     raise ValueError(kind)
 
 

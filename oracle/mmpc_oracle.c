@@ -32,7 +32,8 @@
 #define NUM 5
 #define NSM 65          /* max stages (N+1) */
 #define MMX 16          /* max circle obstacles */
-#define RMX (2 * NUM + 2 * NXM + MMX + 4)
+#define LMX 8           /* max half-space obstacles */
+#define RMX (2 * NUM + 2 * NXM + MMX + 4 + 6)
 #define FCAP 16
 
 typedef struct {
@@ -45,6 +46,8 @@ typedef struct {
     double ulim[2][NUM], xlim[2][NXM], dulim[2][NUM];
     double tol, mu_init;
     int max_iter;
+    int L;               /* half-space ("manipulation") obstacles, demo_wholebody_qref.py:21-33 */
+    double hs[LMX][6];   /* point (3), normal (3) */
 } oracle_cfg;
 
 /* robot_models/manipulator_3DoF.py:18-22, mobile_manipulator.py:14-15, base.py:15,
@@ -135,6 +138,33 @@ static double self_row(const double *x, int i, double *g6) {
     return SELF_R - n;
 }
 
+/* half-space row for sample point i of [j2/2, j2, (j2+j3)/2, j3, (j3+e)/2, e] (mpc_wholebody_qref.py:57-89,216-217):
+ *   h = -max_j n_j.((pi_j - 0.03 n_j) - P_i(x));   one row per (k,i) - the intended formulation, see oracle/nlp.py */
+static const double HS_PTS[6][3] = {{0.5, 0, 0}, {1, 0, 0}, {0.5, 0.5, 0}, {0, 1, 0}, {0, 0.5, 0.5}, {0, 0, 1}};
+static double hs_row(const oracle_cfg *cfg, const double *x, int i, double *g6) {
+    double al = HS_PTS[i][0], be = HS_PTS[i][1], ga = HS_PTS[i][2], sig = al + be + ga;
+    double cm[3] = {sig, be + ga, ga}, dr[3], dz[3];
+    arm_segments(x + 6, dr, dz);
+    double R = sig * BX, Z = sig * BZ;
+    for (int m = 0; m < 3; m++) { R += cm[m] * dr[m]; Z += cm[m] * dz[m]; }
+    double c = cos(x[2]), s = sin(x[2]);
+    double P[3] = {sig * x[0] + R * c, sig * x[1] + R * s, Z};
+    double best = 0; int jb = -1;
+    for (int j = 0; j < cfg->L; j++) {
+        const double *pi = cfg->hs[j], *n = cfg->hs[j] + 3;
+        double v = 0; for (int a = 0; a < 3; a++) v += n[a] * ((pi[a] - 0.03 * n[a]) - P[a]);
+        if (jb < 0 || v > best) { best = v; jb = j; }
+    }
+    if (g6) {
+        const double *n = cfg->hs[jb] + 3;
+        double Rm[3] = {0, 0, 0}, Zm[3] = {0, 0, 0};
+        for (int m = 0; m < 3; m++) for (int j = 0; j < 3; j++) { Rm[j] += cm[m] * dz[m] * SEGC[m][j]; Zm[j] -= cm[m] * dr[m] * SEGC[m][j]; }
+        g6[0] = sig * n[0]; g6[1] = sig * n[1]; g6[2] = n[0] * (-R * s) + n[1] * (R * c);
+        for (int j = 0; j < 3; j++) g6[3 + j] = n[0] * Rm[j] * c + n[1] * Rm[j] * s + n[2] * Zm[j];
+    }
+    return -best;
+}
+
 /* circle row: g = (r+0.4) - dist  (mpc_wholebody_qref.py:53); grad (2), hess (xx,xy,yy) */
 static double circ_row(const double *x, const double *o, double *g2, double *h3) {
     double dx = x[0] - o[0], dy = x[1] - o[1], d = sqrt(dx * dx + dy * dy);
@@ -166,7 +196,8 @@ typedef struct {
     int act[NSM][RMX];
     /* evaluation */
     double h[NSM][RMX];
-    double gcirc[NSM][MMX][2], hcirc[NSM][MMX][3], gself[NSM][4][6];
+    double gcirc[NSM][MMX][2], hcirc[NSM][MMX][3], gself[NSM][4][6], ghs[NSM][6][6];
+    int nhs;
     double A[NSM][NXM][NXM], B[NSM][NXM][NUM], c[NSM][NXM];
     double gX[NSM][NXM], gU[NSM][NUM], gs[NSM];
     /* QP */
@@ -189,6 +220,7 @@ static const double *obs_at(const work *w, int k, int m) {
 #define SL_XHI(w, j) (2 * (w)->nu + (w)->nx + (j))
 #define SL_CIRC(w, m) (2 * (w)->nu + 2 * (w)->nx + (m))
 #define SL_SELF(w, i) (2 * (w)->nu + 2 * (w)->nx + (w)->M + (i))
+#define SL_HS(w, i) (2 * (w)->nu + 2 * (w)->nx + (w)->M + 4 + (i))
 
 static int slack_idx(const work *w, int k) { return k < w->N - 1 ? k : w->N - 1; } /* :265 quirk */
 
@@ -213,6 +245,7 @@ static void setup_rows(work *w) {
             }
         for (int m = 0; m < w->M; m++) w->act[k][SL_CIRC(w, m)] = 1;
         if (c->kind == 0) for (int i = 0; i < 4; i++) w->act[k][SL_SELF(w, i)] = 1;
+        for (int i = 0; i < w->nhs; i++) w->act[k][SL_HS(w, i)] = 1;
     }
 }
 
@@ -234,6 +267,7 @@ static void eval_rows(work *w, double X[NSM][NXM], double U[NSM][NUM], const dou
         if (w->cfg->kind == 0)
             for (int i = 0; i < 4; i++)
                 h[k][SL_SELF(w, i)] = self_row(X[k], i, with_deriv ? w->gself[k][i] : 0) - s[slack_idx(w, k)];
+        for (int i = 0; i < w->nhs; i++) h[k][SL_HS(w, i)] = hs_row(w->cfg, X[k], i, with_deriv ? w->ghs[k][i] : 0) - s[k];
     }
 }
 
@@ -337,9 +371,12 @@ static int factor(work *w, double mu, int use_exact) {
                         w->Hxx[k][0][0] += zz * w->hcirc[k][m][0]; w->Hxx[k][0][1] += zz * w->hcirc[k][m][1];
                         w->Hxx[k][1][0] += zz * w->hcirc[k][m][1]; w->Hxx[k][1][1] += zz * w->hcirc[k][m][2];
                     }
-                } else {
+                } else if (r < 2 * nu + 2 * nx + w->M + 4 || c->kind != 0) {
                     int i = r - 2 * nu - 2 * nx - w->M; ks = slack_idx(w, k);
                     for (int j = 0; j < 6; j++) jx[YIDX[j]] = w->gself[k][i][j];
+                } else {
+                    int i = r - 2 * nu - 2 * nx - w->M - 4; ks = k;     /* half-space rows: s[k] (s[N] at the end, :268) */
+                    for (int j = 0; j < 6; j++) jx[YIDX[j]] = w->ghs[k][i][j];
                 }
                 for (int i = 0; i < nx; i++) { for (int j = 0; j < nx; j++) w->Hxx[k][i][j] += wt * jx[i] * jx[j]; w->qx[k][i] += jx[i] * zh; }
                 w->hss[ks] += wt; w->gss[ks] -= zh;
@@ -435,7 +472,8 @@ int mmpc_oracle_solve(const oracle_cfg *cfg, const double *x_init, const double 
     w->cfg = cfg; w->N = cfg->N; w->M = cfg->M;
     w->nx = cfg->kind == 0 ? 9 : 6; w->nu = cfg->kind == 0 ? 5 : 2;
     int nx = w->nx, nu = w->nu, N = w->N;
-    w->nrow = 2 * nu + 2 * nx + w->M + (cfg->kind == 0 ? 4 : 0);
+    w->nhs = (cfg->kind == 0 && cfg->L > 0) ? 6 : 0;
+    w->nrow = 2 * nu + 2 * nx + w->M + (cfg->kind == 0 ? 4 : 0) + w->nhs;
     w->xinit = x_init; w->xref = traj_ref; w->uref = u_ref; w->ulast = u_last; w->obs = obs;
     for (int i = 0; i < nx; i++) for (int j = 0; j < nx; j++) {
         w->Q2[i][j] = cfg->Q[i * nx + j] + cfg->Q[j * nx + i]; w->P2[i][j] = cfg->P[i * nx + j] + cfg->P[j * nx + i]; }
@@ -494,7 +532,8 @@ int mmpc_oracle_solve(const oracle_cfg *cfg, const double *x_init, const double 
                 if (r < 2 * nu) { int j = r < nu ? r : r - nu; rdu[k][j] += (r < nu ? -zz : zz); }
                 else if (r < 2 * nu + 2 * nx) { int q = r - 2 * nu; int j = q < nx ? q : q - nx; rdx[k][j] += (q < nx ? -zz : zz); }
                 else if (r < 2 * nu + 2 * nx + w->M) { int m = r - 2 * nu - 2 * nx; rdx[k][0] += w->gcirc[k][m][0] * zz; rdx[k][1] += w->gcirc[k][m][1] * zz; rds[k] -= zz; }
-                else { int i = r - 2 * nu - 2 * nx - w->M; for (int j = 0; j < 6; j++) rdx[k][YIDX[j]] += w->gself[k][i][j] * zz; rds[slack_idx(w, k)] -= zz; }
+                else if (r < 2 * nu + 2 * nx + w->M + 4) { int i = r - 2 * nu - 2 * nx - w->M; for (int j = 0; j < 6; j++) rdx[k][YIDX[j]] += w->gself[k][i][j] * zz; rds[slack_idx(w, k)] -= zz; }
+                else { int i = r - 2 * nu - 2 * nx - w->M - 4; for (int j = 0; j < 6; j++) rdx[k][YIDX[j]] += w->ghs[k][i][j] * zz; rds[k] -= zz; }
             }
             for (int k = 0; k < N; k++) {
                 for (int i = 0; i < nx; i++) {
@@ -585,7 +624,8 @@ int mmpc_oracle_solve(const oracle_cfg *cfg, const double *x_init, const double 
                 if (r < 2 * nu) { int j = r < nu ? r : r - nu; jd = (r < nu ? -1.0 : 1.0) * w->dU[k][j]; }
                 else if (r < 2 * nu + 2 * nx) { int q = r - 2 * nu; int j = q < nx ? q : q - nx; jd = (q < nx ? -1.0 : 1.0) * w->dX[k][j]; }
                 else if (r < 2 * nu + 2 * nx + w->M) { int m = r - 2 * nu - 2 * nx; jd = w->gcirc[k][m][0] * w->dX[k][0] + w->gcirc[k][m][1] * w->dX[k][1] - w->ds[k]; }
-                else { int i = r - 2 * nu - 2 * nx - w->M; jd = -w->ds[slack_idx(w, k)]; for (int j = 0; j < 6; j++) jd += w->gself[k][i][j] * w->dX[k][YIDX[j]]; }
+                else if (r < 2 * nu + 2 * nx + w->M + 4) { int i = r - 2 * nu - 2 * nx - w->M; jd = -w->ds[slack_idx(w, k)]; for (int j = 0; j < 6; j++) jd += w->gself[k][i][j] * w->dX[k][YIDX[j]]; }
+                else { int i = r - 2 * nu - 2 * nx - w->M - 4; jd = -w->ds[k]; for (int j = 0; j < 6; j++) jd += w->ghs[k][i][j] * w->dX[k][YIDX[j]]; }
                 double tt = w->t[k][r], zz = w->z[k][r];
                 double dtv = -(w->h[k][r] + tt) - jd, dzv = mu / tt - zz - (zz / tt) * dtv;
                 w->dt_[k][r] = dtv; w->dz[k][r] = dzv;

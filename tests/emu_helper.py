@@ -17,7 +17,8 @@ class MmpcParams(C.Structure):
                 ("dt", C.c_double), ("tol", C.c_double), ("mu_init", C.c_double), ("S", C.c_double),
                 ("Q2", C.c_double * 81), ("P2", C.c_double * 81), ("RW2", C.c_double * 25),
                 ("R2", C.c_double * 25), ("W2", C.c_double * 25),
-                ("ulim", (C.c_double * 5) * 2), ("xlim", (C.c_double * 9) * 2), ("dulim", (C.c_double * 5) * 2)]
+                ("ulim", (C.c_double * 5) * 2), ("xlim", (C.c_double * 9) * 2), ("dulim", (C.c_double * 5) * 2),
+                ("L", C.c_int), ("hs", (C.c_double * 6) * 8)]
 
 
 def build(asan=False):
@@ -30,7 +31,7 @@ def build(asan=False):
     return out
 
 
-def make_params(par, M, obs_per_stage=False, use_xguess=False, tol=1e-8, mu_init=1.0, max_iter=200):
+def make_params(par, M, obs_per_stage=False, use_xguess=False, tol=1e-8, mu_init=1.0, max_iter=200, hs=None):
     """MmpcParams as the C ABI would build it from mmpc_config + weights (terminal_xy_eq from par)."""
     p = MmpcParams()
     nx, nu = par.nx, par.nu
@@ -48,6 +49,13 @@ def make_params(par, M, obs_per_stage=False, use_xguess=False, tol=1e-8, mu_init
             p.ulim[r][j] = par.ulim[r, j]; p.dulim[r][j] = par.dulim[r, j]
         for j in range(nx):
             p.xlim[r][j] = par.xlim[r, j]
+    p.L = 0
+    if hs is not None and len(hs):
+        hs = np.asarray(hs, float).reshape(-1, 6)
+        p.L = hs.shape[0]
+        for j in range(p.L):
+            for a in range(6):
+                p.hs[j][a] = hs[j, a]
     return p
 
 

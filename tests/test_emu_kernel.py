@@ -85,6 +85,41 @@ def test_emu_terminal_xy_equality():
         assert c["eq_violation"] < 1e-9 and c["stationarity_rel"] < 1e-6
 
 
+def _c1_inputs():
+    """demo_wholebody_qref.py:27-44 (scenario 2): x_start = 0, target (5,5,-pi), 3 circles, 2 half-spaces; plus a
+    start next to the block with the arm raised so that the half-space rows are active."""
+    r2 = 1 / np.sqrt(2)
+    hs = np.array([[2.5, 2, 0.35 + 0.606 + 0.333, r2, 0, r2], [2.5, 2, 0.35 + 0.606 + 0.333, -r2, 0, r2]])
+    obs = np.array([[2.5, 3.0, 0.6], [2.5, 1.0, 0.6], [5 - 0.6, 5, 0.1]])
+    x0 = np.zeros(9)
+    x1 = np.array([1.9, 2.0, 0.0, 0.3, 0, 0, 0.3, -1.2, 1.6])
+    g0 = np.linspace(x0, np.array([5, 5, -np.pi, 0, 0, 0, 0, 0, 0.0]), 51)[:21]
+    g1 = np.linspace(x1, np.array([3.2, 2.0, 0, 0, 0, 0, 0.3, -1.2, 1.6]), 51)[:21]
+    return dict(x_init=np.stack([x0, x1]), traj_ref=np.stack([g0, g1]), u_ref=np.zeros((2, 20, 5)),
+                obs=np.stack([obs, obs])), hs
+
+
+def test_emu_halfspace_obstacles_c1():
+    """config C1 geometry with the intended half-space rows (a-9; quirk Q8 not reproduced, see nlp.halfspace_row)"""
+    d, hs = _c1_inputs()
+    par = nlp.WholeBodyParams()
+    r = coracle.solve_batch(par, d["x_init"], d["traj_ref"], d["u_ref"], np.zeros((2, 20, 5)), d["obs"], hs=hs)
+    e = emu_helper.solve_batch(par, d["x_init"], d["traj_ref"], d["u_ref"], np.zeros((2, 20, 5)), d["obs"], hs=hs)
+    assert (r["status"] == 0).all() and (e["status"] == 0).all() and (r["iters"] == e["iters"]).all()
+    assert np.abs(r["X"] - e["X"]).max() < 1e-9 and np.abs(r["U"] - e["U"]).max() < 1e-9
+    assert r["s"][1].max() > 1e-3          # the half-space rows bite in the second instance
+    for b in range(2):
+        prob = nlp.Problem(par, d["x_init"][b], d["traj_ref"][b], d["u_ref"][b], np.zeros((20, 5)), d["obs"][b], hs)
+        c = nlp.kkt_certificate(prob, e["X"][b], e["U"][b], e["s"][b])
+        assert c["eq_violation"] < 1e-9 and c["ineq_violation"] < 1e-9 and c["stationarity_rel"] < 2e-5
+    # rows evaluated literally (world points from the FK, max over planes) agree with the closed form
+    rng = np.random.default_rng(5)
+    for _ in range(20):
+        x = rng.uniform(-2, 2, 9)
+        for i in range(6):
+            assert abs(nlp.halfspace_row(x, i, hs, order=0) - nlp.halfspace_row_direct(x, i, hs)) < 1e-14
+
+
 def test_emu_hard_instances_converge():
     """instances of the 8192 batch that need the filter-reset heuristic / many iterations"""
     d = synth.make_batch(8192)

@@ -127,6 +127,30 @@ def test_terminal_xy_equality_through_opti_facade(mm):
     assert np.abs(r2["X"][:, 20, :2] - d["traj_ref"][:, 20, :2]).max() > 1e-3      # soft tracking only
 
 
+def test_c1_demo_scenario_with_halfspaces(mm):
+    """Config C1: demo_wholebody_qref.py scenario 2 through the reference's constructor signature
+    (obstacle_list + obstacle_manipulation_list), single-instance solve()."""
+    r2 = 1 / np.sqrt(2)
+    oml = [(np.array([2.5, 2, 0.35 + 0.606 + 0.333]), np.array([[r2, 0, r2]])),
+           (np.array([2.5, 2, 0.35 + 0.606 + 0.333]), np.array([[-r2, 0, r2]]))]          # demo_wholebody_qref.py:30-33
+    obstacles = [mm.Obstacles(2.5, 3.0, 0.6), mm.Obstacles(2.5, 1.0, 0.6), mm.Obstacles(5 - 0.6, 5, 0.1)]
+    robot = mm.MobileManipulator(0.1)
+    with pytest.raises(NotImplementedError, match="Q8"):
+        mm.MPCWholeBody(robot, obstacles, oml, N=20)
+    ctrl = mm.MPCWholeBody(robot, obstacles, oml, N=20, faithful_convex=False)
+    hs = np.array([np.concatenate([p, n.reshape(3)]) for p, n in oml])
+    par = nlp.WholeBodyParams()
+    obs = np.array([[2.5, 3.0, 0.6], [2.5, 1.0, 0.6], [4.4, 5, 0.1]])
+    for x_start, target in ((np.zeros(9), np.array([5, 5, -np.pi, 0, 0, 0, 0, 0, 0.0])),
+                            (np.array([1.9, 2.0, 0.0, 0.3, 0, 0, 0.3, -1.2, 1.6]), np.array([3.2, 2.0, 0, 0, 0, 0, 0.3, -1.2, 1.6]))):
+        ctrl.reset()
+        traj = np.linspace(x_start, target, 51)[:21]
+        u0 = ctrl.solve(x_start.copy(), traj, np.zeros((20, 5)))
+        o = coracle.solve_batch(par, x_start[None], traj[None], np.zeros((1, 20, 5)), np.zeros((1, 20, 5)), obs[None], hs=hs)
+        assert o["status"][0] == 0
+        assert np.abs(u0 - o["U"][0, 0]).max() < TOL and np.abs(ctrl.x_guess - o["X"][0]).max() < TOL
+
+
 def test_full_size_properties(mm):
     """BASELINE batch (8192): every instance converges to scaled KKT <= 1e-8, the solve is deterministic,
     dynamics are satisfied by the returned trajectory, bounds hold, and a permutation of the batch
