@@ -43,7 +43,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=8192, help="GLOBAL batch (BASELINE metric: 8192)")
+    ap.add_argument("--batch", type=int, default=8192, help="batch of the BASELINE metric (8192)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): every rank solves `--batch` instances (global = batch x N), no data-path collective "
+                         "needed by the solve itself; strong: the global batch stays `--batch` (BASELINE config C4 read literally)")
     ap.add_argument("--horizon", type=int, default=20)
     ap.add_argument("--obstacles", type=int, default=5)
     ap.add_argument("--cpu-sample", type=int, default=8192, help="instances timed on the host cores (rank 0, N=1)")
@@ -74,38 +77,48 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
-    N, M, Bg = args.horizon, args.obstacles, args.batch
+    N, M = args.horizon, args.obstacles
+    Bg = args.batch * (world if args.scaling == "weak" else 1)       # global number of instances
     nx, nu = 9, 5
-    lo = rank * Bg // world
-    hi = (rank + 1) * Bg // world
+    from mmpc_amd import sharding
+    lo, hi = sharding.shard_bounds(Bg, world, rank)
     Bl = hi - lo
-    # identical seeded inputs on every rank; each rank keeps its contiguous slice
-    d = synth.make_batch(Bg, N=N, M=M)
+    if args.scaling == "weak":
+        # every rank generates its own seeded batch (rank 0 = the N=1 workload); instance b of rank r is global b + r*batch
+        d = synth.make_batch(args.batch, N=N, M=M, config_id=3 + 1000 * rank)
+        sl = slice(0, Bl)
+    else:
+        # identical seeded inputs on every rank; each rank keeps its contiguous slice
+        d = synth.make_batch(Bg, N=N, M=M)
+        sl = slice(lo, hi)
     robot = mm.MobileManipulator(0.1)
     ctrl = mm.MPCWholeBody(robot, [], [], N=N, max_batch=Bl, device=local_rank, n_obstacles=M)
     eng = ctrl._engine
-    t = lambda a: torch.from_numpy(np.ascontiguousarray(a[lo:hi])).to(dev)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a[sl])).to(dev)
     x_init = t(np.clip(d["x_init"], ctrl.xlim[0], ctrl.xlim[1]))
     traj, uref, obs = t(d["traj_ref"]), t(d["u_ref"]), t(d["obs"])
     ulast = torch.zeros((Bl, N, nu), dtype=torch.float64, device=dev)   # cold start: u_latest = 0 (:298-299)
     out = eng.solve_batch_device(x_init, traj, uref, ulast, obs)
-    from mmpc_amd import sharding
-    assert (lo, hi) == sharding.shard_bounds(Bg, world, rank)
-    gathered = packed = None
+    packed = gathered = None
     if world > 1:
         rec = sharding.record_len(N, nx, nu)
         packed = torch.empty((Bl, rec), dtype=torch.float64, device=dev)
         gathered = torch.empty((Bg, rec), dtype=torch.float64, device=dev)
 
-    def step():
+    def gather(i):
+        # the one collective of the path: all-gather of the solved (X,U,s) over xGMI (RCCL), inside the timed region
+        sharding.pack_solution(out["X"], out["U"], out["s"], out=packed)
+        sharding.allgather_solutions(packed, Bg, dist, gathered=gathered)
+
+    def drain():
+        pass
+
+    for i in range(args.warmup):
         eng.solve_batch_device(x_init, traj, uref, ulast, obs, out=out)
         if world > 1:
-            # the one collective of the path: all-gather of the solved (X,U,s) over xGMI (RCCL)
-            sharding.pack_solution(out["X"], out["U"], out["s"], out=packed)
-            sharding.allgather_solutions(packed, Bg, dist, gathered=gathered)
-
-    for _ in range(args.warmup):
-        step()
+            gather(i)
+    if world > 1:
+        drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -113,15 +126,16 @@ def main():
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     kernel_ms = 0.0
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
         ev0.record()
         eng.solve_batch_device(x_init, traj, uref, ulast, obs, out=out)
         ev1.record()
         if world > 1:
-            sharding.pack_solution(out["X"], out["U"], out["s"], out=packed)
-            sharding.allgather_solutions(packed, Bg, dist, gathered=gathered)
+            gather(i)
         ev1.synchronize()
         kernel_ms += ev0.elapsed_time(ev1)
+    if world > 1:
+        drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -159,12 +173,13 @@ def main():
             # separately with the same command and committed under profiles/ (bench.py cannot run the profiler itself)
             traffic = json.load(open(tpath))["traffic_bytes_per_launch"]
         res = {
-            "metric": "MPC solves/sec, whole-body N=%d batch=%d" % (N, Bg),
+            "metric": "MPC solves/sec, whole-body N=%d batch=%d" % (N, args.batch),
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "whole-body MPC solve, N=%d, M=%d static circle obstacles, global batch %d, "
-                                   "cold start (u_latest=0), seeded synthetic (x_init, traj_ref, obstacles)" % (N, M, Bg),
+            "config": {"workload": "whole-body MPC solve, N=%d, M=%d static circle obstacles, batch %d per GPU%s (global %d), "
+                                   "cold start (u_latest=0), seeded synthetic (x_init, traj_ref, obstacles)"
+                                   % (N, M, Bl, "" if args.scaling == "weak" else " [strong: global batch fixed]", Bg),
                        "batch_per_gpu": Bl, "parallelism": "batch-sharded x%d%s" % (world, " + all-gather(X,U,s)" if world > 1 else "")},
             "solver": {"converged_frac": n_conv / Bg, "mean_iters": mean_iters, "max_iters": it_max,
                        "max_scaled_kkt": err_max, "lds_bytes_per_problem": eng.lds_bytes},
@@ -178,7 +193,7 @@ def main():
             from oracle import coracle, nlp
             avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
             cores = min(avail, 16)          # the GPU box gives one GPU a 16-core CPU share
-            ns = min(args.cpu_sample, Bg)
+            ns = min(args.cpu_sample, Bl)
             par = nlp.WholeBodyParams(N=N)
             xi = np.clip(d["x_init"][:ns], par.xlim[0], par.xlim[1])
             coracle.lib()

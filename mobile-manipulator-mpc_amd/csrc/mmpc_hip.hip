@@ -44,8 +44,9 @@ __global__ __launch_bounds__(MMPC_WAVE) void mmpc_solve_kernel(
     mmpc_solve_one<KIND>(P, io, lds);
 }
 
-template <int KIND, int N, int MC>
-__global__ __launch_bounds__(MMPC_WAVE) void mmpc_fast_kernel(
+// WPE = waves per SIMD the register allocation is sized for (2: <= 256 registers, only pays when LDS allows >4 problems/CU)
+template <int KIND, int N, int MC, int WPE>
+__global__ __launch_bounds__(MMPC_WAVE, WPE) void mmpc_fast_kernel(
     const MmpcParams *__restrict__ Pp, int B, const double *__restrict__ x_init, const double *__restrict__ traj_ref,
     const double *__restrict__ u_ref, const double *__restrict__ u_last, const double *__restrict__ x_guess,
     const double *__restrict__ obs, double *__restrict__ X, double *__restrict__ U, double *__restrict__ s,
@@ -78,7 +79,8 @@ __global__ __launch_bounds__(MMPC_WAVE) void mmpc_fast_kernel(
 
 // (kind, N, M) triples with a specialised kernel; everything else runs the generic kernel.
 // BASELINE configs C3/C4 (0,20,5), C5 (0,30,8), C2 (1,15,3); the reference demo (0,20,3).
-#define MMPC_FAST_LIST(X) X(0, 20, 5) X(0, 30, 8) X(0, 20, 3) X(1, 15, 3)
+// The base-only kernel needs 16 KB of LDS per problem (9 problems/CU): it is built for 2 waves/SIMD (+21 % measured).
+#define MMPC_FAST_LIST(X) X(0, 20, 5, 1) X(0, 30, 8, 1) X(0, 20, 3, 1) X(1, 15, 3, 2)
 
 // Longest-processing-time-first order for the NEXT launch: instances sorted by descending iteration count of
 // this one (counting sort, 256 bins, one workgroup).  Kernel time is bounded by the slowest instance; starting
@@ -205,11 +207,11 @@ extern "C" int mmpc_create(const mmpc_config *cfg, mmpc_handle *out) {
         HIPCHK(h, hipFuncSetAttribute((const void *)mmpc_solve_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes));
     h->fast = 0; h->fast_lds_bytes = 0;
     {
-#define MMPC_X(K, NN, MM)                                                                                            \
+#define MMPC_X(K, NN, MM, WW)                                                                                        \
         if (cfg->kind == K && cfg->N == NN && cfg->M == MM && cfg->L == 0) {                                                                       \
             h->fast = 1;                                                                                               \
             h->fast_lds_bytes = mmpc_fast_layout<K, NN>(MM, p.obs_per_stage).total * (int)sizeof(double);         \
-            HIPCHK(h, hipFuncSetAttribute((const void *)mmpc_fast_kernel<K, NN, MM>, hipFuncAttributeMaxDynamicSharedMemorySize, h->fast_lds_bytes)); \
+            HIPCHK(h, hipFuncSetAttribute((const void *)mmpc_fast_kernel<K, NN, MM, WW>, hipFuncAttributeMaxDynamicSharedMemorySize, h->fast_lds_bytes)); \
         }
         MMPC_FAST_LIST(MMPC_X)
 #undef MMPC_X
@@ -292,9 +294,9 @@ static int launch(mmpc_handle h, int B, const double *x_init, const double *traj
     const bool use_fast = h->fast && h->diag && !h->hp.terminal_xy_eq && !getenv("MMPC_FORCE_GENERIC");
     const int *order = (h->order_B == B && B <= h->cfg.max_batch && !getenv("MMPC_NO_LPT")) ? h->d_order : nullptr;
     if (use_fast) {
-#define MMPC_X(K, NN, MM)                                                                                              \
+#define MMPC_X(K, NN, MM, WW)                                                                                          \
         if (h->cfg.kind == K && h->cfg.N == NN && h->cfg.M == MM)                                                                          \
-            hipLaunchKernelGGL((mmpc_fast_kernel<K, NN, MM>), dim3(B), dim3(MMPC_WAVE), h->fast_lds_bytes, st, h->dp, B, x_init, traj, \
+            hipLaunchKernelGGL((mmpc_fast_kernel<K, NN, MM, WW>), dim3(B), dim3(MMPC_WAVE), h->fast_lds_bytes, st, h->dp, B, x_init, traj, \
                                uref, ulast, xguess, obs, X, U, s, status, iters, cost, err, order);
         MMPC_FAST_LIST(MMPC_X)
 #undef MMPC_X

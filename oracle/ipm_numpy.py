@@ -47,6 +47,7 @@ class Options:
     nu_lam = 0.0
     filter = True
     inertia = False
+    slack_reset = False
     delta0 = 1e-4
     delta_min = 1e-20
     delta_max = 1e10
@@ -209,6 +210,12 @@ def solve(prob: nlp.Problem, U0=None, X0=None, opt: Options = None, verbose=Fals
         if p.terminal_xy_equality:
             rdx[N][:2] += nu_eq
             ceq = X[N, :2] - prob.traj_ref[N, :2]
+        if opt.slack_reset:
+            # slack reset: a row that is more satisfied than its slack says (-h > t) gets t := -h; this removes that
+            # row's infeasibility for free and moves the slack away from the boundary (cf. Nocedal & Wright 19.3)
+            for k in range(N + 1):
+                hv = np.array([e[0] for e in ev[k]])
+                t[k] = np.maximum(t[k], -hv)
         rh = [np.array([e[0] for e in ev[k]]) + t[k] for k in range(N + 1)]
         err_d = max(np.abs(rdx).max(), np.abs(rdu).max(), np.abs(rds).max())
         err_p = max(np.abs(c).max() if N else 0.0, max(np.abs(r).max() for r in rh), np.abs(ceq).max())
@@ -387,6 +394,15 @@ def solve(prob: nlp.Problem, U0=None, X0=None, opt: Options = None, verbose=Fals
             neg = dz[k] < 0
             if neg.any():
                 ad = min(ad, (-tau * z[k][neg] / dz[k][neg]).min())
+        if getattr(opt, "debug_block", False):
+            best = (2.0, None)
+            for k in range(N + 1):
+                for i in range(len(rows[k])):
+                    if dt[k][i] < 0:
+                        a = -tau * t[k][i] / dt[k][i]
+                        if a < best[0]:
+                            best = (a, (k, rows[k][i][0], rows[k][i][1], t[k][i], z[k][i], dt[k][i], ev[k][i][0]))
+            print("      block:", best)
         # ---------------- line search -------------------------------------
         phi0, th0 = _merit_parts(prob, rows, X, U, s, t, mu)
         dphi = (gX * dX).sum() + (gU * dU).sum() + gs @ ds
