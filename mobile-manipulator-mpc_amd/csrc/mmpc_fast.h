@@ -26,6 +26,18 @@
 #define MMPC_WR(i) wr_one[i]
 #endif
 
+// Diagnostic build only (-DMMPC_STAMP): per-phase wave-cycle accounting, accumulated in registers and added to a
+// __device__ array at the end (read by tools/probe_stamps.py).  The shipped kernel contains no stamps.
+#if defined(MMPC_STAMP) && !defined(MMPC_EMU)
+__device__ unsigned long long mmpc_stamp_acc[16];
+#define MMPC_T0() unsigned long long t_prev_ = __builtin_readcyclecounter(), t_now_, t_acc_[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define MMPC_TS(i) { t_now_ = __builtin_readcyclecounter(); t_acc_[i] += t_now_ - t_prev_; t_prev_ = t_now_; }
+#define MMPC_TEND() { if (threadIdx.x == 0) for (int i_ = 0; i_ < 14; i_++) atomicAdd(&mmpc_stamp_acc[i_], t_acc_[i_]); }
+#else
+#define MMPC_T0()
+#define MMPC_TS(i)
+#define MMPC_TEND()
+#endif
 #define MMPC_MC_MAX 8    // largest number of circle rows the register-resident path is instantiated for
 
 // ---- light-weight fp64 math for the fast path -------------------------------------------------
@@ -412,8 +424,10 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
     int status = 1, it = 0, nfilt = 0, filt_init = 0;
     double E0 = 0.0, th_max = 0.0, th_min = 0.0;
 
+    MMPC_T0()
 #pragma unroll 1
     for (it = 0; it <= P.max_iter; it++) {
+        MMPC_TS(0)
         // ============================================================ E1 (stage lanes)
         LANES_BEGIN
         auto &ls = MMPC_LS;
@@ -516,6 +530,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
         if (lane == 0) MISC[0] = 0.0;
         if (NSELF == 0 && lane == 0) { for (int a = 0; a < 10; a++) SN[a] = 0.0; }
         LANES_END
+        MMPC_TS(1)
         // ============================================================ E1 (pair lanes) + s residual
         LANES_BEGIN
         auto &ls = MMPC_LS;
@@ -581,6 +596,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
         }
         const double phi0 = cost0 - mu * sumlog;   // barrier objective at the current point for the (possibly new) mu
 
+        MMPC_TS(2)
         // ============================================================ Newton direction
         int failed = 0;
 #pragma unroll 1
@@ -711,6 +727,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                 for (int c = 0; c < NU; c++) HUUD[k * NU + c] = 0.0;
             }
             LANES_END
+            MMPC_TS(3)
             // ---- A1 (pair lanes): barrier terms of the box rows (diagonal entries, unique owners)
             LANES_BEGIN
             auto &ls = MMPC_LS;
@@ -734,6 +751,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                 }
             }
             LANES_END
+            MMPC_TS(4)
             // ---- R0: full copy of P_N
             LANES_BEGIN
             for (int e = lane; e < NX * NX; e += MMPC_WAVE) {
@@ -773,6 +791,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                     }
                 }
                 LANES_END
+                MMPC_TS(5)
                 // R2: [F G^T; G Hh] = [A B]^T T + stage Hessian, [gx; gu] = q + [A B]^T pc
                 LANES_BEGIN
                 auto &ls = MMPC_LS;
@@ -794,6 +813,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                     }
                 }
                 LANES_END
+                MMPC_TS(6)
                 // R3/R4: Cholesky of Hh in registers (every solving lane), one right-hand side per lane
                 LANES_BEGIN
                 if (lane <= NX) {
@@ -844,6 +864,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                 }
                 LANES_END
                 if (MISC[0] != 0.0) { failed = 1; break; }
+                MMPC_TS(7)
                 // R5: P_k = F + G^T K,  p_k = gx + G^T kf
                 LANES_BEGIN
                 auto &ls = MMPC_LS;
@@ -871,6 +892,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
             LANES_END
         }
         if (failed) { status = 2; break; }
+        MMPC_TS(8)
         // ---- forward roll-out, one phase per stage: lane i < NX computes dx_{k+1}[i]; the lanes whose
         //      dynamics row carries an input also produce that input step (base.py:19-26)
         LANES_BEGIN
@@ -909,6 +931,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
             }
             LANES_END
         }
+        MMPC_TS(9)
         // ---- D1: multiplier step and slack-variable step (stage lanes)
         LANES_BEGIN
         auto &ls = MMPC_LS;
@@ -934,6 +957,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
             if (k == N) { for (int c = 0; c < NU; c++) DXU[N * NV + NX + c] = 0.0; }
         }
         LANES_END
+        MMPC_TS(10)
         // ---- D2: row steps, fraction-to-boundary, directional derivative
         const double tau = mmpc_max(0.99, 1.0 - mu);
         LANES_BEGIN
@@ -1012,6 +1036,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
         LANES_END
         const double ap = MMPC_RED_MIN(0), ad = MMPC_RED_MIN(1), dphi = MMPC_RED_SUM(2);
 
+        MMPC_TS(11)
         // ---- merit of a trial point w + alpha dw (stage lanes + pair lanes in one phase)
         auto merit_pass = [&](double alpha, double &phi_out, double &th_out) {
             LANES_BEGIN
@@ -1125,6 +1150,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
             if (lspass == 0 && nfilt > 0) { nfilt = 0; lspass = 1; lsi = 0; alpha = ap; continue; }   // filter reset heuristic
             break;
         }
+        MMPC_TS(12)
         // ---- update
         LANES_BEGIN
         auto &ls = MMPC_LS;
@@ -1169,6 +1195,8 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
         LANES_END
     }
 
+    MMPC_TS(13)
+    MMPC_TEND()
     // ------------------------------------------------------------------ results
     LANES_BEGIN
     double f = 0.0;

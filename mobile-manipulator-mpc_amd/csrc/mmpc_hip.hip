@@ -164,6 +164,15 @@ static int upload_params(mmpc_handle h) {
     return MMPC_OK;
 }
 
+#ifdef MMPC_STAMP
+// diagnostic build only: read and clear the per-phase cycle accumulators (not part of include/mmpc.h)
+extern "C" int mmpc_debug_read_stamps(unsigned long long *out16) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(mmpc_stamp_acc), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(mmpc_stamp_acc), z, sizeof(z)) != hipSuccess) return -1;
+    return 0;
+}
+#endif
 extern "C" const char *mmpc_version(void) { return "mmpc 0.1 (gfx950)"; }
 extern "C" const char *mmpc_last_error(mmpc_handle h) { return h ? h->err : "null handle"; }
 extern "C" int mmpc_lds_bytes(mmpc_handle h) { return h ? ((h->fast && h->diag && !h->hp.terminal_xy_eq) ? h->fast_lds_bytes : h->lds_bytes) : MMPC_E_ARG; }
