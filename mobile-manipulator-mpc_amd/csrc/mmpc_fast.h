@@ -66,6 +66,7 @@ MMPC_DEV void mmpc_sincos(double x, double *sn, double *cs) {
 #ifdef MMPC_EMU
 MMPC_DEV double mmpc_rcp(double x) { return 1.0 / x; }
 MMPC_DEV double mmpc_rsqrt(double x) { return 1.0 / sqrt(x); }
+MMPC_DEV double mmpc_rcp3(double x) { return 1.0 / x; }
 MMPC_DEV double mmpc_powf(double x, float e) { return (double)exp2f(e * log2f((float)x)); }
 MMPC_DEV void mmpc_sched_fence() {}
 #else
@@ -74,6 +75,11 @@ MMPC_DEV double mmpc_rcp(double x) {
     double r = __builtin_amdgcn_rcp(x);
     r = fma(fma(-x, r, 1.0), r, r);
     return fma(fma(-x, r, 1.0), r, r);
+}
+// one cubic step r0 (1 + e + e^2), e = 1 - x r0: full precision from the ~2^-23 seed with a shorter dependent chain
+MMPC_DEV double mmpc_rcp3(double x) {
+    const double r = __builtin_amdgcn_rcp(x), e = fma(-x, r, 1.0);
+    return fma(fma(e, e, e), r, r);
 }
 MMPC_DEV double mmpc_rsqrt(double x) {
     double y = __builtin_amdgcn_rsq(x);
@@ -124,17 +130,41 @@ struct MmpcFastDims {
     static constexpr int NS = N + 1;
     static constexpr int NPAIR = NS * NV;
     static constexpr int NPASS = (NPAIR + MMPC_WAVE - 1) / MMPC_WAVE;
-    static constexpr int NTC = 4 + NU;                              // columns of [A B] that are not unit vectors: 2..5 and the inputs
-    static constexpr int TW = NTC + 1;                              // row of T_ext: those columns of P[A B], then pc = p + P c
-    static constexpr int R1E = NX * TW;
-    static constexpr int R1P = (R1E + MMPC_WAVE - 1) / MMPC_WAVE;
-    static constexpr int R2E = NXX + NU * NX + NUU + NV;            // F | G | Hh | g
-    static constexpr int R2P = (R2E + MMPC_WAVE - 1) / MMPC_WAVE;
+    // Riccati recursion on 16x16 MFMA tiles: K-blocks (4 rows each) that cover the state rows / the input rows,
+    // accumulator registers that hold the input rows NX..NV-1 of the stage matrix
+    static constexpr int NKB = (NX + 3) / 4, NGB = (NU + 3) / 4, GR0 = NX / 4, GR1 = (NV - 1) / 4;
+    static_assert(NV + 1 <= 16, "stage matrix [x u | gradient] must fit one 16x16 tile");
 };
+
+// ---- v_mfma_f64_16x16x4_f64: D = A B + C on one wavefront.  Lane l supplies A[l&15][l>>4] and B[l>>4][l&15] and holds
+// rows (l>>4) + 4r of column l&15 of C/D in accumulator register r (tools/mfma_probe.hip checks this map on the device).
+// An accumulator's register r is therefore K-block r (rows 4r..4r+3) of a B operand as it stands, and - for a
+// symmetric matrix - of an A operand: chained products need no lane movement.
+#ifdef MMPC_EMU
+struct MmpcAcc {
+    double v[4];
+    double &operator[](int i) { return v[i]; }
+    const double &operator[](int i) const { return v[i]; }
+};
+#define MMPC_MFMA(ACC, AEXPR, BEXPR) {                                                                                  \
+    double a_[MMPC_WAVE], b_[MMPC_WAVE];                                                                               \
+    for (int lane = 0; lane < MMPC_WAVE; lane++) { auto &ls = ls_all[lane]; a_[lane] = (AEXPR); b_[lane] = (BEXPR); }   \
+    for (int lane = 0; lane < MMPC_WAVE; lane++) {                                                                     \
+        auto &ls = ls_all[lane];                                                                                       \
+        for (int r_ = 0; r_ < 4; r_++) {                                                                               \
+            double s_ = ls.ACC[r_];                                                                                    \
+            for (int k_ = 0; k_ < 4; k_++) s_ = fma(a_[16 * k_ + (lane >> 4) + 4 * r_], b_[16 * k_ + (lane & 15)], s_); \
+            ls.ACC[r_] = s_;                                                                                           \
+        }                                                                                                              \
+    } }
+#else
+typedef double MmpcAcc __attribute__((ext_vector_type(4)));
+#define MMPC_MFMA(ACC, AEXPR, BEXPR) { auto &ls = ls_one; ls.ACC = __builtin_amdgcn_mfma_f64_16x16x4f64((AEXPR), (BEXPR), ls.ACC, 0, 0, 0); }
+#endif
 
 struct MmpcFastLayout {
     int XU, S, LAM, XUREF, ULAST, OBS, CST, CV, CD, TRG, HXX, QXU, HUXL, HUUL, HUX02, HUUD, SN, KK, KF, DXU, DS, DLAM,
-        PF, TT, MM, FILT, MISC, total;
+        GS, FILT, MISC, total;
 };
 // constants block (CST) offsets
 #define MMPC_C_XLIM 0      // [2][9]
@@ -159,8 +189,7 @@ MMPC_HD MmpcFastLayout mmpc_fast_layout(int M, int obs_per_stage) {
     MMPC_CARVE(HXX, F::NS * F::NXX) MMPC_CARVE(QXU, F::NS * F::NV) MMPC_CARVE(HUXL, F::NU * F::NX)
     MMPC_CARVE(HUUL, F::NUU) MMPC_CARVE(HUX02, F::NS) MMPC_CARVE(HUUD, F::NS * F::NU) MMPC_CARVE(SN, 16)
     MMPC_CARVE(KK, N * F::NU * F::NX) MMPC_CARVE(KF, N * F::NU) MMPC_CARVE(DXU, F::NS * F::NV) MMPC_CARVE(DS, F::NS)
-    MMPC_CARVE(DLAM, F::NS * F::NX) MMPC_CARVE(PF, F::NX * F::NX + F::NX * F::TW) L.TT = L.PF + F::NX * F::NX;
-    MMPC_CARVE(MM, F::R2E) MMPC_CARVE(FILT, 2 * MMPC_FCAP) MMPC_CARVE(MISC, 8)
+    MMPC_CARVE(DLAM, F::NS * F::NX) MMPC_CARVE(GS, 256) MMPC_CARVE(FILT, 2 * MMPC_FCAP) MMPC_CARVE(MISC, 8)
 #undef MMPC_CARVE
     L.total = o;
     return L;
@@ -177,12 +206,14 @@ struct MmpcLaneState {
     double st[4], sz[4], sdt[4];
     // s_k elimination data of stage `lane`
     double hss, gss, vx[6];
-    // Riccati index tables
-    // Riccati index tables, four 8-bit fields per word (MMPC_B extracts field q)
-    unsigned r1_p[F::R1P], r1_c[F::R1P];             // PF offset, CV id
-    unsigned r2_t[F::R2P], r2_c[F::R2P];             // TT offset, CV id
-    unsigned r2_k[F::R2P];                           // kind | a<<8 | b<<16
-    unsigned r5_ij;                                  // i | j<<8
+    // Riccati recursion on MFMA tiles (lane = 16 g + j; accumulator register r <-> row g + 4 r, column j)
+    unsigned ab_o[F::NKB];                           // [A B | c] operand rows 4r+g, column j: LDS offset | stage stride << 16
+    unsigned h_o[4], h_l[4];                         // stage-matrix entry of register r: LDS offset | stage stride << 16; offset of its
+                                                     // stage-(N-1) extra term (Q1 elimination of s_{N-1}) or of the constant 0
+    unsigned h_m;                                    // bit r: register r is part of [P | p]; bit 4+r: ... and is stored (lower triangle, p)
+    MmpcAcc rP, rT, rM;                              // cost-to-go [P | p], T = P [A B | c], stage matrix M
+    double rAB[F::NKB], opa[F::NGB], opb[F::NGB];    // MFMA operands
+    double nab[F::NKB], nhm[4];                      // next stage's [A B | c] rows and stage-matrix entries (loaded one stage ahead)
     unsigned f_c, f_v, f_x;                          // forward roll-out row of [A B]: 4 terms + (5th col | 5th cv<<8 | (a+1)<<16)
 };
 
@@ -238,17 +269,14 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
     typedef MmpcFastDims<KIND, N> F;
     typedef MmpcTab<KIND> TB;
     constexpr int NX = F::NX, NU = F::NU, NV = F::NV, NXX = F::NXX, NUU = F::NUU, NSELF = F::NSELF, NS = F::NS;
-    constexpr int NPASS = F::NPASS, NPAIR = F::NPAIR, R1E = F::R1E, R1P = F::R1P, R2E = F::R2E, R2P = F::R2P;
-    constexpr int TW = F::TW, NTC = F::NTC;
+    constexpr int NPASS = F::NPASS, NPAIR = F::NPAIR, NKB = F::NKB, NGB = F::NGB, GR0 = F::GR0, GR1 = F::GR1;
     constexpr int M = MC;   // number of circle obstacles is a template parameter on this path
     const MmpcFastLayout L = mmpc_fast_layout<KIND, N>(M, P.obs_per_stage);
     double *XU = lds + L.XU, *S = lds + L.S, *LAM = lds + L.LAM, *XUREF = lds + L.XUREF, *ULAST = lds + L.ULAST,
            *OBS = lds + L.OBS, *CST = lds + L.CST, *CV = lds + L.CV, *CD = lds + L.CD, *TRG = lds + L.TRG, *HXX = lds + L.HXX,
            *QXU = lds + L.QXU, *HUXL = lds + L.HUXL, *HUUL = lds + L.HUUL, *HUX02 = lds + L.HUX02,
            *HUUD = lds + L.HUUD, *SN = lds + L.SN, *KK = lds + L.KK, *KF = lds + L.KF, *DXU = lds + L.DXU,
-           *DS = lds + L.DS, *DLAM = lds + L.DLAM, *PF = lds + L.PF, *TT = lds + L.TT, *MM = lds + L.MM,
-           *FILT = lds + L.FILT, *MISC = lds + L.MISC;
-    double *const MF = MM, *const MG = MM + NXX, *const MH = MM + NXX + NU * NX, *const MGV = MM + NXX + NU * NX + NUU;
+           *DS = lds + L.DS, *DLAM = lds + L.DLAM, *GS = lds + L.GS, *FILT = lds + L.FILT, *MISC = lds + L.MISC;
     double *const RB = DXU;   // residual base r[k][v] (alias: dead while DXU is not)
     const double dt = P.dt, Sw = P.S, tol = P.tol;
 #ifdef MMPC_EMU
@@ -297,41 +325,45 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
     // Riccati index tables (once)
     {
         auto &ls = MMPC_LS;
-        // column j of [A B] -> compact T column (or -1 when the column is a unit vector e_j)
-        auto tcol = [&](int j) -> int { return (j >= 2 && j <= 5) ? j - 2 : (j >= NX ? 4 + j - NX : -1); };
-        // offset of T_ext[r][col] relative to PF: plain columns come straight from P
-        auto text = [&](int r, int col) -> unsigned {
-            if (col == NV) return (unsigned)(NX * NX + r * TW + NTC);
-            const int c = tcol(col);
-            return c < 0 ? (unsigned)(r * NX + col) : (unsigned)(NX * NX + r * TW + c);
-        };
+        const int g = lane >> 4, j = lane & 15;
 #pragma unroll
-        for (int p = 0; p < R1P; p++) {
-            const int e = lane + MMPC_WAVE * p;
-            unsigned po = 0, co = 0;
-            if (e < R1E) {
-                const int i = e / TW, c = e % TW;
-                if (c < NTC) {
-                    const int j = c < 4 ? c + 2 : NX + c - 4;
-                    for (int q = 0; q < 4; q++) { po |= (unsigned)(i * NX + TB::crow(j, q)) << (8 * q); co |= (unsigned)TB::ccv(j, q) << (8 * q); }
-                } else { po = (unsigned)i; co = 0xffffffffu; }   // pc row i
-            }
-            ls.r1_p[p] = po; ls.r1_c[p] = co;
+        for (int r = 0; r < NKB; r++) {
+            // operand entry [A B | c][m][j], m = 4r+g: a coefficient of CV[k] (ids 0,1,2 are the constants 0,1,dt),
+            // the defect c_k[m] in column NV, or the constant 0 (stride 0) outside the matrix
+            const int m = 4 * r + g;
+            unsigned off = (unsigned)L.CV, stride = 0;
+            if (m < NX && j < NV) {
+                int id = 0;
+                for (int q = 0; q < 4; q++) if (TB::crow(j, q) == m && TB::ccv(j, q) != 0) id = TB::ccv(j, q);
+                off = (unsigned)(L.CV + id); stride = id >= 3 ? MMPC_NCV : 0;
+            } else if (m < NX && j == NV) { off = (unsigned)(L.CD + m); stride = NX; }
+            ls.ab_o[r] = off | (stride << 16);
         }
+        ls.h_m = 0u;
 #pragma unroll
-        for (int p = 0; p < R2P; p++) {
-            const int e = lane + MMPC_WAVE * p;
-            unsigned to = 0, co = 0, kk = 255u;
-            if (e < R2E) {
-                int row, col, kind, a = 0, b = 0;   // out = sum_q cv(row,q) * T_ext[crow(row,q)][col]
-                if (e < NXX) { kind = 0; row = kTriI[e]; col = kTriJ[e]; }
-                else if (e < NXX + NU * NX) { kind = 1; const int e2 = e - NXX; a = e2 / NX; b = e2 % NX; row = NX + a; col = b; }
-                else if (e < NXX + NU * NX + NUU) { kind = 2; const int e2 = e - NXX - NU * NX; a = kTriI[e2]; b = kTriJ[e2]; row = NX + a; col = NX + b; }
-                else { kind = 3; a = e - NXX - NU * NX - NUU; row = a; col = NV; }
-                for (int q = 0; q < 4; q++) { to |= text(TB::crow(row, q), col) << (8 * q); co |= (unsigned)TB::ccv(row, q) << (8 * q); }
-                kk = (unsigned)kind | ((unsigned)a << 8) | ((unsigned)b << 16);
+        for (int r = 0; r < 4; r++) {
+            // stage matrix [Hxx Hxu q_x; Hux Huu q_u] entry (i, j), i = g+4r, as one LDS word per stage (offset + k*stride):
+            // Hxx: packed HXX[k];  Hux: only (0,2) is non-zero (HUX02[k]);  Huu: constant R2+W2 off the diagonal, HUUD[k] on it;
+            // column NV: gradient QXU[k].  Stage N-1 adds the dense rank-one blocks HUXL / HUUL.
+            const int i = g + 4 * r;
+            unsigned off = (unsigned)L.CV, stride = 0, last = (unsigned)L.CV;
+            if (i < NX && j < NX) {
+                off = (unsigned)(L.HXX + (i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i)); stride = NXX;
+                ls.h_m |= (1u << r) | (i >= j ? (16u << r) : 0u);
+            } else if (i >= NX && i < NV && j < NX) {
+                if (i == NX && j == 2) { off = (unsigned)L.HUX02; stride = 1; }
+                last = (unsigned)(L.HUXL + (i - NX) * NX + j);
+            } else if (i >= NX && i < NV && j >= NX && j < NV) {
+                const int a = i - NX, b = j - NX;
+                if (a == b) { off = (unsigned)(L.HUUD + a); stride = NU; }
+                else off = (unsigned)(L.CST + MMPC_C_RW2 + a * NU + b);
+                last = (unsigned)(L.HUUL + (a >= b ? a * (a + 1) / 2 + b : b * (b + 1) / 2 + a));
+            } else if (i < NV && j == NV) {
+                off = (unsigned)(L.QXU + i); stride = NV;
+                if (i < NX) ls.h_m |= (1u << r) | (16u << r);
             }
-            ls.r2_t[p] = to; ls.r2_c[p] = co; ls.r2_k[p] = kk;
+            ls.h_o[r] = off | (stride << 16);
+            ls.h_l[r] = last;
         }
         {
             unsigned fc = 0, fv = 0, fx = 0;
@@ -342,7 +374,6 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
             }
             ls.f_c = fc; ls.f_v = fv; ls.f_x = fx;
         }
-        ls.r5_ij = lane < NXX ? ((unsigned)kTriI[lane] | ((unsigned)kTriJ[lane] << 8)) : 0u;
     }
     LANES_END
 
@@ -724,7 +755,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                 for (int a = 0; a < 6; a++) ls.vx[a] = vx[a];
                 HUX02[k] = h02;
 #pragma unroll
-                for (int c = 0; c < NU; c++) HUUD[k * NU + c] = 0.0;
+                for (int c = 0; c < NU; c++) HUUD[k * NU + c] = CST[MMPC_C_RW2 + c * NU + c];
             }
             LANES_END
             MMPC_TS(3)
@@ -752,138 +783,135 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
             }
             LANES_END
             MMPC_TS(4)
-            // ---- R0: full copy of P_N
+            // ---- R0: terminal cost-to-go [P_N | p_N] = stage-N Hessian and gradient, in accumulator layout;
+            //      operands of stage N-1: rAB = [A B | c] rows 4r+g, rM = stage matrix (accumulator input), rT = [0 | p_N]
             LANES_BEGIN
-            for (int e = lane; e < NX * NX; e += MMPC_WAVE) {
-                const int i = e / NX, j = e % NX;
-                PF[e] = HXX[N * NXX + (i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i)];
+            auto &ls = MMPC_LS;
+            const bool gcol = (lane & 15) == NV;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const unsigned o = ls.h_o[r];
+                const double v = lds[(o & 0xffffu) + N * (int)(o >> 16)];
+                ls.rP[r] = ((ls.h_m >> r) & 1u) ? v : 0.0;
+                ls.rM[r] = lds[(o & 0xffffu) + (N - 1) * (int)(o >> 16)] + lds[ls.h_l[r]];
+                ls.rT[r] = (gcol && r < NKB) ? ls.rP[r] : 0.0;
             }
+#pragma unroll
+            for (int r = 0; r < NKB; r++) { const unsigned o = ls.ab_o[r]; ls.rAB[r] = lds[(o & 0xffffu) + (N - 1) * (int)(o >> 16)]; }
             LANES_END
 #pragma unroll 1
             for (int k = N - 1; k >= 0; k--) {
-                const double *cv = CV + k * MMPC_NCV;
-                // R1: T_ext = [ (P [A B])(:, non-unit columns) | p + P c ]   (loads first, then arithmetic)
-                LANES_BEGIN
-                auto &ls = MMPC_LS;
-#pragma unroll
-                for (int p = 0; p < R1P; p++) {
-                    const int e = lane + MMPC_WAVE * p;
-                    if (e < R1E) {
-                        const unsigned po = ls.r1_p[p], co = ls.r1_c[p];
-                        double v;
-                        if (co != 0xffffffffu) {
-                            const double p0 = PF[MMPC_B(po, 0)], p1 = PF[MMPC_B(po, 1)], p2 = PF[MMPC_B(po, 2)], p3 = PF[MMPC_B(po, 3)];
-                            const double c0 = cv[MMPC_B(co, 0)], c1 = cv[MMPC_B(co, 1)], c2 = cv[MMPC_B(co, 2)], c3 = cv[MMPC_B(co, 3)];
-                            mmpc_sched_fence();
-                            v = p0 * c0 + p1 * c1 + p2 * c2 + p3 * c3;
-                        } else {
-                            const int i = (int)po;
-                            double pr[NX], cd[NX];
-                            const double p0 = QXU[(k + 1) * NV + i];
-#pragma unroll
-                            for (int m = 0; m < NX; m++) { pr[m] = PF[i * NX + m]; cd[m] = CD[k * NX + m]; }
-                            mmpc_sched_fence();
-                            v = p0;
-#pragma unroll
-                            for (int m = 0; m < NX; m++) v += pr[m] * cd[m];
-                        }
-                        TT[e] = v;
-                    }
-                }
-                LANES_END
                 MMPC_TS(5)
-                // R2: [F G^T; G Hh] = [A B]^T T + stage Hessian, [gx; gu] = q + [A B]^T pc
+                // R1: T = P [A B | c] + [0 | p]   (P symmetric: its accumulator registers are the A operand)
+                MMPC_MFMA(rT, ls.rP[0], ls.rAB[0])
+                MMPC_MFMA(rT, ls.rP[1], ls.rAB[1])
+                if (NKB > 2) MMPC_MFMA(rT, ls.rP[NKB > 2 ? 2 : 0], ls.rAB[NKB > 2 ? 2 : 0])
+                // R2: M = [A B | c]^T T + stage matrix  ->  [F G^T gx; G Hh gu]
+                MMPC_MFMA(rM, ls.rAB[0], ls.rT[0])
+                MMPC_MFMA(rM, ls.rAB[1], ls.rT[1])
+                if (NKB > 2) MMPC_MFMA(rM, ls.rAB[NKB > 2 ? 2 : 0], ls.rT[NKB > 2 ? 2 : 0])
+                // the input rows [G Hh gu] go through LDS to the lanes that solve with them
                 LANES_BEGIN
                 auto &ls = MMPC_LS;
 #pragma unroll
-                for (int p = 0; p < R2P; p++) {
-                    const int e = lane + MMPC_WAVE * p;
-                    if (e < R2E) {
-                        const unsigned to = ls.r2_t[p], co = ls.r2_c[p], kk = ls.r2_k[p];
-                        const double t0 = PF[MMPC_B(to, 0)], t1 = PF[MMPC_B(to, 1)], t2 = PF[MMPC_B(to, 2)], t3 = PF[MMPC_B(to, 3)];
-                        const double c0 = cv[MMPC_B(co, 0)], c1 = cv[MMPC_B(co, 1)], c2 = cv[MMPC_B(co, 2)], c3 = cv[MMPC_B(co, 3)];
-                        const int kind = (int)MMPC_B(kk, 0), a = (int)MMPC_B(kk, 1), b = (int)MMPC_B(kk, 2);
-                        double base;
-                        if (kind == 0) base = HXX[k * NXX + e];
-                        else if (kind == 1) base = (k == N - 1 ? HUXL[e - NXX] : 0.0) + ((a == 0 && b == 2) ? HUX02[k] : 0.0);
-                        else if (kind == 2) base = CST[MMPC_C_RW2 + a * NU + b] + (a == b ? HUUD[k * NU + a] : 0.0) + (k == N - 1 ? HUUL[e - NXX - NU * NX] : 0.0);
-                        else base = QXU[k * NV + a];
-                        mmpc_sched_fence();
-                        MM[e] = base + c0 * t0 + c1 * t1 + c2 * t2 + c3 * t3;
-                    }
-                }
+                for (int r = GR0; r <= GR1; r++) GS[((lane >> 4) + 4 * r) * 16 + (lane & 15)] = ls.rM[r];
                 LANES_END
                 MMPC_TS(6)
-                // R3/R4: Cholesky of Hh in registers (every solving lane), one right-hand side per lane
+                // R3/R4: L D L^T of Hh in registers (every lane), one right-hand side per column j = lane & 15
                 LANES_BEGIN
-                if (lane <= NX) {
-                    double Hm[NUU], rhs[NU];
+                auto &ls = MMPC_LS;
+                {
+                    const int g = lane >> 4, j = lane & 15;
+                    double Hm[NUU], rhs[NU], gop[NGB];
 #pragma unroll
-                    for (int e = 0; e < NUU; e++) Hm[e] = MH[e];
+                    for (int a = 0; a < NU; a++) {
 #pragma unroll
-                    for (int a = 0; a < NU; a++) rhs[a] = lane < NX ? MG[a * NX + lane] : MGV[NX + a];
+                        for (int b = 0; b <= a; b++) Hm[a * (a + 1) / 2 + b] = GS[(NX + a) * 16 + NX + b];
+                        rhs[a] = GS[(NX + a) * 16 + j];
+                    }
+#pragma unroll
+                    for (int r = 0; r < NGB; r++) { const int a = 4 * r + g; gop[r] = GS[(NX + (a < NU ? a : 0)) * 16 + j]; }
+                    // operands of the next stage travel while this one factorises
+                    if (k > 0) {
+#pragma unroll
+                        for (int r = 0; r < NKB; r++) { const unsigned o = ls.ab_o[r]; ls.nab[r] = lds[(o & 0xffffu) + (k - 1) * (int)(o >> 16)]; }
+#pragma unroll
+                        for (int r = 0; r < 4; r++) { const unsigned o = ls.h_o[r]; ls.nhm[r] = lds[(o & 0xffffu) + (k - 1) * (int)(o >> 16)]; }
+                    }
                     mmpc_sched_fence();
-                    double Lc[NUU];   // lower factor, inverse pivots on the diagonal
+                    double Lm[NUU], V[NUU];   // unit lower factor (inverse pivots on its diagonal), V[i][q] = L[i][q] d_q
                     bool ok = true;
 #pragma unroll
-                    for (int j = 0; j < NU; j++) {
-                        double d = Hm[j * (j + 1) / 2 + j];
+                    for (int jj = 0; jj < NU; jj++) {
+                        double d = Hm[jj * (jj + 1) / 2 + jj];
 #pragma unroll
-                        for (int q = 0; q < j; q++) d -= Lc[j * (j + 1) / 2 + q] * Lc[j * (j + 1) / 2 + q];
-                        if (!(d > 0.0) || !mmpc_finite(d)) { ok = false; d = 1.0; }
-                        const double il = mmpc_rsqrt(d);
-                        Lc[j * (j + 1) / 2 + j] = il;
+                        for (int q = 0; q < jj; q++) d -= V[jj * (jj + 1) / 2 + q] * Lm[jj * (jj + 1) / 2 + q];
+                        ok = ok && d > 0.0;   // (NaN fails too; what a bad pivot produces is discarded by the caller)
+                        const double id = mmpc_rcp3(d);
+                        Lm[jj * (jj + 1) / 2 + jj] = id;
 #pragma unroll
-                        for (int i = j + 1; i < NU; i++) {
-                            double v = Hm[i * (i + 1) / 2 + j];
+                        for (int i = jj + 1; i < NU; i++) {
+                            double v = Hm[i * (i + 1) / 2 + jj];
 #pragma unroll
-                            for (int q = 0; q < j; q++) v -= Lc[i * (i + 1) / 2 + q] * Lc[j * (j + 1) / 2 + q];
-                            Lc[i * (i + 1) / 2 + j] = v * il;
+                            for (int q = 0; q < jj; q++) v -= V[i * (i + 1) / 2 + q] * Lm[jj * (jj + 1) / 2 + q];
+                            V[i * (i + 1) / 2 + jj] = v;
+                            Lm[i * (i + 1) / 2 + jj] = v * id;
                         }
                     }
 #pragma unroll
-                    for (int i = 0; i < NU; i++) {
-                        double v = rhs[i];
+                    for (int i = 1; i < NU; i++) {
 #pragma unroll
-                        for (int q = 0; q < i; q++) v -= Lc[i * (i + 1) / 2 + q] * rhs[q];
-                        rhs[i] = v * Lc[i * (i + 1) / 2 + i];
+                        for (int q = 0; q < i; q++) rhs[i] -= Lm[i * (i + 1) / 2 + q] * rhs[q];
                     }
 #pragma unroll
-                    for (int i = NU - 1; i >= 0; i--) {
-                        double v = rhs[i];
+                    for (int i = 0; i < NU; i++) rhs[i] *= Lm[i * (i + 1) / 2 + i];
 #pragma unroll
-                        for (int q = i + 1; q < NU; q++) v -= Lc[q * (q + 1) / 2 + i] * rhs[q];
-                        rhs[i] = v * Lc[i * (i + 1) / 2 + i];
-                    }
+                    for (int i = NU - 2; i >= 0; i--) {
 #pragma unroll
-                    for (int a = 0; a < NU; a++) {
-                        if (lane < NX) KK[(k * NU + a) * NX + lane] = -rhs[a];
-                        else KF[k * NU + a] = -rhs[a];
+                        for (int q = i + 1; q < NU; q++) rhs[i] -= Lm[q * (q + 1) / 2 + i] * rhs[q];
                     }
+                    // feedback gain column j (K = -Hh^-1 G; column NV: kf = -Hh^-1 gu)
+                    const bool kcol = j < NX || j == NV;
+                    if (g == 0 && kcol) {
+                        double *dst = j < NX ? KK + k * NU * NX + j : KF + k * NU;
+                        const int step = j < NX ? NX : 1;
+#pragma unroll
+                        for (int a = 0; a < NU; a++) dst[a * step] = -rhs[a];
+                    }
+                    // operands of P_k = F + G^T K: A[i][a] = G[a][i] (rows i < NX), B[a][j] = K[a][j], a = 4r+g
+#pragma unroll
+                    for (int r = 0; r < NGB; r++) {
+                        const int a = 4 * r + g;
+                        double kv = 0.0;
+#pragma unroll
+                        for (int aa = 0; aa < NU; aa++) if (aa == a) kv = -rhs[aa];
+                        ls.opa[r] = (a < NU && j < NX) ? gop[r] : 0.0;
+                        ls.opb[r] = kcol ? kv : 0.0;
+                    }
+                    // a non-positive pivot: the pass runs to its end and is redone by the caller with the Gauss-Newton Hessian
                     if (!ok && lane == 0) MISC[0] = 1.0;
                 }
                 LANES_END
-                if (MISC[0] != 0.0) { failed = 1; break; }
                 MMPC_TS(7)
-                // R5: P_k = F + G^T K,  p_k = gx + G^T kf
+                // R5: [P_k | p_k] = [F | gx] + G^T [K | kf]  (accumulates onto M; rows/columns >= NX keep M's entries)
+                MMPC_MFMA(rM, ls.opa[0], ls.opb[0])
+                if (NGB > 1) MMPC_MFMA(rM, ls.opa[NGB > 1 ? 1 : 0], ls.opb[NGB > 1 ? 1 : 0])
                 LANES_BEGIN
                 auto &ls = MMPC_LS;
-                if (lane < NXX + NX) {
-                    const bool isP = lane < NXX;
-                    const int i = isP ? (int)MMPC_B(ls.r5_ij, 0) : lane - NXX, j = (int)MMPC_B(ls.r5_ij, 1);
-                    double g[NU], kk[NU];
-                    const double f0 = isP ? MF[lane] : MGV[i];
+                const bool gcol = (lane & 15) == NV;
 #pragma unroll
-                    for (int a = 0; a < NU; a++) { g[a] = MG[a * NX + i]; kk[a] = isP ? KK[(k * NU + a) * NX + j] : KF[k * NU + a]; }
-                    mmpc_sched_fence();
-                    double v = f0;
-#pragma unroll
-                    for (int a = 0; a < NU; a++) v += g[a] * kk[a];
-                    if (isP) { HXX[k * NXX + lane] = v; PF[i * NX + j] = v; PF[j * NX + i] = v; }
-                    else QXU[k * NV + i] = v;
+                for (int r = 0; r < 4; r++) {
+                    ls.rP[r] = ls.rM[r];
+                    const unsigned o = ls.h_o[r];
+                    if ((ls.h_m >> (4 + r)) & 1u) lds[(o & 0xffffu) + k * (int)(o >> 16)] = ls.rM[r];
+                    ls.rM[r] = ls.nhm[r];
+                    ls.rT[r] = (gcol && r < NKB) ? ls.rP[r] : 0.0;
                 }
+#pragma unroll
+                for (int r = 0; r < NKB; r++) ls.rAB[r] = ls.nab[r];
                 LANES_END
             }
+            if (MISC[0] != 0.0) failed = 1;
             if (!failed) break;
             if (attempt == 1) break;
             failed = 0;
