@@ -164,7 +164,7 @@ typedef double MmpcAcc __attribute__((ext_vector_type(4)));
 
 struct MmpcFastLayout {
     int XU, S, LAM, XUREF, ULAST, OBS, CST, CV, CD, TRG, HXX, QXU, HUXL, HUUL, HUX02, HUUD, SN, KK, KF, DXU, DS, DLAM,
-        GS, FILT, MISC, total;
+        GS, DUMP, FILT, MISC, total;
 };
 // constants block (CST) offsets
 #define MMPC_C_XLIM 0      // [2][9]
@@ -189,7 +189,7 @@ MMPC_HD MmpcFastLayout mmpc_fast_layout(int M, int obs_per_stage) {
     MMPC_CARVE(HXX, F::NS * F::NXX) MMPC_CARVE(QXU, F::NS * F::NV) MMPC_CARVE(HUXL, F::NU * F::NX)
     MMPC_CARVE(HUUL, F::NUU) MMPC_CARVE(HUX02, F::NS) MMPC_CARVE(HUUD, F::NS * F::NU) MMPC_CARVE(SN, 16)
     MMPC_CARVE(KK, N * F::NU * F::NX) MMPC_CARVE(KF, N * F::NU) MMPC_CARVE(DXU, F::NS * F::NV) MMPC_CARVE(DS, F::NS)
-    MMPC_CARVE(DLAM, F::NS * F::NX) MMPC_CARVE(GS, 256) MMPC_CARVE(FILT, 2 * MMPC_FCAP) MMPC_CARVE(MISC, 8)
+    MMPC_CARVE(DLAM, F::NS * F::NX) MMPC_CARVE(GS, 256) MMPC_CARVE(DUMP, MMPC_WAVE) MMPC_CARVE(FILT, 2 * MMPC_FCAP) MMPC_CARVE(MISC, 8)
 #undef MMPC_CARVE
     L.total = o;
     return L;
@@ -211,6 +211,8 @@ struct MmpcLaneState {
     unsigned h_o[4], h_l[4];                         // stage-matrix entry of register r: LDS offset | stage stride << 16; offset of its
                                                      // stage-(N-1) extra term (Q1 elimination of s_{N-1}) or of the constant 0
     unsigned h_m;                                    // bit r: register r is part of [P | p]; bit 4+r: ... and is stored (lower triangle, p)
+    unsigned g_o[F::NGB];                            // GS offset of this lane's entry of the G^T operand (or of the constant 0)
+    unsigned k_o[F::NGB];                            // this lane's entry of the [K | kf] operand in KK / KF: offset | stage stride << 16
     MmpcAcc rP, rT, rM;                              // cost-to-go [P | p], T = P [A B | c], stage matrix M
     double rAB[F::NKB], opa[F::NGB], opb[F::NGB];    // MFMA operands
     double nab[F::NKB], nhm[4];                      // next stage's [A B | c] rows and stage-matrix entries (loaded one stage ahead)
@@ -364,6 +366,13 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
             }
             ls.h_o[r] = off | (stride << 16);
             ls.h_l[r] = last;
+        }
+#pragma unroll
+        for (int r = 0; r < NGB; r++) {
+            const int a = 4 * r + g;
+            ls.g_o[r] = (unsigned)((a < NU && j < NX) ? L.GS + (NX + a) * 16 + j : L.CV);
+            ls.k_o[r] = a >= NU ? (unsigned)L.CV : j < NX ? (unsigned)(L.KK + a * NX + j) | ((unsigned)(NU * NX) << 16)
+                                                 : j == NV ? (unsigned)(L.KF + a) | ((unsigned)NU << 16) : (unsigned)L.CV;
         }
         {
             unsigned fc = 0, fv = 0, fx = 0;
@@ -787,14 +796,12 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
             //      operands of stage N-1: rAB = [A B | c] rows 4r+g, rM = stage matrix (accumulator input), rT = [0 | p_N]
             LANES_BEGIN
             auto &ls = MMPC_LS;
-            const bool gcol = (lane & 15) == NV;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const unsigned o = ls.h_o[r];
-                const double v = lds[(o & 0xffffu) + N * (int)(o >> 16)];
-                ls.rP[r] = ((ls.h_m >> r) & 1u) ? v : 0.0;
+                ls.rP[r] = ((ls.h_m >> r) & 1u) ? lds[(o & 0xffffu) + N * (int)(o >> 16)] : 0.0;
                 ls.rM[r] = lds[(o & 0xffffu) + (N - 1) * (int)(o >> 16)] + lds[ls.h_l[r]];
-                ls.rT[r] = (gcol && r < NKB) ? ls.rP[r] : 0.0;
+                ls.rT[r] = (r < NKB && (lane & 15) == NV) ? ls.rP[r] : 0.0;
             }
 #pragma unroll
             for (int r = 0; r < NKB; r++) { const unsigned o = ls.ab_o[r]; ls.rAB[r] = lds[(o & 0xffffu) + (N - 1) * (int)(o >> 16)]; }
@@ -830,7 +837,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                         rhs[a] = GS[(NX + a) * 16 + j];
                     }
 #pragma unroll
-                    for (int r = 0; r < NGB; r++) { const int a = 4 * r + g; gop[r] = GS[(NX + (a < NU ? a : 0)) * 16 + j]; }
+                    for (int r = 0; r < NGB; r++) gop[r] = lds[ls.g_o[r]];
                     // operands of the next stage travel while this one factorises
                     if (k > 0) {
 #pragma unroll
@@ -878,19 +885,17 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
 #pragma unroll
                         for (int a = 0; a < NU; a++) dst[a * step] = -rhs[a];
                     }
-                    // operands of P_k = F + G^T K: A[i][a] = G[a][i] (rows i < NX), B[a][j] = K[a][j], a = 4r+g
 #pragma unroll
-                    for (int r = 0; r < NGB; r++) {
-                        const int a = 4 * r + g;
-                        double kv = 0.0;
-#pragma unroll
-                        for (int aa = 0; aa < NU; aa++) if (aa == a) kv = -rhs[aa];
-                        ls.opa[r] = (a < NU && j < NX) ? gop[r] : 0.0;
-                        ls.opb[r] = kcol ? kv : 0.0;
-                    }
+                    for (int r = 0; r < NGB; r++) ls.opa[r] = gop[r];
                     // a non-positive pivot: the pass runs to its end and is redone by the caller with the Gauss-Newton Hessian
                     if (!ok && lane == 0) MISC[0] = 1.0;
                 }
+                LANES_END
+                // operands of P_k = F + G^T K: A[i][a] = G[a][i] (rows i < NX), B[a][j] = K[a][j], a = 4r+g, read back from KK / KF
+                LANES_BEGIN
+                auto &ls = MMPC_LS;
+#pragma unroll
+                for (int r = 0; r < NGB; r++) { const unsigned o = ls.k_o[r]; ls.opb[r] = lds[(o & 0xffffu) + k * (int)(o >> 16)]; }
                 LANES_END
                 MMPC_TS(7)
                 // R5: [P_k | p_k] = [F | gx] + G^T [K | kf]  (accumulates onto M; rows/columns >= NX keep M's entries)
@@ -898,14 +903,13 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                 if (NGB > 1) MMPC_MFMA(rM, ls.opa[NGB > 1 ? 1 : 0], ls.opb[NGB > 1 ? 1 : 0])
                 LANES_BEGIN
                 auto &ls = MMPC_LS;
-                const bool gcol = (lane & 15) == NV;
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     ls.rP[r] = ls.rM[r];
-                    const unsigned o = ls.h_o[r];
-                    if ((ls.h_m >> (4 + r)) & 1u) lds[(o & 0xffffu) + k * (int)(o >> 16)] = ls.rM[r];
+                    const unsigned o = ((ls.h_m >> (4 + r)) & 1u) ? ls.h_o[r] : (unsigned)(L.DUMP + lane);   // (dump slot: no branch)
+                    lds[(o & 0xffffu) + k * (int)(o >> 16)] = ls.rM[r];
                     ls.rM[r] = ls.nhm[r];
-                    ls.rT[r] = (gcol && r < NKB) ? ls.rP[r] : 0.0;
+                    ls.rT[r] = (r < NKB && (lane & 15) == NV) ? ls.rP[r] : 0.0;
                 }
 #pragma unroll
                 for (int r = 0; r < NKB; r++) ls.rAB[r] = ls.nab[r];
