@@ -100,6 +100,16 @@ int mmpc_solve_batch_device(mmpc_handle h, int B, const double *d_x_init, const 
 int mmpc_get_u_latest(mmpc_handle h, int B, double *u_latest);
 int mmpc_set_u_latest(mmpc_handle h, int B, const double *u_latest);
 
+/* ManipulatorPanda3DoF.inverse_transformation(q_initial_guess, x_target) for B instances
+ * (robot_models/manipulator_3DoF.py:79-133; called by Interface.globalPlanManipulator, interface_wholebody_qref.py:286):
+ * minimise (x_e(q)-x*)^2 + (z_e(q)-z*)^2 over the joint box of :123, started at q0.  Stateless, no handle:
+ * q0[B][3], target_xz[B][2] = (x*, z*) in the arm base frame (the reference asserts y* == 0, :100), out_q[B][3];
+ * out_status[B] (0: projected gradient <= 1e-8) and out_iters[B] may be NULL.  Errors: mmpc_last_error(NULL). */
+int mmpc_ik_batch(int device, int B, const double *q0, const double *target_xz, double *out_q, int *out_status,
+                  int *out_iters);
+int mmpc_ik_batch_device(int device, int B, const double *d_q0, const double *d_target_xz, double *d_q, int *d_status,
+                         int *d_iters, void *stream);
+
 /* bytes of LDS one problem instance occupies (one 64-lane workgroup) */
 int mmpc_lds_bytes(mmpc_handle h);
 const char *mmpc_last_error(mmpc_handle h);

@@ -18,8 +18,8 @@ from .controllers.mpc_wholebody_qref import MPCWholeBody
 from .controllers.mpc_base import MPCBase
 from . import _capi
 from . import interface_wholebody_qref
-from .interface_wholebody_qref import BatchedRecedingHorizon
+from .interface_wholebody_qref import BatchedRecedingHorizon, Interface
 from .build import build_extension
 
 __all__ = ["Obstacles", "Base", "ManipulatorPanda3DoF", "MobileManipulator", "MPCWholeBody", "MPCBase",
-           "build_extension", "_capi", "BatchedRecedingHorizon", "interface_wholebody_qref"]
+           "build_extension", "_capi", "BatchedRecedingHorizon", "Interface", "interface_wholebody_qref"]

@@ -22,7 +22,7 @@ class MmpcConfig(C.Structure):
 
 EXPORTS = ["mmpc_create", "mmpc_destroy", "mmpc_set_weights", "mmpc_set_terminal_xy_equality", "mmpc_reset",
            "mmpc_solve_batch", "mmpc_solve_batch_device", "mmpc_get_u_latest", "mmpc_set_u_latest",
-           "mmpc_lds_bytes", "mmpc_last_error", "mmpc_version"]
+           "mmpc_lds_bytes", "mmpc_last_error", "mmpc_version", "mmpc_ik_batch", "mmpc_ik_batch_device"]
 
 _lib = None
 _dp = C.POINTER(C.c_double)
@@ -51,6 +51,8 @@ def lib():
         L.mmpc_last_error.argtypes = [C.c_void_p]
         L.mmpc_last_error.restype = C.c_char_p
         L.mmpc_version.restype = C.c_char_p
+        L.mmpc_ik_batch.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp, _ip, _ip]
+        L.mmpc_ik_batch_device.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_void_p]
         _lib = L
     return _lib
 
@@ -61,6 +63,21 @@ def _d(a):
 
 def _i(a):
     return a.ctypes.data_as(_ip) if a is not None else None
+
+
+def ik_batch(q0, target_xz, device=0):
+    """mmpc_ik_batch: q0 (B,3), target_xz (B,2) -> dict(q (B,3), status (B,), iters (B,)).  Runs on the GPU (no fallback)."""
+    q0 = np.ascontiguousarray(np.atleast_2d(q0), np.float64)
+    t = np.ascontiguousarray(np.atleast_2d(target_xz), np.float64)
+    B = q0.shape[0]
+    if q0.shape != (B, 3) or t.shape != (B, 2):
+        raise ValueError("q0 must be (B,3) and target_xz (B,2)")
+    q = np.empty((B, 3)); st = np.empty(B, np.int32); it = np.empty(B, np.int32)
+    L = lib()
+    rc = L.mmpc_ik_batch(int(device), B, _d(q0), _d(t), _d(q), _i(st), _i(it))
+    if rc != 0:
+        raise RuntimeError("mmpc_ik_batch failed (%d): %s" % (rc, (L.mmpc_last_error(None) or b"").decode()))
+    return dict(q=q, status=st, iters=it)
 
 
 class Engine:

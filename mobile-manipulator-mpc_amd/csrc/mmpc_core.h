@@ -69,6 +69,10 @@ struct MmpcParams {
 #define MMPC_BZ (0.606 + 0.333)
 #define MMPC_BASE_R 0.4
 #define MMPC_SELF_R 0.05
+// weight of the augmentation rho/2 |E dx_N - e|^2 of the terminal-xy equality inside the stage-wise factorisation: it
+// does not change the Newton step (constant on the constraint) but lets the exact Hessian be used whenever it is
+// positive definite ON the constraint (without it the recursion falls back to Gauss-Newton -> linear convergence)
+#define MMPC_RHO_EQ 1e4
 
 // ---- structure of [A B] = d f / d(x,u) for the diff-drive base (+ integrator arm) -----------
 // robot_models/base.py:19-26, manipulator_3DoF.py:190.  Every column has at most 4 non-zeros.
@@ -215,7 +219,7 @@ MMPC_DEV double mmpc_self_row(int i, double px, double py, double c, double s, c
 // One row per (stage, point): the intended formulation; the reference's L>=2 code path emits L rows that read
 // stale / free `constr` entries (quirk Q8) - not reproduced.  g6 = dh/d(x,y,psi,q1,q2,q3) or null.
 MMPC_DEV double mmpc_hs_row(const MmpcParams &P, int i, double px, double py, double c, double s, const double dr[3],
-                            const double dz[3], double *g6) {
+                            const double dz[3], double *g6, double *h10 = nullptr) {
     const double al = (i == 0 || i == 2) ? 0.5 : (i == 1 ? 1.0 : 0.0);
     const double be = (i == 2 || i == 4) ? 0.5 : (i == 3 ? 1.0 : 0.0);
     const double ga = i == 4 ? 0.5 : (i == 5 ? 1.0 : 0.0);
@@ -240,6 +244,15 @@ MMPC_DEV double mmpc_hs_row(const MmpcParams &P, int i, double px, double py, do
         g6[3] = (n0 * c + n1 * s) * Rm0 + n2 * Zm0;
         g6[4] = (n0 * c + n1 * s) * Rm1 + n2 * Zm1;
         g6[5] = (n0 * c + n1 * s) * Rm2 + n2 * Zm2;
+        if (h10) {
+            // second derivatives of n.P_i(x) over (psi, q1, q2, q3), packed lower triangle: d2 seg/d theta^2 = -seg, so the
+            // entries of R_qq are +-Zm and those of Z_qq are -+Rm (oracle/nlp.py: halfspace_row, order 2)
+            const double nc = n0 * c + n1 * s, nt = -n0 * s + n1 * c;
+            h10[0] = -nc * R;
+            h10[1] = nt * Rm0; h10[2] = nc * Zm0 - n2 * Rm0;
+            h10[3] = nt * Rm1; h10[4] = nc * Zm1 - n2 * Rm1; h10[5] = -nc * Zm1 + n2 * Rm1;
+            h10[6] = nt * Rm2; h10[7] = nc * Zm2 - n2 * Rm2; h10[8] = -nc * Zm2 + n2 * Rm2; h10[9] = -nc * Zm2 + n2 * Rm2;
+        }
     }
     return -best;
 }
@@ -626,6 +639,19 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                         qx[ia] += g6[a] * zh;
                         vx[a] += w * g6[a];
                     }
+                    if (exact) {
+                        // curvature z * d2(n.FK point) over (psi, q1, q2, q3): the row multipliers are large (S = 1e5), without
+                        // it the step is a Gauss-Newton step and convergence is linear
+                        const double *xk = X + k * NX;
+                        double sn, cs, dr[3], dz[3], gt[6], h10[10];
+                        sincos(xk[2], &sn, &cs);
+                        mmpc_arm_segments(xk[NX - 3], xk[NX - 2], xk[NX - 1], dr, dz);
+                        mmpc_hs_row(P, i, xk[0], xk[1], cs, sn, dr, dz, gt, h10);
+                        for (int a = 0; a < 4; a++) {
+                            const int ia = kY[2 + a];
+                            for (int b = 0; b <= a; b++) hxx[ia * (ia + 1) / 2 + kY[2 + b]] += z * h10[a * (a + 1) / 2 + b];
+                        }
+                    }
                     hss += w; gss -= zh;
                 }
                 HSS[k] = hss; GSS[k] = gss;
@@ -682,7 +708,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
             LANES_BEGIN
             for (int e = lane; e < NX * NX; e += MMPC_WAVE) {
                 const int i = e / NX, j = e % NX;
-                PF[e] = HXX[N * NXX + (i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i)];
+                PF[e] = HXX[N * NXX + (i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i)] + ((teq && i == j && i < 2) ? MMPC_RHO_EQ : 0.0);
             }
             if (teq && lane < NX * 2) {   // p^nu_N = E^T, E = [I2 0]
                 const double v = (lane / 2 == lane % 2) ? 1.0 : 0.0;
@@ -703,6 +729,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                     } else {
                         const int i = e - NX * NV;
                         double v = QX[(k + 1) * NX + i];
+                        if (teq && k == N - 1 && i < 2) v -= MMPC_RHO_EQ * (XREF[N * NX + i] - X[N * NX + i]);
                         for (int m = 0; m < NX; m++) v += PF[i * NX + m] * CD[k * NX + m];
                         PC[i] = v;
                     }

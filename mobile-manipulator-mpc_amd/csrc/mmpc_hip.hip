@@ -11,6 +11,7 @@
 #include "../../include/mmpc.h"
 #include "mmpc_core.h"
 #include "mmpc_fast.h"
+#include "mmpc_ik.h"
 
 template <int KIND>
 __global__ __launch_bounds__(MMPC_WAVE) void mmpc_solve_kernel(
@@ -174,7 +175,8 @@ extern "C" int mmpc_debug_read_stamps(unsigned long long *out16) {
 }
 #endif
 extern "C" const char *mmpc_version(void) { return "mmpc 0.1 (gfx950)"; }
-extern "C" const char *mmpc_last_error(mmpc_handle h) { return h ? h->err : "null handle"; }
+static thread_local char g_err[512] = "";   // errors of the handle-less entry points (mmpc_ik_*)
+extern "C" const char *mmpc_last_error(mmpc_handle h) { return h ? h->err : g_err; }
 extern "C" int mmpc_lds_bytes(mmpc_handle h) { return h ? ((h->fast && h->diag && !h->hp.terminal_xy_eq) ? h->fast_lds_bytes : h->lds_bytes) : MMPC_E_ARG; }
 
 extern "C" int mmpc_create(const mmpc_config *cfg, mmpc_handle *out) {
@@ -380,4 +382,69 @@ extern "C" int mmpc_set_u_latest(mmpc_handle h, int B, const double *u_latest) {
     HIPCHK(h, hipSetDevice(h->cfg.device));
     HIPCHK(h, hipMemcpy(h->d_ulatest, u_latest, (size_t)B * h->cfg.N * h->nu * 8, hipMemcpyHostToDevice));
     return MMPC_OK;
+}
+
+// ---- batched inverse kinematics of the arm (manipulator_3DoF.py:79-133): one lane per instance, stateless
+__global__ __launch_bounds__(256) void mmpc_ik_kernel(int B, const double *__restrict__ q0, const double *__restrict__ target,
+                                                      double *__restrict__ q, int *__restrict__ status, int *__restrict__ iters) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const double qi[3] = {q0[3 * b], q0[3 * b + 1], q0[3 * b + 2]};
+    double qo[3];
+    int it = 0;
+    const int st = mmpc_ik_solve(qi, target[2 * b], target[2 * b + 1], qo, &it);
+    q[3 * b] = qo[0]; q[3 * b + 1] = qo[1]; q[3 * b + 2] = qo[2];
+    if (status) status[b] = st;
+    if (iters) iters[b] = it;
+}
+
+#define IKCHK(call)                                                                                              \
+    do {                                                                                                         \
+        hipError_t e_ = (call);                                                                                  \
+        if (e_ != hipSuccess) { snprintf(g_err, sizeof(g_err), "%s: %s", #call, hipGetErrorString(e_)); return MMPC_E_HIP; } \
+    } while (0)
+
+extern "C" int mmpc_ik_batch_device(int device, int B, const double *d_q0, const double *d_target_xz, double *d_q,
+                                    int *d_status, int *d_iters, void *stream) {
+    if (B < 0 || !d_q0 || !d_target_xz || !d_q) { snprintf(g_err, sizeof(g_err), "mmpc_ik_batch_device: bad argument"); return MMPC_E_ARG; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+        snprintf(g_err, sizeof(g_err), "no HIP device %d (this library has no CPU fallback)", device);
+        return MMPC_E_NODEVICE;
+    }
+    if (B == 0) return MMPC_OK;
+    IKCHK(hipSetDevice(device));
+    hipLaunchKernelGGL(mmpc_ik_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, B, d_q0, d_target_xz, d_q, d_status, d_iters);
+    IKCHK(hipGetLastError());
+    return MMPC_OK;
+}
+
+extern "C" int mmpc_ik_batch(int device, int B, const double *q0, const double *target_xz, double *out_q, int *out_status,
+                             int *out_iters) {
+    if (B < 0 || !q0 || !target_xz || !out_q) { snprintf(g_err, sizeof(g_err), "mmpc_ik_batch: bad argument"); return MMPC_E_ARG; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+        snprintf(g_err, sizeof(g_err), "no HIP device %d (this library has no CPU fallback)", device);
+        return MMPC_E_NODEVICE;
+    }
+    if (B == 0) return MMPC_OK;
+    IKCHK(hipSetDevice(device));
+    double *d_q0 = nullptr, *d_t = nullptr, *d_q = nullptr;
+    int *d_st = nullptr, *d_it = nullptr;
+    int rc = MMPC_OK;
+    hipError_t e = hipSuccess;
+    if ((e = hipMalloc(&d_q0, (size_t)B * 24)) == hipSuccess && (e = hipMalloc(&d_t, (size_t)B * 16)) == hipSuccess &&
+        (e = hipMalloc(&d_q, (size_t)B * 24)) == hipSuccess && (e = hipMalloc(&d_st, (size_t)B * 4)) == hipSuccess &&
+        (e = hipMalloc(&d_it, (size_t)B * 4)) == hipSuccess &&
+        (e = hipMemcpy(d_q0, q0, (size_t)B * 24, hipMemcpyHostToDevice)) == hipSuccess &&
+        (e = hipMemcpy(d_t, target_xz, (size_t)B * 16, hipMemcpyHostToDevice)) == hipSuccess) {
+        rc = mmpc_ik_batch_device(device, B, d_q0, d_t, d_q, d_st, d_it, nullptr);
+        if (rc == MMPC_OK && (e = hipDeviceSynchronize()) == hipSuccess && (e = hipMemcpy(out_q, d_q, (size_t)B * 24, hipMemcpyDeviceToHost)) == hipSuccess) {
+            if (out_status) e = hipMemcpy(out_status, d_st, (size_t)B * 4, hipMemcpyDeviceToHost);
+            if (e == hipSuccess && out_iters) e = hipMemcpy(out_iters, d_it, (size_t)B * 4, hipMemcpyDeviceToHost);
+        }
+    }
+    if (e != hipSuccess) { snprintf(g_err, sizeof(g_err), "mmpc_ik_batch: %s", hipGetErrorString(e)); rc = MMPC_E_HIP; }
+    (void)hipFree(d_q0); (void)hipFree(d_t); (void)hipFree(d_q); (void)hipFree(d_st); (void)hipFree(d_it);
+    return rc;
 }

@@ -27,5 +27,24 @@ class ManipulatorPanda3DoF:
         """q + q_dot*dt (manipulator_3DoF.py:189-191; the reference mutates q in place, this does not)."""
         return np.asarray(q, float) + np.asarray(q_dot, float) * self.dt
 
-    def inverse_transformation(self, q_initial_guess, x_target):
-        raise NotImplementedError("batched IK (manipulator_3DoF.py:79-133) is on the 'next' list (SURVEY 8f-3)")
+    def inverse_transformation(self, q_initial_guess, x_target, device=0):
+        """Joint angles that bring the endpoint to x_target = (x, 0, z) in the arm base frame, started at
+        q_initial_guess (manipulator_3DoF.py:79-133; same objective :111 and joint box :123).  Raises ValueError when the
+        solver does not reach a stationary point, as the reference does on an IPOPT failure (:124-125).  For a reachable
+        target the solution set is a curve; the point returned is the one this solver reaches from the guess, which need
+        not be IPOPT's (inverse kinematics)."""
+        x_target = np.asarray(x_target, float).squeeze()
+        q0 = np.asarray(q_initial_guess, float).squeeze()
+        if x_target.shape[0] != 3:
+            raise ValueError("Wrong target ")                       # :131 (4- and 6-component targets are `pass` upstream)
+        assert x_target[1] == 0.0, "y should always be 0"          # :100
+        r = self.inverse_transformation_batch(q0[None, :], x_target[None, [0, 2]], device=device)
+        if r["status"][0] != 0:
+            raise ValueError(f"No solution in joint space found for given target {x_target} in cartesian space")
+        return r["q"][0]
+
+    @staticmethod
+    def inverse_transformation_batch(q_initial_guess, target_xz, device=0):
+        """B independent IK problems in one launch: q0 (B,3), target_xz (B,2) -> dict(q, status, iters)."""
+        from .. import _capi
+        return _capi.ik_batch(q_initial_guess, target_xz, device=device)

@@ -43,6 +43,7 @@ class Options:
     curv_dyn = True
     curv_circ = True
     curv_self = False
+    curv_hs = True        # exact curvature of the half-space rows (n . FK point): their multipliers are large (S = 1e5)
     piv_frac = 0.0
     nu_lam = 0.0
     filter = True
@@ -51,6 +52,7 @@ class Options:
     delta0 = 1e-4
     delta_min = 1e-20
     delta_max = 1e10
+    rho_eq = 1e4          # augmentation weight of the terminal-xy equality inside the factorisation
 
 
 def _rows_for_stage(prob, k):
@@ -119,8 +121,8 @@ def _eval_row(prob, k, row, X, U, s, order):
     if kind == "hs":
         if order == 0:
             return nlp.halfspace_row(X[k], j, prob.hs, 0) - s[k], None, None, k, None
-        h, jx = nlp.halfspace_row(X[k], j, prob.hs, 1)
-        return h - s[k], jx, None, k, None
+        h, jx, H = nlp.halfspace_row(X[k], j, prob.hs, 2)
+        return h - s[k], jx, None, k, H
     raise ValueError(kind)
 
 
@@ -271,7 +273,8 @@ def solve(prob: nlp.Problem, U0=None, X0=None, opt: Options = None, verbose=Fals
                         Hu += w * np.outer(ju, ju)
                         gu += ju * zh
                     if Hr is not None and use_exact:
-                        if (rows[k][i][0] == "circ" and opt.curv_circ) or (rows[k][i][0] == "self" and opt.curv_self):
+                        if (rows[k][i][0] == "circ" and opt.curv_circ) or (rows[k][i][0] == "self" and opt.curv_self) or \
+                                (rows[k][i][0] == "hs" and opt.curv_hs):
                             H += z[k][i] * Hr
                     if ks is not None:
                         hss[ks] += w
@@ -300,6 +303,14 @@ def solve(prob: nlp.Problem, U0=None, X0=None, opt: Options = None, verbose=Fals
             Pm = [None] * (N + 1); pv = [None] * (N + 1)
             K = [None] * N; kf = [None] * N
             Pm[N] = Hxx[N]; pv[N] = qx[N]
+            if p.terminal_xy_equality:
+                # augmentation of the terminal equality E dx_N = e: + rho/2 |E dx_N - e|^2 leaves the Newton step
+                # unchanged (the term is constant on the constraint) but lets the stage-wise factorisation see the
+                # curvature restricted to the constraint, where the exact Hessian only has to be positive definite
+                Pm[N] = Pm[N].copy(); pv[N] = pv[N].copy()
+                e_aug = prob.traj_ref[N, :2] - X[N, :2]
+                Pm[N][0, 0] += opt.rho_eq; Pm[N][1, 1] += opt.rho_eq
+                pv[N][:2] -= opt.rho_eq * e_aug
             pvv = [None] * (N + 1); kfv = [None] * N
             pvv[N] = np.zeros((nx, 2)); pvv[N][0, 0] = 1.0; pvv[N][1, 1] = 1.0    # E^T, E = [I2 0] (terminal xy equality)
             for k in range(N - 1, -1, -1):

@@ -35,6 +35,7 @@
 #define LMX 8           /* max half-space obstacles */
 #define RMX (2 * NUM + 2 * NXM + MMX + 4 + 6)
 #define FCAP 16
+#define RHO_EQ 1e4     /* augmentation weight of the terminal-xy equality inside the factorisation */
 
 typedef struct {
     int kind;            /* 0 whole-body (nx=9,nu=5), 1 base-only (nx=6,nu=2) */
@@ -141,7 +142,7 @@ static double self_row(const double *x, int i, double *g6) {
 /* half-space row for sample point i of [j2/2, j2, (j2+j3)/2, j3, (j3+e)/2, e] (mpc_wholebody_qref.py:57-89,216-217):
  *   h = -max_j n_j.((pi_j - 0.03 n_j) - P_i(x));   one row per (k,i) - the intended formulation, see oracle/nlp.py */
 static const double HS_PTS[6][3] = {{0.5, 0, 0}, {1, 0, 0}, {0.5, 0.5, 0}, {0, 1, 0}, {0, 0.5, 0.5}, {0, 0, 1}};
-static double hs_row(const oracle_cfg *cfg, const double *x, int i, double *g6) {
+static double hs_row(const oracle_cfg *cfg, const double *x, int i, double *g6, double *h10) {
     double al = HS_PTS[i][0], be = HS_PTS[i][1], ga = HS_PTS[i][2], sig = al + be + ga;
     double cm[3] = {sig, be + ga, ga}, dr[3], dz[3];
     arm_segments(x + 6, dr, dz);
@@ -161,6 +162,17 @@ static double hs_row(const oracle_cfg *cfg, const double *x, int i, double *g6) 
         for (int m = 0; m < 3; m++) for (int j = 0; j < 3; j++) { Rm[j] += cm[m] * dz[m] * SEGC[m][j]; Zm[j] -= cm[m] * dr[m] * SEGC[m][j]; }
         g6[0] = sig * n[0]; g6[1] = sig * n[1]; g6[2] = n[0] * (-R * s) + n[1] * (R * c);
         for (int j = 0; j < 3; j++) g6[3 + j] = n[0] * Rm[j] * c + n[1] * Rm[j] * s + n[2] * Zm[j];
+        if (h10) {
+            /* second derivatives of n.P_i(x) w.r.t. (psi, q1, q2, q3), packed lower triangle; d2 seg/d theta^2 = -seg, so
+             * R_qq = -sum_t cm_t dr_t D_t D_t^T (entries are +-Zm), Z_qq likewise with dz (entries are -+Rm) */
+            double nc = n[0] * c + n[1] * s, nt = -n[0] * s + n[1] * c;
+            double Rqq[6] = {Zm[0], Zm[1], -Zm[1], Zm[2], -Zm[2], -Zm[2]};   /* (0,0) (1,0) (1,1) (2,0) (2,1) (2,2) */
+            double Zqq[6] = {-Rm[0], -Rm[1], Rm[1], -Rm[2], Rm[2], Rm[2]};
+            h10[0] = -nc * R;
+            h10[1] = nt * Rm[0]; h10[2] = nc * Rqq[0] + n[2] * Zqq[0];
+            h10[3] = nt * Rm[1]; h10[4] = nc * Rqq[1] + n[2] * Zqq[1]; h10[5] = nc * Rqq[2] + n[2] * Zqq[2];
+            h10[6] = nt * Rm[2]; h10[7] = nc * Rqq[3] + n[2] * Zqq[3]; h10[8] = nc * Rqq[4] + n[2] * Zqq[4]; h10[9] = nc * Rqq[5] + n[2] * Zqq[5];
+        }
     }
     return -best;
 }
@@ -196,7 +208,7 @@ typedef struct {
     int act[NSM][RMX];
     /* evaluation */
     double h[NSM][RMX];
-    double gcirc[NSM][MMX][2], hcirc[NSM][MMX][3], gself[NSM][4][6], ghs[NSM][6][6];
+    double gcirc[NSM][MMX][2], hcirc[NSM][MMX][3], gself[NSM][4][6], ghs[NSM][6][6], hhs[NSM][6][10];
     int nhs;
     double A[NSM][NXM][NXM], B[NSM][NXM][NUM], c[NSM][NXM];
     double gX[NSM][NXM], gU[NSM][NUM], gs[NSM];
@@ -267,7 +279,7 @@ static void eval_rows(work *w, double X[NSM][NXM], double U[NSM][NUM], const dou
         if (w->cfg->kind == 0)
             for (int i = 0; i < 4; i++)
                 h[k][SL_SELF(w, i)] = self_row(X[k], i, with_deriv ? w->gself[k][i] : 0) - s[slack_idx(w, k)];
-        for (int i = 0; i < w->nhs; i++) h[k][SL_HS(w, i)] = hs_row(w->cfg, X[k], i, with_deriv ? w->ghs[k][i] : 0) - s[k];
+        for (int i = 0; i < w->nhs; i++) h[k][SL_HS(w, i)] = hs_row(w->cfg, X[k], i, with_deriv ? w->ghs[k][i] : 0, with_deriv ? w->hhs[k][i] : 0) - s[k];
     }
 }
 
@@ -377,6 +389,11 @@ static int factor(work *w, double mu, int use_exact) {
                 } else {
                     int i = r - 2 * nu - 2 * nx - w->M - 4; ks = k;     /* half-space rows: s[k] (s[N] at the end, :268) */
                     for (int j = 0; j < 6; j++) jx[YIDX[j]] = w->ghs[k][i][j];
+                    if (use_exact)   /* curvature of n.FK point over (psi, q1, q2, q3) = y-indices 2..5 */
+                        for (int a = 0; a < 4; a++) for (int b = 0; b < 4; b++) {
+                            int hi = a >= b ? a : b, lo = a >= b ? b : a;
+                            w->Hxx[k][YIDX[2 + a]][YIDX[2 + b]] += zz * w->hhs[k][i][hi * (hi + 1) / 2 + lo];
+                        }
                 }
                 for (int i = 0; i < nx; i++) { for (int j = 0; j < nx; j++) w->Hxx[k][i][j] += wt * jx[i] * jx[j]; w->qx[k][i] += jx[i] * zh; }
                 w->hss[ks] += wt; w->gss[ks] -= zh;
@@ -404,6 +421,11 @@ static int factor(work *w, double mu, int use_exact) {
             }
     }
     /* Riccati: P_k, p_k overwrite Hxx[k], qx[k] */
+    if (c->terminal_xy_eq)
+        for (int j = 0; j < 2; j++) {   /* augmentation rho/2 |E dx_N - e|^2 (see ipm_numpy.py: same Newton step, better-posed recursion) */
+            w->Hxx[N][j][j] += RHO_EQ;
+            w->qx[N][j] -= RHO_EQ * (w->xref[N * nx + j] - w->X[N][j]);
+        }
     memset(w->pvv[N], 0, sizeof(w->pvv[N]));
     w->pvv[N][0][0] = 1.0; w->pvv[N][1][1] = 1.0; /* E^T, E = [I2 0] */
     for (int k = N - 1; k >= 0; k--) {

@@ -6,6 +6,7 @@
 // phase in the opposite order: a result that changes exposes an intra-phase data race.
 #define MMPC_EMU 1
 #include "../../mobile-manipulator-mpc_amd/csrc/mmpc_fast.h"
+#include "../../mobile-manipulator-mpc_amd/csrc/mmpc_ik.h"
 #include <stdlib.h>
 #include <string.h>
 
@@ -95,3 +96,8 @@ extern "C" int mmpc_emu_lds_doubles(int kind, int N, int M, int obs_per_stage) {
     return kind == 0 ? mmpc_layout<0>(N, M, obs_per_stage).total : mmpc_layout<1>(N, M, obs_per_stage).total;
 }
 extern "C" int mmpc_emu_params_size() { return (int)sizeof(MmpcParams); }
+
+// arm inverse kinematics (mmpc_ik.h is plain scalar code: the same function the GPU kernel calls per lane)
+extern "C" void mmpc_emu_ik(int B, const double *q0, const double *target, double *q, int *status, int *iters) {
+    for (int b = 0; b < B; b++) status[b] = mmpc_ik_solve(q0 + 3 * b, target[2 * b], target[2 * b + 1], q + 3 * b, iters + b);
+}

@@ -9,6 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SRC = os.path.join(_HERE, "emu", "mmpc_emu.cpp")
 _CORE = os.path.join(_HERE, "..", "mobile-manipulator-mpc_amd", "csrc", "mmpc_core.h")
 _FAST = os.path.join(_HERE, "..", "mobile-manipulator-mpc_amd", "csrc", "mmpc_fast.h")
+_IK = os.path.join(_HERE, "..", "mobile-manipulator-mpc_amd", "csrc", "mmpc_ik.h")
 
 
 class MmpcParams(C.Structure):
@@ -23,7 +24,7 @@ class MmpcParams(C.Structure):
 
 def build(asan=False):
     out = os.path.join(_HERE, "emu", "_build", "libmmpc_emu_asan.so" if asan else "libmmpc_emu.so")
-    newest = max(os.path.getmtime(_SRC), os.path.getmtime(_CORE), os.path.getmtime(_FAST))
+    newest = max(os.path.getmtime(f) for f in (_SRC, _CORE, _FAST, _IK))
     if not os.path.exists(out) or os.path.getmtime(out) < newest:
         os.makedirs(os.path.dirname(out), exist_ok=True)
         flags = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer"] if asan else ["-O2"]
@@ -85,3 +86,13 @@ def solve_batch(par, x_init, traj_ref, u_ref, u_last, obs, x_guess=None, reverse
     if rc != 0:
         raise RuntimeError('no fast instantiation for this configuration')
     return dict(X=X, U=U, s=s, status=status, iters=iters, cost=cost, err=err)
+
+
+def ik_batch(q0, target_xz, asan=False):
+    """mmpc_ik_solve (the function the GPU kernel runs per lane) on the host."""
+    lib = C.CDLL(build(asan))
+    q0 = np.ascontiguousarray(np.atleast_2d(q0), float); t = np.ascontiguousarray(np.atleast_2d(target_xz), float)
+    B = q0.shape[0]
+    q = np.zeros((B, 3)); st = np.zeros(B, np.int32); it = np.zeros(B, np.int32)
+    lib.mmpc_emu_ik(B, _p(q0), _p(t), _p(q), st.ctypes.data_as(C.POINTER(C.c_int)), it.ctypes.data_as(C.POINTER(C.c_int)))
+    return dict(q=q, status=st, iters=it)

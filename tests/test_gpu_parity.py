@@ -230,3 +230,31 @@ def test_bad_arguments_raise(mm):
         ctrl.solve_batch(d["x_init"], d["traj_ref"], d["u_ref"], d["obs"])
     with pytest.raises(ValueError):
         ctrl.solve_batch(d["x_init"][:4], d["traj_ref"][:4, :5], d["u_ref"][:4], d["obs"][:4])
+
+
+@pytest.mark.gpu
+def test_closed_loop_demo_state_machine(mm):
+    """demo_wholebody_qref.py scenario 2 (x_start 0, endpoint target (4.4, 5, 1.439, -pi), three circle obstacles, two
+    half-space obstacles) through the whole task state machine of interface_wholebody_qref.py:146-228 with
+    physical_sim=False: move -> approach (terminal-xy equality) -> rotate -> manipulate (IK + joint reference) ->
+    finish.  Every tick is one solve on the GPU; a failed solve raises, as in the reference."""
+    dt, N = 0.1, 20
+    obstacles = [mm.Obstacles(2.5, 3.0, 0.6), mm.Obstacles(2.5, 1.0, 0.6), mm.Obstacles(5 - 0.6, 5, 0.1)]
+    r2 = 1 / np.sqrt(2)
+    manip = [(np.array([2.5, 2, 0.35 + 0.606 + 0.333]), np.array([[r2, 0, r2]])),
+             (np.array([2.5, 2, 0.35 + 0.606 + 0.333]), np.array([[-r2, 0, r2]]))]
+    target = np.array([5 - 0.6, 5, 0.606 + 0.333 + 0.5, -np.pi])
+    ctrl = mm.MPCWholeBody(mm.MobileManipulator(dt), obstacles, manip, N=N, faithful_convex=False)
+    world = mm.Interface(dt, 5, 2, np.zeros(9), target, ctrl, physical_sim=False)
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        flag = world.run(max_steps=400)
+    flags = list(dict.fromkeys(world.flag_log))
+    assert flag == 'manipulate finish', (flag, world.mpc_step_counter, flags)
+    assert flags[:3] == ['move', 'approach', 'rotate'] and 'manipulate' in flags
+    X = np.array(world.x_log)
+    # the base never enters an inflated obstacle disc, the endpoint ends within 1 cm of the target
+    for o in obstacles:
+        assert (np.hypot(X[:, 0] - o.x, X[:, 1] - o.y) >= o.radius + 0.4 - 5e-3).all()   # soft rows (S = 1e5): mm-level slack
+    assert np.linalg.norm(world.current_joints_pose[:3] - target[:3]) <= 0.01
+    assert np.abs(X[-1, :2] - world.x_target[:2]).max() < 0.02
