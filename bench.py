@@ -167,11 +167,23 @@ def main():
         achieved_tf = fl / (k_ms * 1e-3) / 1e12
         by = algorithmic_bytes_per_solve(N, nx, nu, M) * Bl
         traffic = None
-        tpath = os.path.join(_ROOT, "profiles", "r01_pmc_traffic.json")
+        mfma = None
+        tpath = os.path.join(_ROOT, "profiles", "r01_f_pmc_traffic.json")
+        mpath = os.path.join(_ROOT, "profiles", "r01_f_pmc_mfma.json")
         if world == 1 and (N, M, Bg) == (20, 5, 8192) and os.path.exists(tpath):
             # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), collected
             # separately with the same command and committed under profiles/ (bench.py cannot run the profiler itself)
             traffic = json.load(open(tpath))["traffic_bytes_per_launch"]
+        if world == 1 and (N, M) == (20, 5) and os.path.exists(mpath):
+            # matrix-core use of the same kernel from its PMC passes (tools/pmc_collect.sh): v_mfma_f64_16x16x4 count and
+            # busy cycles per wave per solver iteration; utilisation = executed MFMA flops / s over the 78.6 TFLOP/s peak
+            c = json.load(open(mpath))["per_wave_per_iteration"]
+            n_mfma = c.get("SQ_INSTS_MFMA", 0.0)
+            mfma = {"insts_per_iter": n_mfma, "busy_cycles_per_iter": c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0),
+                    "wave_cycles_per_iter": 4.0 * c.get("SQ_WAVE_CYCLES", 0.0),
+                    "executed_tflops": n_mfma * 2048.0 * mean_iters * Bl / (k_ms * 1e-3) / 1e12,
+                    "source": "profiles/r01_f_pmc_mfma.json"}
+            mfma["util"] = mfma["executed_tflops"] / FP64_PEAK_TFLOPS
         res = {
             "metric": "MPC solves/sec, whole-body N=%d batch=%d" % (N, args.batch),
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -185,10 +197,21 @@ def main():
                        "max_scaled_kkt": err_max, "lds_bytes_per_problem": eng.lds_bytes},
             "roofline": {"bound": "mfma", "kernel": "mmpc_fast_kernel<0,20,5>" if (N, M) == (20, 5) else "mmpc_solve_kernel<0>", "achieved": achieved_tf,
                          "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tf / FP64_PEAK_TFLOPS,
-                         "traffic": traffic, "kernel_ms": k_ms,
+                         "traffic": traffic, "kernel_ms": k_ms, "mfma": mfma,
                          "flops_per_iter": riccati_flops_per_iter(N, nx, nu, M, 4),
                          "hbm_achieved_GBs": by / (k_ms * 1e-3) / 1e9, "hbm_frac": by / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
+        if world == 1:
+            # PCIe-inclusive rate of the host-pointer entry point (mmpc_solve_batch: H2D, solve, D2H of X,U,s,...): a note
+            # beside `value`, which is always the device-resident rate
+            hx = np.clip(d["x_init"][:Bl], ctrl.xlim[0], ctrl.xlim[1])
+            eng.reset(); eng.solve_batch(hx, d["traj_ref"][:Bl], d["u_ref"][:Bl], d["obs"][:Bl])
+            h0 = time.perf_counter()
+            for _ in range(3):
+                eng.reset()
+                eng.solve_batch(hx, d["traj_ref"][:Bl], d["u_ref"][:Bl], d["obs"][:Bl])
+            res["host_pointer_api"] = {"value": 3 * Bl / (time.perf_counter() - h0), "unit": "solves/s",
+                                       "note": "mmpc_solve_batch with pageable host arrays in and out (PCIe-inclusive, cold start)"}
         if world == 1 and not args.no_cpu:
             from oracle import coracle, nlp
             avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
