@@ -24,6 +24,9 @@ extern "C" {
 
 #define MMPC_KIND_WHOLEBODY 0 /* controllers/mpc_wholebody_qref.py:MPCWholeBody */
 #define MMPC_KIND_BASE 1      /* controllers/mpc_base.py:MPCBase */
+#define MMPC_KIND_WHOLEBODY_POSE 2 /* controllers/mpc_wholebody.py:MPCWholeBody - whole-body model, the state cost tracks the
+                                      endpoint pose forward_tranformation(x)[0] = (x, y, z, psi): traj_ref[B][N+1][4], Q and P
+                                      are 4x4 (:11-12,79-80,104-106); circle rows only; X is warm-started too (:134-139) */
 
 #define MMPC_OK 0
 #define MMPC_E_ARG (-1)         /* bad argument / unsupported size */
@@ -69,7 +72,8 @@ int mmpc_create(const mmpc_config *cfg, mmpc_handle *out);
 int mmpc_destroy(mmpc_handle h);
 
 /* setWeight(Q,R,P,S,W) (mpc_wholebody_qref.py:119-139; mpc_base.py:96-112 where S is `M`):
- * row-major nx*nx / nu*nu matrices; a NULL pointer keeps the current value; S<0 keeps S. */
+ * row-major nx*nx / nu*nu matrices (Q, P: 4*4 for MMPC_KIND_WHOLEBODY_POSE); a NULL pointer keeps the current value;
+ * S<0 keeps S. */
 int mmpc_set_weights(mmpc_handle h, const double *Q, const double *R, const double *P, double S, const double *W);
 
 /* The hard terminal equality the driver injects through controller.opti

@@ -16,10 +16,11 @@ from .robot_models.manipulator_3DoF import ManipulatorPanda3DoF
 from .robot_models.mobile_manipulator import MobileManipulator
 from .controllers.mpc_wholebody_qref import MPCWholeBody
 from .controllers.mpc_base import MPCBase
+from .controllers.mpc_wholebody import MPCWholeBody as MPCWholeBodyPoseRef
 from . import _capi
 from . import interface_wholebody_qref
 from .interface_wholebody_qref import BatchedRecedingHorizon, Interface
 from .build import build_extension
 
-__all__ = ["Obstacles", "Base", "ManipulatorPanda3DoF", "MobileManipulator", "MPCWholeBody", "MPCBase",
+__all__ = ["Obstacles", "Base", "ManipulatorPanda3DoF", "MobileManipulator", "MPCWholeBody", "MPCBase", "MPCWholeBodyPoseRef",
            "build_extension", "_capi", "BatchedRecedingHorizon", "Interface", "interface_wholebody_qref"]

@@ -8,7 +8,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MMPC_LIB") or os.path.join(_HERE, "csrc", "libmmpc.so")   # MMPC_LIB: A/B builds of the same HIP library
 
-KIND_WHOLEBODY, KIND_BASE = 0, 1
+KIND_WHOLEBODY, KIND_BASE, KIND_WHOLEBODY_POSE = 0, 1, 2
 STATUS_CONVERGED, STATUS_MAXITER, STATUS_NUMERIC = 0, 1, 2
 
 
@@ -84,9 +84,10 @@ class Engine:
     """Owns one mmpc_handle (one controller's NLP structure on one GPU)."""
 
     def __init__(self, kind, N, M, dt, ulim, xlim, dulim, max_batch=1, device=0, obs_per_stage=False,
-                 tol=1e-8, mu_init=1.0, max_iter=200, halfspaces=None):
+                 tol=1e-8, mu_init=1.0, max_iter=2000, halfspaces=None):
         self.kind, self.N, self.M = kind, int(N), int(M)
-        self.nx, self.nu = (9, 5) if kind == KIND_WHOLEBODY else (6, 2)
+        self.nx, self.nu = (6, 2) if kind == KIND_BASE else (9, 5)
+        self.nref = 4 if kind == KIND_WHOLEBODY_POSE else self.nx      # reference row: endpoint pose (x,y,z,psi) or the state
         self.max_batch, self.device, self.obs_per_stage = int(max_batch), int(device), bool(obs_per_stage)
         cfg = MmpcConfig()
         cfg.kind, cfg.N, cfg.M, cfg.obs_per_stage = kind, self.N, self.M, int(self.obs_per_stage)
@@ -144,7 +145,7 @@ class Engine:
             if a.shape != (n, n):
                 raise ValueError("weight matrix must be %dx%d" % (n, n))
             return a
-        Q, P, R, W = m(Q, self.nx), m(P, self.nx), m(R, self.nu), m(W, self.nu)
+        Q, P, R, W = m(Q, self.nref), m(P, self.nref), m(R, self.nu), m(W, self.nu)
         Sv = -1.0 if S is None else float(np.ravel(S)[0])
         self._chk(lib().mmpc_set_weights(self._h, _d(Q), _d(R), _d(P), Sv, _d(W)), "mmpc_set_weights")
 
@@ -165,7 +166,7 @@ class Engine:
         traj_ref = np.ascontiguousarray(traj_ref, float)
         u_ref = np.ascontiguousarray(u_ref, float)
         obs = np.ascontiguousarray(obs, float)
-        if x_init.shape != (B, nx) or traj_ref.shape != (B, N + 1, nx) or u_ref.shape != (B, N, nu):
+        if x_init.shape != (B, nx) or traj_ref.shape != (B, N + 1, self.nref) or u_ref.shape != (B, N, nu):
             raise ValueError("shape mismatch: x_init %s traj_ref %s u_ref %s" % (x_init.shape, traj_ref.shape, u_ref.shape))
         if obs.shape != self.obs_shape(B):
             raise ValueError("obs shape %s, expected %s" % (obs.shape, self.obs_shape(B)))
@@ -191,7 +192,7 @@ class Engine:
         import torch
         N, nx, nu = self.N, self.nx, self.nu
         B = x_init.shape[0]
-        for t_, shp in ((x_init, (B, nx)), (traj_ref, (B, N + 1, nx)), (u_ref, (B, N, nu)), (u_last, (B, N, nu))):
+        for t_, shp in ((x_init, (B, nx)), (traj_ref, (B, N + 1, self.nref)), (u_ref, (B, N, nu)), (u_last, (B, N, nu))):
             if tuple(t_.shape) != shp or t_.dtype != torch.float64 or not t_.is_cuda or not t_.is_contiguous():
                 raise ValueError("device tensor must be contiguous cuda float64 of shape %s" % (shp,))
         if tuple(obs.shape) != self.obs_shape(B) or obs.dtype != torch.float64 or not obs.is_contiguous():

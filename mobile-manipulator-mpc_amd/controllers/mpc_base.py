@@ -13,7 +13,7 @@ class MPCBase:
                  M=np.diag([1e5]),
                  ulim=np.array([[-2, -PI], [2, PI]]),
                  xlim=np.array([[-100, -100, -2, -2, -PI], [100, 100, 2, 2, PI]]),
-                 max_batch=1, device=0, obs_per_stage=False, n_obstacles=None, tol=1e-8, max_iter=200):
+                 max_batch=1, device=0, obs_per_stage=False, n_obstacles=None, tol=1e-8, max_iter=2000):
         self.Q_value, self.R_value, self.P_value, self.M_value = Q, R, P, M
         self.dt = robot.dt
         self.N = N

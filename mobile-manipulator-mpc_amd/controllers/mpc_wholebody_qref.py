@@ -26,7 +26,7 @@ class MPCWholeBody:
                  xlim=np.array([[-100, -100, -INF, -2, -2, -PI, -PI / 2, -PI, 0],
                                 [100, 100, INF, 2, 2, PI, PI / 2, 0, 3 * PI / 2]]),
                  dulim=np.array([[-INF, -INF, -0.5, -0.5, -0.5], [INF, INF, 0.5, 0.5, 0.5]]),
-                 max_batch=1, device=0, obs_per_stage=False, n_obstacles=None, tol=1e-8, max_iter=200,
+                 max_batch=1, device=0, obs_per_stage=False, n_obstacles=None, tol=1e-8, max_iter=2000,
                  faithful_convex=None):
         self.N = N
         self.Q_value, self.R_value, self.P_value, self.S_value, self.W_value = Q, R, P, S, W

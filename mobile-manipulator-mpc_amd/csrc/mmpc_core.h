@@ -113,9 +113,12 @@ MMPC_CONST unsigned char kY[6] = {0, 1, 2, 6, 7, 8};
 
 template <int KIND>
 struct MmpcDims {
-    static constexpr int NX = KIND == 0 ? 9 : 6;
-    static constexpr int NU = KIND == 0 ? 5 : 2;
+    // KIND 0: whole-body, joint-space reference (controllers/mpc_wholebody_qref.py); 1: base only (controllers/mpc_base.py);
+    // 2: whole-body, endpoint-pose reference (controllers/mpc_wholebody.py: 4-vector reference rows, no self-collision rows)
+    static constexpr int NX = KIND != 1 ? 9 : 6;
+    static constexpr int NU = KIND != 1 ? 5 : 2;
     static constexpr int NSELF = KIND == 0 ? 4 : 0;
+    static constexpr int NREF = KIND == 2 ? 4 : NX;
     static constexpr int NV = NX + NU;
     static constexpr int NXX = NX * (NX + 1) / 2;
     static constexpr int NUU = NU * (NU + 1) / 2;
@@ -277,12 +280,78 @@ struct MmpcTab<0> {
     MMPC_DEV static int rcv(int i, int q) { return kRowCvWB[i][q]; }
 };
 template <>
+struct MmpcTab<2> : MmpcTab<0> {};
+template <>
 struct MmpcTab<1> {
     MMPC_DEV static int crow(int j, int q) { return kColRowB[j][q]; }
     MMPC_DEV static int ccv(int j, int q) { return kColCvB[j][q]; }
     MMPC_DEV static int rcol(int i, int q) { return kRowColB[i][q]; }
     MMPC_DEV static int rcv(int i, int q) { return kRowCvB[i][q]; }
 };
+
+// State term of a stage: returns q = e^T W2 e with W2 = W + W^T (the cost term is q/2), W = Q (k < N) or P; optional
+// gradient (NX) and packed lower Hessian (Gauss-Newton part, plus the remaining curvature when `exact`).
+//   KIND 0 / 1: e = x - ref (angleDiff on psi for the base kind, mpc_base.py:148), Hessian = W2;
+//   KIND 2: e = endpoint pose (x + R cos psi, y + R sin psi, Z, psi) - ref (controllers/mpc_wholebody.py:79-80,104-106 with
+//           mobile_manipulator.py:36-53), W2 is 4x4 (leading dimension 4); Hessian = J^T W2 J + sum_c (W2 e)_c d2E_c.
+template <int KIND>
+MMPC_DEV double mmpc_state_cost(const MmpcParams &P, bool terminal, const double *xk, const double *ref, double *grad,
+                                double *hxx, bool exact) {
+    typedef MmpcDims<KIND> D;
+    constexpr int NX = D::NX;
+    const double *W2 = terminal ? P.P2 : P.Q2;
+    if constexpr (KIND != 2) {
+        double e[NX], q = 0.0;
+        for (int j = 0; j < NX; j++) e[j] = xk[j] - ref[j];
+        if (KIND == 1) e[2] = mmpc_angle_diff(xk[2], ref[2]);
+        for (int i = 0; i < NX; i++) {
+            double v = 0.0;
+            for (int j = 0; j < NX; j++) v += W2[i * NX + j] * e[j];
+            if (grad) grad[i] = v;
+            q += e[i] * v;
+        }
+        if (hxx) for (int e2 = 0; e2 < D::NXX; e2++) hxx[e2] = W2[kTriI[e2] * NX + kTriJ[e2]];
+        (void)exact;
+        return q;
+    } else {
+    double sn, cs, dr[3], dz[3];
+    sincos(xk[2], &sn, &cs);
+    mmpc_arm_segments(xk[NX - 3], xk[NX - 2], xk[NX - 1], dr, dz);
+    const double R = MMPC_BX + dr[0] + dr[1] + dr[2], Z = MMPC_BZ + dz[0] + dz[1] + dz[2];
+    const double e[4] = {xk[0] + R * cs - ref[0], xk[1] + R * sn - ref[1], Z - ref[2], xk[2] - ref[3]};
+    double v[4], q = 0.0;
+    for (int i = 0; i < 4; i++) { v[i] = 0.0; for (int j = 0; j < 4; j++) v[i] += W2[i * 4 + j] * e[j]; q += e[i] * v[i]; }
+    if (!grad && !hxx) return q;
+    const double Rm[3] = {dz[0] + dz[1] + dz[2], -(dz[1] + dz[2]), -dz[2]}, Zm[3] = {-(dr[0] + dr[1] + dr[2]), dr[1] + dr[2], dr[2]};
+    double J[4][6];   // over y = (x, y, psi, q1, q2, q3)
+    for (int i = 0; i < 4; i++) for (int a = 0; a < 6; a++) J[i][a] = 0.0;
+    J[0][0] = 1.0; J[0][2] = -R * sn; J[1][1] = 1.0; J[1][2] = R * cs; J[3][2] = 1.0;
+    for (int a = 0; a < 3; a++) { J[0][3 + a] = Rm[a] * cs; J[1][3 + a] = Rm[a] * sn; J[2][3 + a] = Zm[a]; }
+    if (grad) {
+        for (int j = 0; j < NX; j++) grad[j] = 0.0;
+        for (int a = 0; a < 6; a++) { double g = 0.0; for (int i = 0; i < 4; i++) g += J[i][a] * v[i]; grad[kY[a]] = g; }
+    }
+    if (hxx) {
+        for (int e2 = 0; e2 < D::NXX; e2++) hxx[e2] = 0.0;
+        for (int a = 0; a < 6; a++) for (int b = 0; b <= a; b++) {
+            double h = 0.0;
+            for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) h += J[i][a] * W2[i * 4 + j] * J[j][b];
+            hxx[kY[a] * (kY[a] + 1) / 2 + kY[b]] = h;
+        }
+        if (exact) {
+            // same closed form as the half-space rows with n = (v0, v1, v2): entries of R_qq are +-Zm, of Z_qq -+Rm
+            const double nc = v[0] * cs + v[1] * sn, nt = -v[0] * sn + v[1] * cs;
+            const double h10[10] = {-nc * R,
+                                    nt * Rm[0], nc * Zm[0] - v[2] * Rm[0],
+                                    nt * Rm[1], nc * Zm[1] - v[2] * Rm[1], -nc * Zm[1] + v[2] * Rm[1],
+                                    nt * Rm[2], nc * Zm[2] - v[2] * Rm[2], -nc * Zm[2] + v[2] * Rm[2], -nc * Zm[2] + v[2] * Rm[2]};
+            for (int a = 0; a < 4; a++) for (int b = 0; b <= a; b++)
+                hxx[kY[2 + a] * (kY[2 + a] + 1) / 2 + kY[2 + b]] += h10[a * (a + 1) / 2 + b];
+        }
+    }
+    return q;
+    }
+}
 
 // ------------------------------------------------------------------------------------------
 // The solver.  `lds` points at this problem's slab of mmpc_layout<KIND>(N,M,..).total doubles.
@@ -294,6 +363,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
     constexpr int NX = D::NX, NU = D::NU, NSELF = D::NSELF, NV = D::NV, NXX = D::NXX, NUU = D::NUU;
     const int N = P.N, M = P.M, NS = N + 1;
     const int NHS = (KIND == 0 && P.L > 0) ? 6 : 0;
+    constexpr int NREF = D::NREF;
     const MmpcLayout L = mmpc_layout<KIND>(N, M, P.obs_per_stage, NHS);
     const int R = L.R, NR = L.NR;
     double *X = lds + L.X, *U = lds + L.U, *S = lds + L.S, *LAM = lds + L.LAM, *XREF = lds + L.XREF,
@@ -336,8 +406,8 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
     for (int i = lane; i < NS * NX; i += MMPC_WAVE) {
         const int j = i % NX;
         double x0 = io.x_init[j];
-        if (KIND == 0) x0 = mmpc_max(mmpc_min(x0, P.xlim[1][j]), P.xlim[0][j]);  // :290-291
-        XREF[i] = io.traj_ref[i];
+        if (KIND != 1) x0 = mmpc_max(mmpc_min(x0, P.xlim[1][j]), P.xlim[0][j]);  // :290-291
+        if (i < NS * NREF) XREF[i] = io.traj_ref[i];
         X[i] = (P.use_xguess && i >= NX) ? io.x_guess[i] : x0;  // :302 / mpc_base.py:200
         LAM[i] = 0.0;
     }
@@ -414,16 +484,9 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
             double rdx[NX], rdu[NU > 0 ? NU : 1];
             // cost gradient (mpc_wholebody_qref.py:192-201,240-242; mpc_base.py:146-153)
             {
-                double e[NX];
-                for (int j = 0; j < NX; j++) e[j] = xk[j] - XREF[k * NX + j];
-                if (KIND == 1) e[2] = mmpc_angle_diff(xk[2], XREF[k * NX + 2]);
-                const double *W2 = k < N ? P.Q2 : P.P2;
-                for (int i = 0; i < NX; i++) {
-                    double v = 0.0;
-                    for (int j = 0; j < NX; j++) v += W2[i * NX + j] * e[j];
-                    GX[k * NX + i] = v;
-                    rdx[i] = v + (k >= 1 ? LAM[k * NX + i] : 0.0);
-                }
+                double g[NX];
+                mmpc_state_cost<KIND>(P, k == N, xk, XREF + k * NREF, g, nullptr, false);
+                for (int i = 0; i < NX; i++) { GX[k * NX + i] = g[i]; rdx[i] = g[i] + (k >= 1 ? LAM[k * NX + i] : 0.0); }
             }
             double *cv = CV + k * MMPC_NCV;
             if (k < N) {
@@ -437,7 +500,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                 xn[3] = xk[3] + dt * (uk[0] * cs - xk[4] * xk[5]);
                 xn[4] = xk[4] + dt * (uk[0] * sn + xk[3] * xk[5]);
                 xn[5] = xk[5] + dt * uk[1];
-                if (KIND == 0) { xn[6] = xk[6] + dt * uk[2]; xn[7] = xk[7] + dt * uk[3]; xn[8] = xk[8] + dt * uk[4]; }
+                if (KIND != 1) { xn[6] = xk[6] + dt * uk[2]; xn[7] = xk[7] + dt * uk[3]; xn[8] = xk[8] + dt * uk[4]; }
                 for (int j = 0; j < NX; j++) {
                     const double c = xn[j] - X[(k + 1) * NX + j];
                     CD[k * NX + j] = c;
@@ -571,8 +634,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
             LANES_BEGIN
             for (int k = lane; k < NS; k += MMPC_WAVE) {
                 double *hxx = HXX + k * NXX, *qx = QX + k * NX;
-                const double *W2 = k < N ? P.Q2 : P.P2;
-                for (int e = 0; e < NXX; e++) hxx[e] = W2[kTriI[e] * NX + kTriJ[e]];
+                mmpc_state_cost<KIND>(P, k == N, X + k * NX, XREF + k * NREF, nullptr, hxx, exact);
                 for (int j = 0; j < NX; j++) qx[j] = GX[k * NX + j];
                 if (k < N) {
                     for (int a = 0; a < NU; a++) { HUUD[k * NU + a] = 0.0; QU[k * NU + a] = GU[k * NU + a]; }
@@ -945,15 +1007,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
             const int ks = slack_idx(k);
             const double sks = S[ks] + alpha * DS[ks];
             double f = Sw * sk * sk, th = 0.0;
-            {
-                double e[NX];
-                for (int j = 0; j < NX; j++) e[j] = xk[j] - XREF[k * NX + j];
-                if (KIND == 1) e[2] = mmpc_angle_diff(xk[2], XREF[k * NX + 2]);
-                const double *W2 = k < N ? P.Q2 : P.P2;
-                double q = 0.0;
-                for (int i = 0; i < NX; i++) for (int j = 0; j < NX; j++) q += e[i] * W2[i * NX + j] * e[j];
-                f += 0.5 * q;
-            }
+            f += 0.5 * mmpc_state_cost<KIND>(P, k == N, xk, XREF + k * NREF, nullptr, nullptr, false);
             double sn, cs;
             sincos(xk[2], &sn, &cs);
             if (k < N) {
@@ -968,7 +1022,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                 xn[3] = xk[3] + dt * (uk[0] * cs - xk[4] * xk[5]);
                 xn[4] = xk[4] + dt * (uk[0] * sn + xk[3] * xk[5]);
                 xn[5] = xk[5] + dt * uk[1];
-                if (KIND == 0) { xn[6] = xk[6] + dt * uk[2]; xn[7] = xk[7] + dt * uk[3]; xn[8] = xk[8] + dt * uk[4]; }
+                if (KIND != 1) { xn[6] = xk[6] + dt * uk[2]; xn[7] = xk[7] + dt * uk[3]; xn[8] = xk[8] + dt * uk[4]; }
                 for (int j = 0; j < NX; j++) th += fabs(xn[j] - (X[(k + 1) * NX + j] + alpha * DX[(k + 1) * NX + j]));
             }
             // sum of log t: product of mantissas + sum of exponents (one log per stage)
@@ -1138,12 +1192,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
     double f = 0.0;
     for (int k = lane; k < NS; k += MMPC_WAVE) {
         const double *xk = X + k * NX;
-        double e[NX];
-        for (int j = 0; j < NX; j++) e[j] = xk[j] - XREF[k * NX + j];
-        if (KIND == 1) e[2] = mmpc_angle_diff(xk[2], XREF[k * NX + 2]);
-        const double *W2 = k < N ? P.Q2 : P.P2;
-        double q = 0.0;
-        for (int i = 0; i < NX; i++) for (int j = 0; j < NX; j++) q += e[i] * W2[i * NX + j] * e[j];
+        double q = mmpc_state_cost<KIND>(P, k == N, xk, XREF + k * NREF, nullptr, nullptr, false);
         if (k < N) {
             const double *uk = U + k * NU;
             for (int a = 0; a < NU; a++) for (int b = 0; b < NU; b++)

@@ -30,7 +30,7 @@ __global__ __launch_bounds__(MMPC_WAVE) void mmpc_solve_kernel(
     const size_t so = (size_t)(P.obs_per_stage ? N + 1 : 1) * M * 3;
     MmpcIO io;
     io.x_init = x_init + (size_t)b * D::NX;
-    io.traj_ref = traj_ref + (size_t)b * (N + 1) * D::NX;
+    io.traj_ref = traj_ref + (size_t)b * (N + 1) * D::NREF;
     io.u_ref = u_ref + (size_t)b * N * D::NU;
     io.u_last = u_last + (size_t)b * N * D::NU;
     io.x_guess = x_guess ? x_guess + (size_t)b * (N + 1) * D::NX : nullptr;
@@ -108,7 +108,7 @@ struct mmpc_handle_s {
     mmpc_config cfg;
     MmpcParams hp;          // host copy
     MmpcParams *dp;         // device copy
-    int nx, nu, lds_bytes;
+    int nx, nu, nref, lds_bytes;
     int fast;               // 1: specialised kernel exists for (kind, N, M)
     int fast_lds_bytes;
     int diag;               // weights are diagonal (required by the specialised kernel)
@@ -137,7 +137,12 @@ static void default_weights(mmpc_handle h) {
     memset(p.Q2, 0, sizeof(p.Q2)); memset(p.P2, 0, sizeof(p.P2)); memset(p.RW2, 0, sizeof(p.RW2));
     memset(p.R2, 0, sizeof(p.R2)); memset(p.W2, 0, sizeof(p.W2));
     const int nx = h->nx, nu = h->nu;
-    if (h->cfg.kind == MMPC_KIND_WHOLEBODY) {
+    if (h->cfg.kind == MMPC_KIND_WHOLEBODY_POSE) {
+        // controllers/mpc_wholebody.py:11-15: Q = 5 I4, P = 50 I4 (4x4, leading dimension 4), R, W as the qref controller
+        const double r[5] = {0.1, 0.1, 0, 0, 0}, w[5] = {0, 0, 0.1, 0.1, 0.1};
+        for (int i = 0; i < 4; i++) { p.Q2[i * 4 + i] = 2 * 5.0; p.P2[i * 4 + i] = 2 * 50.0; }
+        for (int i = 0; i < nu; i++) { p.R2[i * nu + i] = 2 * r[i]; p.W2[i * nu + i] = 2 * w[i]; }
+    } else if (h->cfg.kind == MMPC_KIND_WHOLEBODY) {
         const double q[9] = {25, 25, 0, 0, 0, 5, 5, 5, 5}, r[5] = {0.1, 0.1, 0, 0, 0}, w[5] = {0, 0, 0.1, 0.1, 0.1};
         for (int i = 0; i < nx; i++) p.Q2[i * nx + i] = p.P2[i * nx + i] = 2 * q[i];
         for (int i = 0; i < nu; i++) { p.R2[i * nu + i] = 2 * r[i]; p.W2[i * nu + i] = 2 * w[i]; }
@@ -182,7 +187,7 @@ extern "C" int mmpc_lds_bytes(mmpc_handle h) { return h ? ((h->fast && h->diag &
 extern "C" int mmpc_create(const mmpc_config *cfg, mmpc_handle *out) {
     if (!cfg || !out) return MMPC_E_ARG;
     *out = nullptr;
-    if (cfg->kind != MMPC_KIND_WHOLEBODY && cfg->kind != MMPC_KIND_BASE) return MMPC_E_ARG;
+    if (cfg->kind != MMPC_KIND_WHOLEBODY && cfg->kind != MMPC_KIND_BASE && cfg->kind != MMPC_KIND_WHOLEBODY_POSE) return MMPC_E_ARG;
     if (cfg->N < 1 || cfg->N > 63 || cfg->M < 0 || cfg->M > 16 || cfg->max_batch < 1) return MMPC_E_ARG;
     if (cfg->L < 0 || cfg->L > 8 || (cfg->L > 0 && cfg->kind != MMPC_KIND_WHOLEBODY)) return MMPC_E_ARG;
     int ndev = 0;
@@ -191,13 +196,14 @@ extern "C" int mmpc_create(const mmpc_config *cfg, mmpc_handle *out) {
     if (!h) return MMPC_E_ARG;
     memset(h, 0, sizeof(*h));
     h->cfg = *cfg;
-    h->nx = cfg->kind == MMPC_KIND_WHOLEBODY ? 9 : 6;
-    h->nu = cfg->kind == MMPC_KIND_WHOLEBODY ? 5 : 2;
+    h->nx = cfg->kind != MMPC_KIND_BASE ? 9 : 6;
+    h->nu = cfg->kind != MMPC_KIND_BASE ? 5 : 2;
+    h->nref = cfg->kind == MMPC_KIND_WHOLEBODY_POSE ? 4 : h->nx;   // reference row: endpoint pose (x,y,z,psi) or the state
     *out = h;  // returned even on failure below so that the caller can read the error text
     HIPCHK(h, hipSetDevice(cfg->device));
     MmpcParams &p = h->hp;
     p.N = cfg->N; p.M = cfg->M; p.obs_per_stage = cfg->obs_per_stage ? 1 : 0;
-    p.max_iter = cfg->max_iter > 0 ? cfg->max_iter : 200;
+    p.max_iter = cfg->max_iter > 0 ? cfg->max_iter : 2000;   // the reference passes ipopt.max_iter 2000 (mpc_wholebody_qref.py:280)
     p.use_xguess = 0; p.terminal_xy_eq = 0;
     p.dt = cfg->dt; p.tol = cfg->tol > 0 ? cfg->tol : 1e-8; p.mu_init = cfg->mu_init > 0 ? cfg->mu_init : 1.0;
     for (int r = 0; r < 2; r++) {
@@ -209,13 +215,16 @@ extern "C" int mmpc_create(const mmpc_config *cfg, mmpc_handle *out) {
     const int nhs = (cfg->kind == MMPC_KIND_WHOLEBODY && cfg->L > 0) ? 6 : 0;
     default_weights(h);
     const MmpcLayout L = cfg->kind == MMPC_KIND_WHOLEBODY ? mmpc_layout<0>(cfg->N, cfg->M, p.obs_per_stage, nhs)
-                                                          : mmpc_layout<1>(cfg->N, cfg->M, p.obs_per_stage, 0);
+                       : cfg->kind == MMPC_KIND_BASE    ? mmpc_layout<1>(cfg->N, cfg->M, p.obs_per_stage, 0)
+                                                        : mmpc_layout<2>(cfg->N, cfg->M, p.obs_per_stage, 0);
     h->lds_bytes = L.total * (int)sizeof(double);
     if (h->lds_bytes > 160 * 1024) return fail(h, MMPC_E_ARG, "problem needs %s bytes of LDS%s", "more than 163840");
     if (cfg->kind == MMPC_KIND_WHOLEBODY)
         HIPCHK(h, hipFuncSetAttribute((const void *)mmpc_solve_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes));
-    else
+    else if (cfg->kind == MMPC_KIND_BASE)
         HIPCHK(h, hipFuncSetAttribute((const void *)mmpc_solve_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes));
+    else
+        HIPCHK(h, hipFuncSetAttribute((const void *)mmpc_solve_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes));
     h->fast = 0; h->fast_lds_bytes = 0;
     {
 #define MMPC_X(K, NN, MM, WW)                                                                                        \
@@ -266,8 +275,9 @@ extern "C" int mmpc_set_weights(mmpc_handle h, const double *Q, const double *R,
     if (!h) return MMPC_E_ARG;
     const int nx = h->nx, nu = h->nu;
     MmpcParams &p = h->hp;
-    if (Q) for (int i = 0; i < nx; i++) for (int j = 0; j < nx; j++) p.Q2[i * nx + j] = Q[i * nx + j] + Q[j * nx + i];
-    if (P) for (int i = 0; i < nx; i++) for (int j = 0; j < nx; j++) p.P2[i * nx + j] = P[i * nx + j] + P[j * nx + i];
+    const int nq = h->nref;   // Q, P weigh the reference error: nx x nx, or 4 x 4 for the endpoint-pose reference
+    if (Q) for (int i = 0; i < nq; i++) for (int j = 0; j < nq; j++) p.Q2[i * nq + j] = Q[i * nq + j] + Q[j * nq + i];
+    if (P) for (int i = 0; i < nq; i++) for (int j = 0; j < nq; j++) p.P2[i * nq + j] = P[i * nq + j] + P[j * nq + i];
     if (R) for (int i = 0; i < nu; i++) for (int j = 0; j < nu; j++) p.R2[i * nu + j] = R[i * nu + j] + R[j * nu + i];
     if (W) for (int i = 0; i < nu; i++) for (int j = 0; j < nu; j++) p.W2[i * nu + j] = W[i * nu + j] + W[j * nu + i];
     if (S >= 0) p.S = S;
@@ -278,6 +288,8 @@ extern "C" int mmpc_set_weights(mmpc_handle h, const double *Q, const double *R,
 
 extern "C" int mmpc_set_terminal_xy_equality(mmpc_handle h, int on) {
     if (!h) return MMPC_E_ARG;
+    if (on && h->cfg.kind == MMPC_KIND_WHOLEBODY_POSE)
+        return fail(h, MMPC_E_UNSUPPORTED, "terminal-xy equality%s%s", " is defined on the joint-space reference only (mpc_wholebody_qref.py)");
     h->hp.terminal_xy_eq = on ? 1 : 0;   // handled by the generic kernel (the specialised kernels do not carry it)
     HIPCHK(h, hipSetDevice(h->cfg.device));
     return upload_params(h);
@@ -314,8 +326,11 @@ static int launch(mmpc_handle h, int B, const double *x_init, const double *traj
     } else if (h->cfg.kind == MMPC_KIND_WHOLEBODY)
         hipLaunchKernelGGL(mmpc_solve_kernel<0>, dim3(B), dim3(MMPC_WAVE), h->lds_bytes, st, h->dp, B, x_init, traj, uref,
                            ulast, xguess, obs, X, U, s, status, iters, cost, err, order);
-    else
+    else if (h->cfg.kind == MMPC_KIND_BASE)
         hipLaunchKernelGGL(mmpc_solve_kernel<1>, dim3(B), dim3(MMPC_WAVE), h->lds_bytes, st, h->dp, B, x_init, traj, uref,
+                           ulast, xguess, obs, X, U, s, status, iters, cost, err, order);
+    else
+        hipLaunchKernelGGL(mmpc_solve_kernel<2>, dim3(B), dim3(MMPC_WAVE), h->lds_bytes, st, h->dp, B, x_init, traj, uref,
                            ulast, xguess, obs, X, U, s, status, iters, cost, err, order);
     HIPCHK(h, hipGetLastError());
     if (B <= h->cfg.max_batch && B > 256 && !getenv("MMPC_NO_LPT")) {
@@ -347,11 +362,12 @@ extern "C" int mmpc_solve_batch(mmpc_handle h, int B, const double *x_init, cons
     const size_t nobs = (size_t)(h->hp.obs_per_stage ? N + 1 : 1) * (size_t)h->cfg.M * 3;
     hipStream_t st = 0;
     HIPCHK(h, hipMemcpyAsync(h->d_x_init, x_init, b * nx * 8, hipMemcpyHostToDevice, st));
-    HIPCHK(h, hipMemcpyAsync(h->d_traj, traj_ref, b * (N + 1) * nx * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(h, hipMemcpyAsync(h->d_traj, traj_ref, b * (N + 1) * (size_t)h->nref * 8, hipMemcpyHostToDevice, st));
     HIPCHK(h, hipMemcpyAsync(h->d_uref, u_ref, b * N * nu * 8, hipMemcpyHostToDevice, st));
     if (nobs) HIPCHK(h, hipMemcpyAsync(h->d_obs, obs, b * nobs * 8, hipMemcpyHostToDevice, st));
-    // base kind warm-starts X as well (mpc_base.py:194-201); whole-body never does (:301-302)
-    const double *xg = (h->cfg.kind == MMPC_KIND_BASE && h->warm) ? h->d_xguess : nullptr;
+    // the base kind and the pose-reference kind warm-start X as well (mpc_base.py:194-201, mpc_wholebody.py:134-139); the
+    // joint-reference whole-body controller never does (mpc_wholebody_qref.py:301-302)
+    const double *xg = (h->cfg.kind != MMPC_KIND_WHOLEBODY && h->warm) ? h->d_xguess : nullptr;
     int rc = launch(h, B, h->d_x_init, h->d_traj, h->d_uref, h->d_ulatest, xg, h->d_obs, h->d_X, h->d_U, h->d_s,
                     h->d_status, h->d_iters, h->d_cost, h->d_err, st);
     if (rc) return rc;

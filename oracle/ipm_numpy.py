@@ -81,7 +81,7 @@ def _rows_for_stage(prob, k):
                 rows.append(("xhi", j, p.xlim[1, j]))
     for m, o in enumerate(prob.obs_at(k)):
         rows.append(("circ", m, o))
-    if p.kind == "wholebody":
+    if nlp.has_arm_rows(p):
         for i in range(4):
             rows.append(("self", i, None))
         if prob.hs is not None and len(prob.hs):
@@ -255,7 +255,8 @@ def solve(prob: nlp.Problem, U0=None, X0=None, opt: Options = None, verbose=Fals
             vx = np.zeros((N + 1, nx))        # sum_i w_i J_i,x for rows bound to s_k from stage k
             vxN = np.zeros(nx)                # Q1: stage-N self rows bound to s_{N-1}
             for k in range(N + 1):
-                H = (Q2 if k < N else P2) + delta * np.eye(nx)
+                _, _, Hgn, Hcv = nlp.state_cost(p, k, X[k], prob.traj_ref[k], 2)
+                H = Hgn + (Hcv if use_exact else 0.0) + delta * np.eye(nx)
                 Hu = RW2 + delta * np.eye(nu) if k < N else None
                 Hc = np.zeros((nu, nx)) if k < N else None
                 g = gX[k].copy()

@@ -49,6 +49,8 @@ typedef struct {
     int max_iter;
     int L;               /* half-space ("manipulation") obstacles, demo_wholebody_qref.py:21-33 */
     double hs[LMX][6];   /* point (3), normal (3) */
+    int pose_ref;        /* controllers/mpc_wholebody.py: the state cost tracks the endpoint pose (x,y,z,psi); Q, P are 4x4
+                            (leading dimension 4), traj_ref is [N+1][4]; no self-collision / half-space rows */
 } oracle_cfg;
 
 /* robot_models/manipulator_3DoF.py:18-22, mobile_manipulator.py:14-15, base.py:15,
@@ -256,7 +258,7 @@ static void setup_rows(work *w) {
                 if (isfinite(c->xlim[1][j])) { w->act[k][SL_XHI(w, j)] = 1; w->bnd[k][SL_XHI(w, j)] = c->xlim[1][j]; }
             }
         for (int m = 0; m < w->M; m++) w->act[k][SL_CIRC(w, m)] = 1;
-        if (c->kind == 0) for (int i = 0; i < 4; i++) w->act[k][SL_SELF(w, i)] = 1;
+        if (c->kind == 0 && !c->pose_ref) for (int i = 0; i < 4; i++) w->act[k][SL_SELF(w, i)] = 1;
         for (int i = 0; i < w->nhs; i++) w->act[k][SL_HS(w, i)] = 1;
     }
 }
@@ -276,7 +278,7 @@ static void eval_rows(work *w, double X[NSM][NXM], double U[NSM][NUM], const dou
         for (int m = 0; m < w->M; m++)
             h[k][SL_CIRC(w, m)] = circ_row(X[k], obs_at(w, k, m), with_deriv ? w->gcirc[k][m] : 0,
                                             with_deriv ? w->hcirc[k][m] : 0) - s[k];
-        if (w->cfg->kind == 0)
+        if (w->cfg->kind == 0 && !w->cfg->pose_ref)
             for (int i = 0; i < 4; i++)
                 h[k][SL_SELF(w, i)] = self_row(X[k], i, with_deriv ? w->gself[k][i] : 0) - s[slack_idx(w, k)];
         for (int i = 0; i < w->nhs; i++) h[k][SL_HS(w, i)] = hs_row(w->cfg, X[k], i, with_deriv ? w->ghs[k][i] : 0, with_deriv ? w->hhs[k][i] : 0) - s[k];
@@ -288,15 +290,71 @@ static void state_err(const work *w, const double *xk, const double *ref, double
     if (w->cfg->kind == 1) e[2] = angle_diff(xk[2], ref[2]); /* mpc_base.py:148 */
 }
 
+/* endpoint pose E = forward_tranformation(x)[0] = (x + R cos psi, y + R sin psi, Z, psi) (mobile_manipulator.py:36-53), its
+ * Jacobian over y = (x, y, psi, q1, q2, q3) and the pieces of its second derivatives (see oracle/nlp.py: endpoint_pose) */
+static void endpoint_pose(const double *x, double E[4], double J[4][6], double *Rout, double Rm[3], double Zm[3], double *cs) {
+    double dr[3], dz[3];
+    arm_segments(x + 6, dr, dz);
+    double R = BX + dr[0] + dr[1] + dr[2], Z = BZ + dz[0] + dz[1] + dz[2], c = cos(x[2]), s = sin(x[2]);
+    E[0] = x[0] + R * c; E[1] = x[1] + R * s; E[2] = Z; E[3] = x[2];
+    if (!J) return;
+    Rm[0] = dz[0] + dz[1] + dz[2]; Rm[1] = -(dz[1] + dz[2]); Rm[2] = -dz[2];
+    Zm[0] = -(dr[0] + dr[1] + dr[2]); Zm[1] = dr[1] + dr[2]; Zm[2] = dr[2];
+    memset(J, 0, sizeof(double) * 24);
+    J[0][0] = 1; J[0][2] = -R * s; J[1][1] = 1; J[1][2] = R * c; J[3][2] = 1;
+    for (int a = 0; a < 3; a++) { J[0][3 + a] = Rm[a] * c; J[1][3 + a] = Rm[a] * s; J[2][3 + a] = Zm[a]; }
+    *Rout = R; cs[0] = c; cs[1] = s;
+}
+
+/* state term of stage k: e^T W e (W = Q or P).  grad (nx), Hgn = Gauss-Newton Hessian, Hcv = remaining curvature (zero unless
+ * the cost goes through the forward kinematics, controllers/mpc_wholebody.py:79-80,104-106).  Any output may be NULL. */
+static double state_cost(const work *w, int k, const double *xk, double *grad, double Hgn[NXM][NXM], double Hcv[NXM][NXM]) {
+    const oracle_cfg *c = w->cfg;
+    int nx = w->nx;
+    const double *Wt = k < w->N ? c->Q : c->P;
+    if (!c->pose_ref) {
+        double e[NXM], q = 0;
+        state_err(w, xk, w->xref + k * nx, e);
+        for (int i = 0; i < nx; i++) for (int j = 0; j < nx; j++) q += e[i] * Wt[i * nx + j] * e[j];
+        if (grad) for (int i = 0; i < nx; i++) { double v = 0; for (int j = 0; j < nx; j++) v += (Wt[i * nx + j] + Wt[j * nx + i]) * e[j]; grad[i] = v; }
+        if (Hgn) for (int i = 0; i < nx; i++) for (int j = 0; j < nx; j++) { Hgn[i][j] = Wt[i * nx + j] + Wt[j * nx + i]; if (Hcv) Hcv[i][j] = 0; }
+        return q;
+    }
+    double E[4], J[4][6], R = 0, Rm[3] = {0, 0, 0}, Zm[3] = {0, 0, 0}, cs[2] = {1, 0}, e[4], v[4], q = 0;
+    endpoint_pose(xk, E, (grad || Hgn) ? J : 0, &R, Rm, Zm, cs);
+    for (int i = 0; i < 4; i++) e[i] = E[i] - w->xref[k * 4 + i];
+    for (int i = 0; i < 4; i++) { v[i] = 0; for (int j = 0; j < 4; j++) { q += e[i] * Wt[i * 4 + j] * e[j]; v[i] += (Wt[i * 4 + j] + Wt[j * 4 + i]) * e[j]; } }
+    if (grad) { memset(grad, 0, sizeof(double) * nx); for (int a = 0; a < 6; a++) for (int i = 0; i < 4; i++) grad[YIDX[a]] += J[i][a] * v[i]; }
+    if (Hgn) {
+        for (int i = 0; i < nx; i++) for (int j = 0; j < nx; j++) { Hgn[i][j] = 0; if (Hcv) Hcv[i][j] = 0; }
+        for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) {
+            double h = 0;
+            for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) h += J[i][a] * (Wt[i * 4 + j] + Wt[j * 4 + i]) * J[j][b];
+            Hgn[YIDX[a]][YIDX[b]] = h;
+        }
+        if (Hcv) {
+            /* sum_c v_c d2E_c over (psi, q1, q2, q3): same closed form as the half-space rows with n = (v0, v1, v2) */
+            double nc = v[0] * cs[0] + v[1] * cs[1], nt = -v[0] * cs[1] + v[1] * cs[0];
+            double Rqq[3][3] = {{Zm[0], Zm[1], Zm[2]}, {Zm[1], -Zm[1], -Zm[2]}, {Zm[2], -Zm[2], -Zm[2]}};
+            double Zqq[3][3] = {{-Rm[0], -Rm[1], -Rm[2]}, {-Rm[1], Rm[1], Rm[2]}, {-Rm[2], Rm[2], Rm[2]}};
+            Hcv[2][2] = -nc * R;
+            for (int a = 0; a < 3; a++) {
+                Hcv[2][6 + a] = Hcv[6 + a][2] = nt * Rm[a];
+                for (int b = 0; b < 3; b++) Hcv[6 + a][6 + b] = nc * Rqq[a][b] + v[2] * Zqq[a][b];
+            }
+        }
+    }
+    return q;
+}
+
 static double cost_fn(const work *w, double X[NSM][NXM], double U[NSM][NUM], const double *s) {
     /* mpc_wholebody_qref.py:199-201,227,242,270 */
     const oracle_cfg *c = w->cfg;
     int nx = w->nx, nu = w->nu;
-    double J = 0, e[NXM], a[NUM], b[NUM];
+    double J = 0, a[NUM], b[NUM];
+    (void)nx;
     for (int k = 0; k <= w->N; k++) {
-        const double *Wt = k < w->N ? c->Q : c->P;
-        state_err(w, X[k], w->xref + k * nx, e);
-        for (int i = 0; i < nx; i++) for (int j = 0; j < nx; j++) J += e[i] * Wt[i * nx + j] * e[j];
+        J += state_cost(w, k, X[k], 0, 0, 0);
         J += c->S * s[k] * s[k];
         if (k < w->N) {
             for (int j = 0; j < nu; j++) { a[j] = U[k][j] - w->uref[k * nu + j]; b[j] = U[k][j] - w->ulast[k * nu + j]; }
@@ -353,7 +411,11 @@ static int factor(work *w, double mu, int use_exact) {
     for (int k = 0; k <= N; k++) { w->hss[k] = 2 * c->S; w->gss[k] = w->gs[k]; memset(w->vx[k], 0, sizeof(w->vx[k])); }
     memset(w->vxN, 0, sizeof(w->vxN));
     for (int k = 0; k <= N; k++) {
-        for (int i = 0; i < nx; i++) { for (int j = 0; j < nx; j++) w->Hxx[k][i][j] = k < N ? w->Q2[i][j] : w->P2[i][j]; w->qx[k][i] = w->gX[k][i]; }
+        {
+            double Hcv[NXM][NXM];
+            state_cost(w, k, w->X[k], 0, w->Hxx[k], Hcv);
+            for (int i = 0; i < nx; i++) { for (int j = 0; j < nx; j++) if (use_exact) w->Hxx[k][i][j] += Hcv[i][j]; w->qx[k][i] = w->gX[k][i]; }
+        }
         if (k < N) {
             for (int i = 0; i < nu; i++) { for (int j = 0; j < nu; j++) w->Huu[k][i][j] = w->RW2[i][j]; w->qu[k][i] = w->gU[k][i]; for (int j = 0; j < nx; j++) w->Hux[k][i][j] = 0; }
             if (use_exact) {
@@ -494,8 +556,8 @@ int mmpc_oracle_solve(const oracle_cfg *cfg, const double *x_init, const double 
     w->cfg = cfg; w->N = cfg->N; w->M = cfg->M;
     w->nx = cfg->kind == 0 ? 9 : 6; w->nu = cfg->kind == 0 ? 5 : 2;
     int nx = w->nx, nu = w->nu, N = w->N;
-    w->nhs = (cfg->kind == 0 && cfg->L > 0) ? 6 : 0;
-    w->nrow = 2 * nu + 2 * nx + w->M + (cfg->kind == 0 ? 4 : 0) + w->nhs;
+    w->nhs = (cfg->kind == 0 && !cfg->pose_ref && cfg->L > 0) ? 6 : 0;
+    w->nrow = 2 * nu + 2 * nx + w->M + ((cfg->kind == 0 && !cfg->pose_ref) ? 4 : 0) + w->nhs;
     w->xinit = x_init; w->xref = traj_ref; w->uref = u_ref; w->ulast = u_last; w->obs = obs;
     for (int i = 0; i < nx; i++) for (int j = 0; j < nx; j++) {
         w->Q2[i][j] = cfg->Q[i * nx + j] + cfg->Q[j * nx + i]; w->P2[i][j] = cfg->P[i * nx + j] + cfg->P[j * nx + i]; }
@@ -521,11 +583,8 @@ int mmpc_oracle_solve(const oracle_cfg *cfg, const double *x_init, const double 
     for (it = 0; it <= cfg->max_iter; it++) {
         /* ---- evaluation at the current point */
         eval_rows(w, w->X, w->U, w->s, w->h, 1);
-        double e[NXM];
         for (int k = 0; k <= N; k++) {
-            const double *Wt2 = k < N ? &w->Q2[0][0] : &w->P2[0][0];
-            state_err(w, w->X[k], w->xref + k * nx, e);
-            for (int i = 0; i < nx; i++) { double v = 0; for (int j = 0; j < nx; j++) v += Wt2[i * NXM + j] * e[j]; w->gX[k][i] = v; }
+            state_cost(w, k, w->X[k], w->gX[k], 0, 0);
             w->gs[k] = 2 * cfg->S * w->s[k];
             if (k < N) {
                 for (int i = 0; i < nu; i++) {
@@ -728,7 +787,7 @@ int mmpc_oracle_solve_batch(const oracle_cfg *cfg, int B, const double *x_init, 
 #pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads > 0 ? nthreads : 1)
 #endif
     for (int b = 0; b < B; b++) {
-        status[b] = mmpc_oracle_solve(cfg, x_init + (size_t)b * nx, traj_ref + (size_t)b * (N + 1) * nx, u_ref + (size_t)b * N * nu,
+        status[b] = mmpc_oracle_solve(cfg, x_init + (size_t)b * nx, traj_ref + (size_t)b * (N + 1) * (cfg->pose_ref ? 4 : nx), u_ref + (size_t)b * N * nu,
                                       u_last + (size_t)b * N * nu, X0 ? X0 + (size_t)b * (N + 1) * nx : 0, 0, obs + (size_t)b * so_,
                                       Xo + (size_t)b * (N + 1) * nx, Uo + (size_t)b * N * nu, so + (size_t)b * (N + 1),
                                       iters + b, cost + b, err + b);

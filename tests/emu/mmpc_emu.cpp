@@ -24,7 +24,7 @@ static void run(const MmpcParams *P, int B, const double *x_init, const double *
         for (int i = 0; i < L.total; i++) lds[i] = NAN;
         MmpcIO io;
         io.x_init = x_init + (size_t)b * D::NX;
-        io.traj_ref = traj_ref + (size_t)b * (N + 1) * D::NX;
+        io.traj_ref = traj_ref + (size_t)b * (N + 1) * D::NREF;
         io.u_ref = u_ref + (size_t)b * N * D::NU;
         io.u_last = u_last + (size_t)b * N * D::NU;
         io.x_guess = x_guess ? x_guess + (size_t)b * (N + 1) * D::NX : nullptr;
@@ -89,11 +89,12 @@ extern "C" int mmpc_emu_solve(int kind, const MmpcParams *P, int B, const double
                               double *X, double *U, double *s, int *status, int *iters, double *cost, double *err,
                               int reverse) {
     if (kind == 0) run<0>(P, B, x_init, traj_ref, u_ref, u_last, x_guess, obs, X, U, s, status, iters, cost, err, reverse);
-    else run<1>(P, B, x_init, traj_ref, u_ref, u_last, x_guess, obs, X, U, s, status, iters, cost, err, reverse);
+    else if (kind == 1) run<1>(P, B, x_init, traj_ref, u_ref, u_last, x_guess, obs, X, U, s, status, iters, cost, err, reverse);
+    else run<2>(P, B, x_init, traj_ref, u_ref, u_last, x_guess, obs, X, U, s, status, iters, cost, err, reverse);
     return 0;
 }
 extern "C" int mmpc_emu_lds_doubles(int kind, int N, int M, int obs_per_stage) {
-    return kind == 0 ? mmpc_layout<0>(N, M, obs_per_stage).total : mmpc_layout<1>(N, M, obs_per_stage).total;
+    return kind == 0 ? mmpc_layout<0>(N, M, obs_per_stage).total : kind == 1 ? mmpc_layout<1>(N, M, obs_per_stage).total : mmpc_layout<2>(N, M, obs_per_stage).total;
 }
 extern "C" int mmpc_emu_params_size() { return (int)sizeof(MmpcParams); }
 

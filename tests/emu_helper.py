@@ -79,7 +79,8 @@ def solve_batch(par, x_init, traj_ref, u_ref, u_last, obs, x_guess=None, reverse
     X = np.zeros((B, N + 1, nx)); U = np.zeros((B, N, nu)); s = np.zeros((B, N + 1))
     status = np.zeros(B, np.int32); iters = np.zeros(B, np.int32); cost = np.zeros(B); err = np.zeros(B)
     fn = lib.mmpc_emu_solve_fast if fast else lib.mmpc_emu_solve
-    rc = fn(0 if par.kind == "wholebody" else 1, C.byref(prm), B, _p(x_init), _p(traj_ref), _p(u_ref),
+    kind = (2 if getattr(par, "pose_ref", False) else 0) if par.kind == "wholebody" else 1
+    rc = fn(kind, C.byref(prm), B, _p(x_init), _p(traj_ref), _p(u_ref),
                        _p(u_last), _p(x_guess), _p(obs), _p(X), _p(U), _p(s),
                        status.ctypes.data_as(C.POINTER(C.c_int)), iters.ctypes.data_as(C.POINTER(C.c_int)),
                        _p(cost), _p(err), int(reverse))

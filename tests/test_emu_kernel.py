@@ -8,7 +8,9 @@ import sys
 import numpy as np
 import pytest
 
-from oracle import nlp, coracle, synth
+from oracle import nlp, coracle, synth, ipm_numpy
+
+TOL = 1e-6
 import emu_helper
 
 
@@ -153,3 +155,41 @@ def test_emu_under_asan():
     env = dict(os.environ, LD_PRELOAD=libasan, ASAN_OPTIONS="detect_leaks=0")
     p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "ASAN-OK" in p.stdout, p.stderr[-3000:]
+
+
+def _pose_batch(B, N, seed=5):
+    rng = np.random.default_rng(seed)
+    x0 = np.zeros((B, 9)); ref = np.zeros((B, N + 1, 4)); obs = np.zeros((B, 2, 3))
+    for b in range(B):
+        x0[b] = [0, 0, rng.uniform(-1, 1), rng.uniform(0, 0.5), 0, 0, rng.uniform(-0.5, 0.5), rng.uniform(-2, -0.3), rng.uniform(0.3, 2.5)]
+        E0 = nlp.endpoint_pose(x0[b])
+        tgt = E0 + np.array([rng.uniform(0.5, 2), rng.uniform(-1, 1), rng.uniform(-0.2, 0.2), rng.uniform(-0.5, 0.5)])
+        ref[b] = np.linspace(E0, tgt, N + 1)
+        obs[b] = [[E0[0] + 0.5 * (tgt[0] - E0[0]), E0[1] + 0.5 * (tgt[1] - E0[1]) + 0.3, 0.3], [3, 3, 0.2]]
+    return x0, ref, obs
+
+
+def test_emu_pose_reference_controller():
+    """controllers/mpc_wholebody.py (endpoint-pose reference, KIND 2 of the generic kernel) vs the C and numpy oracles,
+    first solve and a warm-started second one (X and U initial guesses = previous optimum, :134-139)."""
+    N, B = 10, 6
+    par = nlp.pose_ref_params(N=N)
+    x0, ref, obs = _pose_batch(B, N)
+    ul = np.zeros((B, N, 5)); ur = np.zeros((B, N, 5))
+    o = coracle.solve_batch(par, x0, ref, ur, ul, obs)
+    e = emu_helper.solve_batch(par, x0, ref, ur, ul, obs)
+    er = emu_helper.solve_batch(par, x0, ref, ur, ul, obs, reverse=True)
+    assert (o["status"] == 0).all() and (e["status"] == 0).all()
+    assert np.abs(e["X"] - o["X"]).max() < TOL and np.abs(e["U"] - o["U"]).max() < TOL
+    assert np.array_equal(e["X"], er["X"])
+    prob = nlp.Problem(par, x0[0], ref[0], ur[0], ul[0], obs[0])
+    q = ipm_numpy.solve(prob)
+    assert np.abs(q["X"] - e["X"][0]).max() < TOL
+    k = nlp.kkt_certificate(prob, e["X"][0], e["U"][0], e["s"][0])
+    assert k["stationarity_rel"] < 1e-6 and k["eq_violation"] < 1e-9 and k["ineq_violation"] < 1e-9
+    # second tick: plant step, shifted reference, warm start of X and U
+    x1 = np.array([nlp.f_dyn("wholebody", x0[b], e["U"][b, 0], par.dt) for b in range(B)])
+    ref1 = np.concatenate([ref[:, 1:], ref[:, -1:]], axis=1)
+    o2 = coracle.solve_batch(par, x1, ref1, ur, e["U"], obs, X0=e["X"])
+    e2 = emu_helper.solve_batch(par, x1, ref1, ur, e["U"], obs, x_guess=e["X"])
+    assert (e2["status"] == 0).all() and np.abs(e2["X"] - o2["X"]).max() < TOL

@@ -258,3 +258,34 @@ def test_closed_loop_demo_state_machine(mm):
         assert (np.hypot(X[:, 0] - o.x, X[:, 1] - o.y) >= o.radius + 0.4 - 5e-3).all()   # soft rows (S = 1e5): mm-level slack
     assert np.linalg.norm(world.current_joints_pose[:3] - target[:3]) <= 0.01
     assert np.abs(X[-1, :2] - world.x_target[:2]).max() < 0.02
+
+
+@pytest.mark.gpu
+def test_pose_reference_controller(mm):
+    """controllers/mpc_wholebody.py (endpoint-pose reference): GPU (generic kernel, KIND 2) vs the C oracle on a batch,
+    a warm-started second tick, and the single-instance reference API."""
+    from oracle import coracle
+    N, B = 10, 64
+    par = nlp.pose_ref_params(N=N)
+    rng = np.random.default_rng(5)
+    x0 = np.zeros((B, 9)); ref = np.zeros((B, N + 1, 4)); obs = np.zeros((B, 2, 3))
+    for b in range(B):
+        x0[b] = [0, 0, rng.uniform(-1, 1), rng.uniform(0, 0.5), 0, 0, rng.uniform(-0.5, 0.5), rng.uniform(-2, -0.3), rng.uniform(0.3, 2.5)]
+        E0 = nlp.endpoint_pose(x0[b])
+        tgt = E0 + np.array([rng.uniform(0.5, 2), rng.uniform(-1, 1), rng.uniform(-0.2, 0.2), rng.uniform(-0.5, 0.5)])
+        ref[b] = np.linspace(E0, tgt, N + 1)
+        obs[b] = [[E0[0] + 0.5 * (tgt[0] - E0[0]), E0[1] + 0.5 * (tgt[1] - E0[1]) + 0.3, 0.3], [3, 3, 0.2]]
+    ur = np.zeros((B, N, 5))
+    ctrl = mm.MPCWholeBodyPoseRef(mm.MobileManipulator(0.1), [], N=N, max_batch=B, n_obstacles=2)
+    g = ctrl.solve_batch(x0, ref, ur, obs)
+    o = coracle.solve_batch(par, x0, ref, ur, np.zeros((B, N, 5)), obs, nthreads=4)
+    assert (g["status"] == 0).all() and (o["status"] == 0).all()
+    assert np.abs(g["X"] - o["X"]).max() < TOL and np.abs(g["U"] - o["U"]).max() < TOL
+    x1 = np.array([nlp.f_dyn("wholebody", x0[b], g["U"][b, 0], 0.1) for b in range(B)])
+    ref1 = np.concatenate([ref[:, 1:], ref[:, -1:]], axis=1)
+    g2 = ctrl.solve_batch(x1, ref1, ur, obs)                       # warm start kept in the handle (X and U)
+    o2 = coracle.solve_batch(par, x1, ref1, ur, o["U"], obs, X0=o["X"], nthreads=4)
+    assert (g2["status"] == 0).all() and np.abs(g2["X"] - o2["X"]).max() < 1e-5
+    one = mm.MPCWholeBodyPoseRef(mm.MobileManipulator(0.1), [mm.Obstacles(*obs[0, 0]), mm.Obstacles(*obs[0, 1])], N=N)
+    u0 = one.solve(x0[0].copy(), ref[0], ur[0])
+    assert np.abs(u0 - o["U"][0, 0]).max() < TOL and one.x_guess.shape == (N + 1, 9)
