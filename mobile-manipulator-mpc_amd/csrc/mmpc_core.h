@@ -38,7 +38,15 @@ struct MmpcEmu { int first, end, step; };
 // lane-derived address out of the solver's loops and the hoisted values alone exceed the register file.
 __device__ __forceinline__ int mmpc_lane_id() { int l = (int)threadIdx.x; asm volatile("" : "+v"(l)); return l; }
 #define LANES_BEGIN { const int lane = mmpc_lane_id();
+// End of a phase.  A workgroup is ONE wavefront, and the LDS unit executes the LDS instructions of a wavefront in issue
+// order: what one lane wrote in a phase is visible to every lane's reads of the next phase without waiting for the
+// writes to retire.  So no s_barrier and no s_waitcnt here - only a fence that keeps the COMPILER from moving memory
+// accesses across the phase boundary.  (-DMMPC_PHASE_SYNC restores the conservative __syncthreads() for A/B checks.)
+#ifdef MMPC_PHASE_SYNC
 #define LANES_END } __syncthreads();
+#else
+#define LANES_END } __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
 #define MMPC_EMU_ARG
 #endif
 
@@ -73,6 +81,9 @@ struct MmpcParams {
 // does not change the Newton step (constant on the constraint) but lets the exact Hessian be used whenever it is
 // positive definite ON the constraint (without it the recursion falls back to Gauss-Newton -> linear convergence)
 #define MMPC_RHO_EQ 1e4
+// bound push of the initial point (IPOPT's bound_push): a variable with a finite simple bound starts at least this far
+// inside it; the box rows are linear, so their slack then stays equal to the distance to the bound
+#define MMPC_BOUND_PUSH 1e-2
 
 // ---- structure of [A B] = d f / d(x,u) for the diff-drive base (+ integrator arm) -----------
 // robot_models/base.py:19-26, manipulator_3DoF.py:190.  Every column has at most 4 non-zeros.
@@ -170,6 +181,11 @@ struct MmpcIO {
 };
 
 MMPC_DEV double mmpc_min(double a, double b) { return a < b ? a : b; }
+MMPC_DEV double mmpc_bound_push(double v, double lo, double hi) {
+    double lo2 = lo + MMPC_BOUND_PUSH, hi2 = hi - MMPC_BOUND_PUSH;
+    if (lo2 > hi2) lo2 = hi2 = 0.5 * (lo + hi);
+    return v < lo2 ? lo2 : (v > hi2 ? hi2 : v);
+}
 MMPC_DEV double mmpc_max(double a, double b) { return a > b ? a : b; }
 MMPC_DEV bool mmpc_finite(double v) { return fabs(v) < 1.0e300; }
 
@@ -419,6 +435,23 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
     for (int i = lane; i < NS; i += MMPC_WAVE) S[i] = 0.0;  // :304
     if (lane < 4) NUEQ[lane] = 0.0;
     for (int i = lane; i < (P.obs_per_stage ? NS : 1) * M * 3; i += MMPC_WAVE) OBS[i] = io.obs[i];
+    LANES_END
+    // bound push of the initial point (needs U_last of the previous phase for the merged input box)
+    LANES_BEGIN
+    for (int i = lane; i < N * NU; i += MMPC_WAVE) {
+        const int k = i / NU, j = i % NU;
+        double lo, hi;
+        if (!box_bound(k, j, lo)) lo = -INFINITY;
+        if (!box_bound(k, NU + j, hi)) hi = INFINITY;
+        U[i] = mmpc_bound_push(U[i], lo, hi);
+    }
+    for (int i = lane + NX; i < NS * NX; i += MMPC_WAVE) {
+        const int k = i / NX, j = i % NX;
+        double lo, hi;
+        if (!box_bound(k, SL_XLO + j, lo)) lo = -INFINITY;
+        if (!box_bound(k, SL_XLO + NX + j, hi)) hi = INFINITY;
+        X[i] = mmpc_bound_push(X[i], lo, hi);
+    }
     LANES_END
 
     // value of the non-box rows of stage k at a point (used for slack init and line search)

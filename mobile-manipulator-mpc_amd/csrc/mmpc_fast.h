@@ -122,6 +122,10 @@ MMPC_DEV void mmpc_arm_segments_fast(double q1, double q2, double q3, double dr[
 MMPC_HD constexpr int mmpc_y(int a) { return a < 3 ? a : a + 3; }
 
 #define MMPC_B(x, q) (((x) >> (8 * (q))) & 255u)
+// slack of a box row = distance of the variable to its bound.  The fraction-to-boundary rule keeps it positive in exact
+// arithmetic ((1-tau) t with 1-tau down to 1e-9), but v + alpha dv is rounded to the grid of v (4e-16 near |v| = 2), so a
+// distance of that size can round to zero: floor it at a couple of ulps.
+MMPC_DEV double mmpc_box_t(double d) { return mmpc_max(d, 1e-15); }
 
 template <int KIND, int N>
 struct MmpcFastDims {
@@ -199,7 +203,9 @@ template <int KIND, int N, int MC>
 struct MmpcLaneState {
     typedef MmpcFastDims<KIND, N> F;
     // box pairs (stage, variable): index idx = lane + 64 p
-    double lo_t[F::NPASS], lo_z[F::NPASS], hi_t[F::NPASS], hi_z[F::NPASS];
+    // (only the multipliers: the initial point is pushed >= MMPC_BOUND_PUSH inside every finite bound and the box rows are
+    //  linear, so the slack of a box row IS the distance to its bound, t = v - lo / hi - v, for the whole solve)
+    double lo_z[F::NPASS], hi_z[F::NPASS];
     // circle rows of stage `lane`
     double ct[MC > 0 ? MC : 1], cz[MC > 0 ? MC : 1], cdt[MC > 0 ? MC : 1];
     // self-collision rows of stage `lane`
@@ -410,6 +416,16 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
     };
 
     double mu = P.mu_init;
+    // ------------------------------------------------------------------ bound push of the initial point (own phase: the
+    //                                                                    stage lanes below read what the pair lanes move)
+    LANES_BEGIN
+    for (int idx = lane; idx < NPAIR; idx += MMPC_WAVE) {
+        const int k = idx / NV, v = idx % NV;
+        double lo, hi; bool alo, ahi;
+        pair_bounds(k, v, lo, hi, alo, ahi);
+        if (alo || ahi) XU[idx] = mmpc_bound_push(XU[idx], alo ? lo : -INFINITY, ahi ? hi : INFINITY);
+    }
+    LANES_END
     // ------------------------------------------------------------------ slack / multiplier init
     LANES_BEGIN
     auto &ls = MMPC_LS;
@@ -417,14 +433,14 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
     for (int p = 0; p < NPASS; p++) {
         mmpc_sched_fence();
         const int idx = lane + MMPC_WAVE * p;
-        ls.lo_t[p] = 1.0; ls.lo_z[p] = 0.0; ls.hi_t[p] = 1.0; ls.hi_z[p] = 0.0;
+        ls.lo_z[p] = 0.0; ls.hi_z[p] = 0.0;
         if (idx < NPAIR) {
             const int k = idx / NV, v = idx % NV;
             double lo, hi; bool alo, ahi;
             pair_bounds(k, v, lo, hi, alo, ahi);
             const double val = XU[idx];
-            if (alo) { ls.lo_t[p] = mmpc_max(val - lo, 1e-2); ls.lo_z[p] = mu / ls.lo_t[p]; }
-            if (ahi) { ls.hi_t[p] = mmpc_max(hi - val, 1e-2); ls.hi_z[p] = mu / ls.hi_t[p]; }
+            if (alo) ls.lo_z[p] = mu / mmpc_box_t(val - lo);
+            if (ahi) ls.hi_z[p] = mu / mmpc_box_t(hi - val);
         }
     }
 #pragma unroll
@@ -597,13 +613,13 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                 }
                 double r = RB[idx] + g;
                 if (alo) {
-                    const double t = ls.lo_t[p], z = ls.lo_z[p], rh = (lo - val) + t;
-                    r -= z; e_p = mmpc_max(e_p, fabs(rh)); th += fabs(rh); la.mul(t);
+                    const double t = mmpc_box_t(val - lo), z = ls.lo_z[p];
+                    r -= z; la.mul(t);
                     tzmax = mmpc_max(tzmax, t * z); tzmin = mmpc_min(tzmin, t * z); zsum += z;
                 }
                 if (ahi) {
-                    const double t = ls.hi_t[p], z = ls.hi_z[p], rh = (val - hi) + t;
-                    r += z; e_p = mmpc_max(e_p, fabs(rh)); th += fabs(rh); la.mul(t);
+                    const double t = mmpc_box_t(hi - val), z = ls.hi_z[p];
+                    r += z; la.mul(t);
                     tzmax = mmpc_max(tzmax, t * z); tzmin = mmpc_min(tzmin, t * z); zsum += z;
                 }
                 RB[idx] = g;   // keep the plain cost gradient for the assembly / directional derivative
@@ -620,7 +636,11 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
         double sd = zsum / (nrows_act + (double)(NS * NX));
         sd = (sd > 100.0 ? sd : 100.0) / 100.0;
         E0 = mmpc_max(mmpc_max(err_d / sd, err_p), tzmax / sd);
-        if (!(E0 == E0) || !mmpc_finite(E0)) { status = 2; break; }
+        if (!(E0 == E0) || !mmpc_finite(E0)) {
+#ifdef MMPC_EMU_DEBUG
+            fprintf(stderr, "E0 nan it %d: err_d %g err_p %g tzmax %g tzmin %g zsum %g sumlog %g\n", it, err_d, err_p, tzmax, tzmin, zsum, sumlog);
+#endif
+            status = 2; break; }
         if (E0 <= tol) { status = 0; break; }
         if (it == P.max_iter) break;
         {
@@ -781,8 +801,8 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                     pair_bounds(k, v, lo, hi, alo, ahi);
                     const double val = XU[idx];
                     double wsum = 0.0, gsum = 0.0;
-                    if (alo) { const double t = ls.lo_t[p], z = ls.lo_z[p], it_ = mmpc_rcp(t), w = z * it_; wsum += w; gsum -= mu * it_ + w * ((lo - val) + t); }
-                    if (ahi) { const double t = ls.hi_t[p], z = ls.hi_z[p], it_ = mmpc_rcp(t), w = z * it_; wsum += w; gsum += mu * it_ + w * ((val - hi) + t); }
+                    if (alo) { const double it_ = mmpc_rcp(mmpc_box_t(val - lo)); wsum += ls.lo_z[p] * it_; gsum -= mu * it_; }
+                    if (ahi) { const double it_ = mmpc_rcp(mmpc_box_t(hi - val)); wsum += ls.hi_z[p] * it_; gsum += mu * it_; }
                     if (alo || ahi) {
                         QXU[idx] += gsum;
                         if (v < NX) HXX[k * NXX + v * (v + 1) / 2 + v] += wsum;
@@ -923,7 +943,11 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
             if (lane == 0) MISC[0] = 0.0;
             LANES_END
         }
-        if (failed) { status = 2; break; }
+        if (failed) {
+#ifdef MMPC_EMU_DEBUG
+            fprintf(stderr, "riccati failed twice it %d\n", it);
+#endif
+            status = 2; break; }
         MMPC_TS(8)
         // ---- forward roll-out, one phase per stage: lane i < NX computes dx_{k+1}[i]; the lanes whose
         //      dynamics row carries an input also produce that input step (base.py:19-26)
@@ -1051,13 +1075,13 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                 if (v >= NX && k < N) g += CST[MMPC_C_WW + v - NX] * (val - ULAST[k * NU + v - NX]);
                 dphi += g * dv;
                 if (alo) {
-                    const double t = ls.lo_t[p], z = ls.lo_z[p], dtv = -((lo - val) + t) + dv, it_ = mmpc_rcp(t), dzv = mu * it_ - z - z * it_ * dtv;
+                    const double t = mmpc_box_t(val - lo), z = ls.lo_z[p], dtv = dv, it_ = mmpc_rcp(t), dzv = mu * it_ - z - z * it_ * dtv;
                     if (dtv < 0) ap = mmpc_min(ap, -tau * t * mmpc_rcp(dtv));
                     if (dzv < 0) ad = mmpc_min(ad, -tau * z * mmpc_rcp(dzv));
                     dphi -= mu * dtv * it_;
                 }
                 if (ahi) {
-                    const double t = ls.hi_t[p], z = ls.hi_z[p], dtv = -((val - hi) + t) - dv, it_ = mmpc_rcp(t), dzv = mu * it_ - z - z * it_ * dtv;
+                    const double t = mmpc_box_t(hi - val), z = ls.hi_z[p], dtv = -dv, it_ = mmpc_rcp(t), dzv = mu * it_ - z - z * it_ * dtv;
                     if (dtv < 0) ap = mmpc_min(ap, -tau * t * mmpc_rcp(dtv));
                     if (dzv < 0) ad = mmpc_min(ad, -tau * z * mmpc_rcp(dzv));
                     dphi -= mu * dtv * it_;
@@ -1135,14 +1159,8 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                     if (KIND == 1 && v == 2) e = mmpc_angle_diff(val, XUREF[idx]);
                     phi += 0.5 * w_diag(k, v) * e * e;
                     if (v >= NX && k < N) { const double e2 = val - ULAST[k * NU + v - NX]; phi += 0.5 * CST[MMPC_C_WW + v - NX] * e2 * e2; }
-                    if (alo) {
-                        const double t0 = ls.lo_t[p], tv = t0 + alpha * (-((lo - v0) + t0) + dv);
-                        th += fabs((lo - val) + tv); la.mul(tv);
-                    }
-                    if (ahi) {
-                        const double t0 = ls.hi_t[p], tv = t0 + alpha * (-((v0 - hi) + t0) - dv);
-                        th += fabs((val - hi) + tv); la.mul(tv);
-                    }
+                    if (alo) la.mul(mmpc_box_t(val - lo));
+                    if (ahi) la.mul(mmpc_box_t(hi - val));
                 }
             }
             phi -= mu * la.value();
@@ -1209,14 +1227,8 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                 double lo, hi; bool alo, ahi;
                 pair_bounds(k, v, lo, hi, alo, ahi);
                 const double val = XU[idx], dv = DXU[idx];
-                if (alo) {
-                    const double t = ls.lo_t[p], z = ls.lo_z[p], dtv = -((lo - val) + t) + dv, it_ = mmpc_rcp(t), dzv = mu * it_ - z - z * it_ * dtv;
-                    ls.lo_t[p] = t + alpha * dtv; ls.lo_z[p] = z + ad * dzv;
-                }
-                if (ahi) {
-                    const double t = ls.hi_t[p], z = ls.hi_z[p], dtv = -((val - hi) + t) - dv, it_ = mmpc_rcp(t), dzv = mu * it_ - z - z * it_ * dtv;
-                    ls.hi_t[p] = t + alpha * dtv; ls.hi_z[p] = z + ad * dzv;
-                }
+                if (alo) { const double z = ls.lo_z[p], it_ = mmpc_rcp(mmpc_box_t(val - lo)); ls.lo_z[p] = z + ad * (mu * it_ - z - z * it_ * dv); }
+                if (ahi) { const double z = ls.hi_z[p], it_ = mmpc_rcp(mmpc_box_t(hi - val)); ls.hi_z[p] = z + ad * (mu * it_ - z + z * it_ * dv); }
             }
         }
         LANES_END

@@ -52,6 +52,7 @@ class Options:
     delta0 = 1e-4
     delta_min = 1e-20
     delta_max = 1e10
+    bound_push = 1e-2
     rho_eq = 1e4          # augmentation weight of the terminal-xy equality inside the factorisation
 
 
@@ -130,6 +131,16 @@ class State:
     pass
 
 
+def _bound_push(v, lo, hi, kap):
+    """clip v into [lo + kap, hi - kap]; a box narrower than 2 kap collapses to its midpoint"""
+    lo2, hi2 = lo + kap, hi - kap
+    with np.errstate(invalid="ignore"):
+        mid = 0.5 * (lo + hi)            # (nan for a free variable: never selected)
+    narrow = lo2 > hi2
+    lo2 = np.where(narrow, mid, lo2); hi2 = np.where(narrow, mid, hi2)
+    return np.minimum(np.maximum(v, lo2), hi2)
+
+
 def _eval_all(prob, rows, X, U, s, order):
     out = []
     for k in range(prob.par.N + 1):
@@ -171,6 +182,16 @@ def solve(prob: nlp.Problem, U0=None, X0=None, opt: Options = None, verbose=Fals
     U = np.zeros((N, nu)) if U0 is None else np.array(U0, float)
     s = np.zeros(N + 1)
     lam = np.zeros((N + 1, nx))      # lam[k+1]: multiplier of x_{k+1} - f(x_k,u_k) = 0
+    # bound push (IPOPT's treatment of the initial point, bound_push = 1e-2): a variable with a finite simple bound
+    # starts at least kappa inside it.  The box rows are linear, so their slack then equals the distance to the bound
+    # for the whole solve (t = v - lo), which is what lets the GPU kernel keep no slack state for them.
+    for k in range(N + 1):
+        if k < N:
+            lo = np.maximum(p.ulim[0], prob.u_last[k] + p.dulim[0])
+            hi = np.minimum(p.ulim[1], prob.u_last[k] + p.dulim[1])
+            U[k] = _bound_push(U[k], lo, hi, opt.bound_push)
+        if k >= 1:
+            X[k] = _bound_push(X[k], p.xlim[0], p.xlim[1], opt.bound_push)
     rows = [_rows_for_stage(prob, k) for k in range(N + 1)]
     mu = opt.mu_init
     # slacks / multipliers

@@ -238,6 +238,13 @@ static const double *obs_at(const work *w, int k, int m) {
 
 static int slack_idx(const work *w, int k) { return k < w->N - 1 ? k : w->N - 1; } /* :265 quirk */
 
+#define BOUND_PUSH 1e-2
+static double bound_push(double v, double lo, double hi) {
+    double lo2 = lo + BOUND_PUSH, hi2 = hi - BOUND_PUSH;
+    if (lo2 > hi2) lo2 = hi2 = 0.5 * (lo + hi);
+    return v < lo2 ? lo2 : (v > hi2 ? hi2 : v);
+}
+
 static void setup_rows(work *w) {
     const oracle_cfg *c = w->cfg;
     for (int k = 0; k <= w->N; k++) {
@@ -569,6 +576,15 @@ int mmpc_oracle_solve(const oracle_cfg *cfg, const double *x_init, const double 
         w->s[k] = 0;
     }
     setup_rows(w);
+    /* bound push of the initial point (see oracle/ipm_numpy.py): finite simple bounds are kept >= BOUND_PUSH away */
+    for (int k = 0; k <= N; k++) {
+        if (k < N) for (int j = 0; j < nu; j++)
+            w->U[k][j] = bound_push(w->U[k][j], w->act[k][SL_ULO(w, j)] ? w->bnd[k][SL_ULO(w, j)] : -INFINITY,
+                                    w->act[k][SL_UHI(w, j)] ? w->bnd[k][SL_UHI(w, j)] : INFINITY);
+        if (k >= 1) for (int j = 0; j < nx; j++)
+            w->X[k][j] = bound_push(w->X[k][j], w->act[k][SL_XLO(w, j)] ? w->bnd[k][SL_XLO(w, j)] : -INFINITY,
+                                    w->act[k][SL_XHI(w, j)] ? w->bnd[k][SL_XHI(w, j)] : INFINITY);
+    }
     double mu = cfg->mu_init;
     eval_rows(w, w->X, w->U, w->s, w->h, 0);
     int nrows_act = 0;
