@@ -89,7 +89,11 @@ MMPC_DEV double mmpc_rsqrt(double x) {
 // x^e in single precision (only used by the filter's switching rule, a heuristic threshold)
 MMPC_DEV double mmpc_powf(double x, float e) { return (double)__builtin_amdgcn_exp2f(e * __builtin_amdgcn_logf((float)x)); }
 // keeps the scheduler from interleaving independent unrolled bodies (bounds the live registers)
+#ifdef MMPC_NO_SCHED_FENCE
+MMPC_DEV void mmpc_sched_fence() {}
+#else
 MMPC_DEV void mmpc_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+#endif
 #endif
 // natural log of a product of mantissas m in (0,1]: renormalise to [sqrt(1/2), sqrt(2)), then
 // log m = 2 atanh(s), s = (m-1)/(m+1), |s| < 0.1716, odd series to s^21 (< 1e-17)
@@ -206,6 +210,8 @@ struct MmpcLaneState {
     // (only the multipliers: the initial point is pushed >= MMPC_BOUND_PUSH inside every finite bound and the box rows are
     //  linear, so the slack of a box row IS the distance to its bound, t = v - lo / hi - v, for the whole solve)
     double lo_z[F::NPASS], hi_z[F::NPASS];
+    // the bounds themselves (constant during a solve: the merged input box uses U_last); -+1e300 marks an absent side
+    double b_lo[F::NPASS], b_hi[F::NPASS];
     // circle rows of stage `lane`
     double ct[MC > 0 ? MC : 1], cz[MC > 0 ? MC : 1], cdt[MC > 0 ? MC : 1];
     // self-collision rows of stage `lane`
@@ -433,14 +439,14 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
     for (int p = 0; p < NPASS; p++) {
         mmpc_sched_fence();
         const int idx = lane + MMPC_WAVE * p;
-        ls.lo_z[p] = 0.0; ls.hi_z[p] = 0.0;
+        ls.lo_z[p] = 0.0; ls.hi_z[p] = 0.0; ls.b_lo[p] = -1e300; ls.b_hi[p] = 1e300;
         if (idx < NPAIR) {
             const int k = idx / NV, v = idx % NV;
             double lo, hi; bool alo, ahi;
             pair_bounds(k, v, lo, hi, alo, ahi);
             const double val = XU[idx];
-            if (alo) ls.lo_z[p] = mu / mmpc_box_t(val - lo);
-            if (ahi) ls.hi_z[p] = mu / mmpc_box_t(hi - val);
+            if (alo) { ls.b_lo[p] = lo; ls.lo_z[p] = mu / mmpc_box_t(val - lo); }
+            if (ahi) { ls.b_hi[p] = hi; ls.hi_z[p] = mu / mmpc_box_t(hi - val); }
         }
     }
 #pragma unroll
@@ -598,8 +604,8 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
             const int idx = lane + MMPC_WAVE * p;
             if (idx < NPAIR) {
                 const int k = idx / NV, v = idx % NV;
-                double lo, hi; bool alo, ahi;
-                pair_bounds(k, v, lo, hi, alo, ahi);
+                const double lo = ls.b_lo[p], hi = ls.b_hi[p];
+                const bool alo = lo > -1e299, ahi = hi < 1e299;
                 const double val = XU[idx];
                 // cost gradient / value (diagonal weights): mpc_wholebody_qref.py:192-201,240-242
                 double e = val - XUREF[idx];
@@ -797,8 +803,8 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                 const int idx = lane + MMPC_WAVE * p;
                 if (idx < NPAIR) {
                     const int k = idx / NV, v = idx % NV;
-                    double lo, hi; bool alo, ahi;
-                    pair_bounds(k, v, lo, hi, alo, ahi);
+                    const double lo = ls.b_lo[p], hi = ls.b_hi[p];
+                    const bool alo = lo > -1e299, ahi = hi < 1e299;
                     const double val = XU[idx];
                     double wsum = 0.0, gsum = 0.0;
                     if (alo) { const double it_ = mmpc_rcp(mmpc_box_t(val - lo)); wsum += ls.lo_z[p] * it_; gsum -= mu * it_; }
@@ -1066,8 +1072,8 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
             const int idx = lane + MMPC_WAVE * p;
             if (idx < NPAIR) {
                 const int k = idx / NV, v = idx % NV;
-                double lo, hi; bool alo, ahi;
-                pair_bounds(k, v, lo, hi, alo, ahi);
+                const double lo = ls.b_lo[p], hi = ls.b_hi[p];
+                const bool alo = lo > -1e299, ahi = hi < 1e299;
                 const double val = XU[idx], dv = DXU[idx];
                 double e = val - XUREF[idx];
                 if (KIND == 1 && v == 2) e = mmpc_angle_diff(val, XUREF[idx]);
@@ -1152,8 +1158,8 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                 const int idx = lane + MMPC_WAVE * p;
                 if (idx < NPAIR) {
                     const int k = idx / NV, v = idx % NV;
-                    double lo, hi; bool alo, ahi;
-                    pair_bounds(k, v, lo, hi, alo, ahi);
+                    const double lo = ls.b_lo[p], hi = ls.b_hi[p];
+                    const bool alo = lo > -1e299, ahi = hi < 1e299;
                     const double v0 = XU[idx], dv = DXU[idx], val = v0 + alpha * dv;
                     double e = val - XUREF[idx];
                     if (KIND == 1 && v == 2) e = mmpc_angle_diff(val, XUREF[idx]);
@@ -1224,8 +1230,8 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
             const int idx = lane + MMPC_WAVE * p;
             if (idx < NPAIR) {
                 const int k = idx / NV, v = idx % NV;
-                double lo, hi; bool alo, ahi;
-                pair_bounds(k, v, lo, hi, alo, ahi);
+                const double lo = ls.b_lo[p], hi = ls.b_hi[p];
+                const bool alo = lo > -1e299, ahi = hi < 1e299;
                 const double val = XU[idx], dv = DXU[idx];
                 if (alo) { const double z = ls.lo_z[p], it_ = mmpc_rcp(mmpc_box_t(val - lo)); ls.lo_z[p] = z + ad * (mu * it_ - z - z * it_ * dv); }
                 if (ahi) { const double z = ls.hi_z[p], it_ = mmpc_rcp(mmpc_box_t(hi - val)); ls.hi_z[p] = z + ad * (mu * it_ - z + z * it_ * dv); }
