@@ -172,7 +172,7 @@ typedef double MmpcAcc __attribute__((ext_vector_type(4)));
 
 struct MmpcFastLayout {
     int XU, S, LAM, XUREF, ULAST, OBS, CST, CV, CD, TRG, HXX, QXU, HUXL, HUUL, HUX02, HUUD, SN, KK, KF, DXU, DS, DLAM,
-        GS, DUMP, FILT, MISC, total;
+        GS, DUMP, RB, RDS, FILT, MISC, total;
 };
 // constants block (CST) offsets
 #define MMPC_C_XLIM 0      // [2][9]
@@ -197,7 +197,11 @@ MMPC_HD MmpcFastLayout mmpc_fast_layout(int M, int obs_per_stage) {
     MMPC_CARVE(HXX, F::NS * F::NXX) MMPC_CARVE(QXU, F::NS * F::NV) MMPC_CARVE(HUXL, F::NU * F::NX)
     MMPC_CARVE(HUUL, F::NUU) MMPC_CARVE(HUX02, F::NS) MMPC_CARVE(HUUD, F::NS * F::NU) MMPC_CARVE(SN, 16)
     MMPC_CARVE(KK, N * F::NU * F::NX) MMPC_CARVE(KF, N * F::NU) MMPC_CARVE(DXU, F::NS * F::NV) MMPC_CARVE(DS, F::NS)
-    MMPC_CARVE(DLAM, F::NS * F::NX) MMPC_CARVE(GS, 256) MMPC_CARVE(DUMP, MMPC_WAVE) MMPC_CARVE(FILT, 2 * MMPC_FCAP) MMPC_CARVE(MISC, 8)
+    MMPC_CARVE(DLAM, F::NS * F::NX) MMPC_CARVE(RB, F::NS * F::NV) MMPC_CARVE(RDS, F::NS) MMPC_CARVE(FILT, 2 * MMPC_FCAP)
+    // scratch of the backward pass lives, where it fits, in arrays that are dead while it runs: the 16x16 exchange tile in
+    // the search direction (written by the forward roll-out afterwards), the dump slots in the multiplier step (D1)
+    if (F::NS * F::NV >= 256) L.GS = L.DXU; else { MMPC_CARVE(GS, 256) }
+    if (F::NS * F::NX >= MMPC_WAVE) L.DUMP = L.DLAM; else { MMPC_CARVE(DUMP, MMPC_WAVE) } MMPC_CARVE(MISC, 8)
 #undef MMPC_CARVE
     L.total = o;
     return L;
@@ -291,7 +295,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
            *QXU = lds + L.QXU, *HUXL = lds + L.HUXL, *HUUL = lds + L.HUUL, *HUX02 = lds + L.HUX02,
            *HUUD = lds + L.HUUD, *SN = lds + L.SN, *KK = lds + L.KK, *KF = lds + L.KF, *DXU = lds + L.DXU,
            *DS = lds + L.DS, *DLAM = lds + L.DLAM, *GS = lds + L.GS, *FILT = lds + L.FILT, *MISC = lds + L.MISC;
-    double *const RB = DXU;   // residual base r[k][v] (alias: dead while DXU is not)
+    double *const RB = lds + L.RB, *const RDS = lds + L.RDS;   // residual base r[k][v] and the s_k residual of the current point
     const double dt = P.dt, Sw = P.S, tol = P.tol;
 #ifdef MMPC_EMU
     static thread_local MmpcLaneState<KIND, N, MC> ls_all[MMPC_WAVE];
@@ -485,10 +489,58 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
 
     int status = 1, it = 0, nfilt = 0, filt_init = 0;
     double E0 = 0.0, th_max = 0.0, th_min = 0.0;
+    // results of the evaluation of the current point (iterate or line-search trial)
+    double err_d = 0.0, err_p = 0.0, tzmax = 0.0, tzmin = 0.0, zsum = 0.0, cost_c = 0.0, th_c = 0.0, sumlog = 0.0;
+    // line-search state: the evaluation of a trial point IS the evaluation the next iteration starts from (98.6 % of the
+    // first trials are accepted), so the loop below evaluates once per trial and never a second time for the accepted one
+    int in_ls = 0, lspass = 0, lsi = 0;
+    double alpha = 0.0, ap = 1.0, ad = 1.0, dphi = 0.0, phi0 = 0.0, th0 = 0.0;
+
+    // ---- move to a trial point: the primal variables, the equality multipliers and the slacks of the nonlinear rows by
+    //      d_alpha times the direction (signed: a rejected trial is moved back by the difference); with `first` also the
+    //      row multipliers by alpha_d (they do not depend on alpha; evaluated with the slacks of the point the step starts at)
+    auto apply_step = [&](double d_alpha, bool first) {
+        LANES_BEGIN
+        auto &ls = MMPC_LS;
+        if (lane < NS) {
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                const double t = ls.ct[m], z = ls.cz[m], dtv = ls.cdt[m];
+                if (first) { const double it_ = mmpc_rcp(t); ls.cz[m] = z + ad * (mu * it_ - z - z * it_ * dtv); }
+                ls.ct[m] = t + d_alpha * dtv;
+            }
+#pragma unroll
+            for (int i = 0; i < NSELF; i++) {
+                const double t = ls.st[i], z = ls.sz[i], dtv = ls.sdt[i];
+                if (first) { const double it_ = mmpc_rcp(t); ls.sz[i] = z + ad * (mu * it_ - z - z * it_ * dtv); }
+                ls.st[i] = t + d_alpha * dtv;
+            }
+        }
+        if (first) {
+#pragma unroll
+            for (int p = 0; p < NPASS; p++) {
+                mmpc_sched_fence();
+                const int idx = lane + MMPC_WAVE * p;
+                if (idx < NPAIR) {
+                    const double lo = ls.b_lo[p], hi = ls.b_hi[p];
+                    const bool alo = lo > -1e299, ahi = hi < 1e299;
+                    const double val = XU[idx], dv = DXU[idx];
+                    if (alo) { const double z = ls.lo_z[p], it_ = mmpc_rcp(mmpc_box_t(val - lo)); ls.lo_z[p] = z + ad * (mu * it_ - z - z * it_ * dv); }
+                    if (ahi) { const double z = ls.hi_z[p], it_ = mmpc_rcp(mmpc_box_t(hi - val)); ls.hi_z[p] = z + ad * (mu * it_ - z + z * it_ * dv); }
+                }
+            }
+        }
+        LANES_END
+        LANES_BEGIN
+        for (int i = lane; i < NPAIR; i += MMPC_WAVE) if (i >= NX) XU[i] += d_alpha * DXU[i];   // x_0 is data
+        for (int i = lane; i < NS * NX; i += MMPC_WAVE) if (i >= NX) LAM[i] += d_alpha * DLAM[i];
+        for (int i = lane; i < NS; i += MMPC_WAVE) S[i] += d_alpha * DS[i];
+        LANES_END
+    };
 
     MMPC_T0()
 #pragma unroll 1
-    for (it = 0; it <= P.max_iter; it++) {
+    for (;;) {
         MMPC_TS(0)
         // ============================================================ E1 (stage lanes)
         LANES_BEGIN
@@ -584,7 +636,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
             }
             if (k < N) rds -= selfz;
             slog = la.value();
-            DS[k] = rds;
+            RDS[k] = rds;
 #pragma unroll
             for (int j = 0; j < NV; j++) RB[k * NV + j] = rb[j];
         }
@@ -634,11 +686,40 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
             }
         }
         MMPC_WR(7) += la.value();   // sum of log t over all rows (the barrier term is applied after the mu update)
-        if (lane < NS) e_d = mmpc_max(e_d, fabs(DS[lane] - (lane == N - 1 ? SN[3] : 0.0)));
+        if (lane < NS) e_d = mmpc_max(e_d, fabs(RDS[lane] - (lane == N - 1 ? SN[3] : 0.0)));
         MMPC_WR(0) = e_d; MMPC_WR(1) = e_p; MMPC_WR(2) = tzmax; MMPC_WR(3) = tzmin; MMPC_WR(4) = zsum; MMPC_WR(5) = phi; MMPC_WR(6) = th;
         LANES_END
-        const double err_d = MMPC_RED_MAX(0), err_p = MMPC_RED_MAX(1), tzmax = MMPC_RED_MAX(2), tzmin = MMPC_RED_MIN(3),
-                     zsum = MMPC_RED_SUM(4), cost0 = MMPC_RED_SUM(5), th0 = MMPC_RED_SUM(6), sumlog = MMPC_RED_SUM(7);
+        err_d = MMPC_RED_MAX(0); err_p = MMPC_RED_MAX(1); tzmax = MMPC_RED_MAX(2); tzmin = MMPC_RED_MIN(3);
+        zsum = MMPC_RED_SUM(4); cost_c = MMPC_RED_SUM(5); th_c = MMPC_RED_SUM(6); sumlog = MMPC_RED_SUM(7);
+        if (in_ls) {
+            // ---- filter test of the trial point just evaluated (Waechter-Biegler; + filter reset heuristic)
+            const double phi = cost_c - mu * sumlog, th = th_c;
+            bool okf = th < th_max;
+            for (int i = 0; i < nfilt && okf; i++) if (th >= FILT[2 * i] && phi >= FILT[2 * i + 1]) okf = false;
+            const bool ftype = dphi < 0 && th0 <= th_min && alpha * mmpc_powf(-dphi, 2.3f) > mmpc_powf(th0, 1.1f);
+            bool accepted = false, augment = false;
+            if (okf) {
+                if (ftype) accepted = phi <= phi0 + 1e-8 * alpha * dphi + 1e-14 * fabs(phi0);
+                else if (th <= (1 - 1e-5) * th0 || phi <= phi0 - 1e-5 * th0) { accepted = true; augment = true; }
+            }
+            if (augment) {
+                int slot = nfilt;
+                if (nfilt >= MMPC_FCAP) { slot = 0; for (int i = 1; i < MMPC_FCAP; i++) if (FILT[2 * i] > FILT[2 * slot]) slot = i; }
+                else nfilt++;
+                LANES_BEGIN
+                if (lane == 0) { FILT[2 * slot] = (1 - 1e-5) * th0; FILT[2 * slot + 1] = phi0 - 1e-5 * th0; }
+                LANES_END
+            }
+            if (!accepted) {
+                double anext = alpha;
+                bool retry = false;
+                if (lsi < MMPC_MAX_LS - 1) { anext = 0.5 * alpha; lsi++; retry = true; }
+                else if (lspass == 0 && nfilt > 0) { nfilt = 0; lspass = 1; lsi = 0; anext = ap; retry = true; }   // filter reset heuristic
+                if (retry) { apply_step(anext - alpha, false); alpha = anext; continue; }
+            }
+            in_ls = 0;   // accepted (or every trial rejected: the last one is kept, as IPOPT without restoration would stall too)
+            MMPC_TS(12)
+        }
         double sd = zsum / (nrows_act + (double)(NS * NX));
         sd = (sd > 100.0 ? sd : 100.0) / 100.0;
         E0 = mmpc_max(mmpc_max(err_d / sd, err_p), tzmax / sd);
@@ -660,7 +741,8 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
             }
             if (changed) filt_init = 0;
         }
-        const double phi0 = cost0 - mu * sumlog;   // barrier objective at the current point for the (possibly new) mu
+        phi0 = cost_c - mu * sumlog;   // barrier objective at the current point for the (possibly new) mu
+        th0 = th_c;
 
         MMPC_TS(2)
         // ============================================================ Newton direction
@@ -1096,153 +1178,15 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
         }
         MMPC_WR(0) = ap; MMPC_WR(1) = ad; MMPC_WR(2) = dphi;
         LANES_END
-        const double ap = MMPC_RED_MIN(0), ad = MMPC_RED_MIN(1), dphi = MMPC_RED_SUM(2);
+        ap = MMPC_RED_MIN(0); ad = MMPC_RED_MIN(1); dphi = MMPC_RED_SUM(2);
 
         MMPC_TS(11)
-        // ---- merit of a trial point w + alpha dw (stage lanes + pair lanes in one phase)
-        auto merit_pass = [&](double alpha, double &phi_out, double &th_out) {
-            LANES_BEGIN
-            auto &ls = MMPC_LS;
-            double phi = 0.0, th = 0.0;
-            MmpcLogAcc la; la.init();
-            if (lane < NS) {
-                const int k = lane;
-                double xk[NX];
-#pragma unroll
-                for (int j = 0; j < NX; j++) xk[j] = XU[k * NV + j] + alpha * DXU[k * NV + j];
-                const double sk = S[k] + alpha * DS[k];
-                const int ks = slack_idx(k);
-                const double sks = S[ks] + alpha * DS[ks];
-                phi += Sw * sk * sk;
-                double sn, cs;
-                mmpc_sincos(xk[2], &sn, &cs);
-                if (k < N) {
-                    double uk[NU];
-#pragma unroll
-                    for (int a = 0; a < NU; a++) uk[a] = XU[k * NV + NX + a] + alpha * DXU[k * NV + NX + a];
-                    const double *x1 = XU + (k + 1) * NV, *d1 = DXU + (k + 1) * NV;
-                    th += fabs(xk[0] + dt * xk[3] - (x1[0] + alpha * d1[0]));
-                    th += fabs(xk[1] + dt * xk[4] - (x1[1] + alpha * d1[1]));
-                    th += fabs(xk[2] + dt * xk[5] - (x1[2] + alpha * d1[2]));
-                    th += fabs(xk[3] + dt * (uk[0] * cs - xk[4] * xk[5]) - (x1[3] + alpha * d1[3]));
-                    th += fabs(xk[4] + dt * (uk[0] * sn + xk[3] * xk[5]) - (x1[4] + alpha * d1[4]));
-                    th += fabs(xk[5] + dt * uk[1] - (x1[5] + alpha * d1[5]));
-                    if (KIND == 0) {
-                        th += fabs(xk[6] + dt * uk[2] - (x1[6] + alpha * d1[6]));
-                        th += fabs(xk[7] + dt * uk[3] - (x1[7] + alpha * d1[7]));
-                        th += fabs(xk[8] + dt * uk[4] - (x1[8] + alpha * d1[8]));
-                    }
-                }
-#pragma unroll
-                for (int m = 0; m < M; m++) {
-                    const double *o = obs_ptr(k, m);
-                    const double dx = xk[0] - o[0], dy = xk[1] - o[1];
-                    const double h = (o[2] + MMPC_BASE_R) - sqrt(dx * dx + dy * dy) - sk;
-                    const double tv = ls.ct[m] + alpha * ls.cdt[m];
-                    th += fabs(h + tv); la.mul(tv);
-                }
-                if (NSELF) {
-                    double dr[3], dz[3];
-                    mmpc_arm_segments_fast(xk[NX - 3], xk[NX - 2], xk[NX - 1], dr, dz);
-#pragma unroll
-                    for (int i = 0; i < NSELF; i++) {
-                        const double h = mmpc_self_row(i, xk[0], xk[1], cs, sn, dr, dz, nullptr) - sks;
-                        const double tv = ls.st[i] + alpha * ls.sdt[i];
-                        th += fabs(h + tv); la.mul(tv);
-                    }
-                }
-            }
-#pragma unroll
-            for (int p = 0; p < NPASS; p++) {
-                mmpc_sched_fence();
-                const int idx = lane + MMPC_WAVE * p;
-                if (idx < NPAIR) {
-                    const int k = idx / NV, v = idx % NV;
-                    const double lo = ls.b_lo[p], hi = ls.b_hi[p];
-                    const bool alo = lo > -1e299, ahi = hi < 1e299;
-                    const double v0 = XU[idx], dv = DXU[idx], val = v0 + alpha * dv;
-                    double e = val - XUREF[idx];
-                    if (KIND == 1 && v == 2) e = mmpc_angle_diff(val, XUREF[idx]);
-                    phi += 0.5 * w_diag(k, v) * e * e;
-                    if (v >= NX && k < N) { const double e2 = val - ULAST[k * NU + v - NX]; phi += 0.5 * CST[MMPC_C_WW + v - NX] * e2 * e2; }
-                    if (alo) la.mul(mmpc_box_t(val - lo));
-                    if (ahi) la.mul(mmpc_box_t(hi - val));
-                }
-            }
-            phi -= mu * la.value();
-            MMPC_WR(0) = phi; MMPC_WR(1) = th;
-            LANES_END
-            phi_out = MMPC_RED_SUM(0);
-            th_out = MMPC_RED_SUM(1);
-        };
         if (!filt_init) { nfilt = 0; th_max = 1e4 * mmpc_max(1.0, th0); th_min = 1e-4 * mmpc_max(1.0, th0); filt_init = 1; }
-
-        // ---- filter line search (+ filter reset heuristic)
-        double alpha = ap;
-        int lspass = 0, lsi = 0;
-#pragma unroll 1
-        for (;;) {
-            double phi, th;
-            merit_pass(alpha, phi, th);
-            bool okf = th < th_max;
-            for (int i = 0; i < nfilt && okf; i++) if (th >= FILT[2 * i] && phi >= FILT[2 * i + 1]) okf = false;
-            const bool ftype = dphi < 0 && th0 <= th_min && alpha * mmpc_powf(-dphi, 2.3f) > mmpc_powf(th0, 1.1f);
-            bool accepted = false, augment = false;
-            if (okf) {
-                if (ftype) accepted = phi <= phi0 + 1e-8 * alpha * dphi + 1e-14 * fabs(phi0);
-                else if (th <= (1 - 1e-5) * th0 || phi <= phi0 - 1e-5 * th0) { accepted = true; augment = true; }
-            }
-            if (augment) {
-                int slot = nfilt;
-                if (nfilt >= MMPC_FCAP) { slot = 0; for (int i = 1; i < MMPC_FCAP; i++) if (FILT[2 * i] > FILT[2 * slot]) slot = i; }
-                else nfilt++;
-                LANES_BEGIN
-                if (lane == 0) { FILT[2 * slot] = (1 - 1e-5) * th0; FILT[2 * slot + 1] = phi0 - 1e-5 * th0; }
-                LANES_END
-            }
-            if (accepted) break;
-            if (lsi < MMPC_MAX_LS - 1) { alpha *= 0.5; lsi++; continue; }
-            // every trial of this pass was rejected
-            if (lspass == 0 && nfilt > 0) { nfilt = 0; lspass = 1; lsi = 0; alpha = ap; continue; }   // filter reset heuristic
-            break;
-        }
-        MMPC_TS(12)
-        // ---- update
-        LANES_BEGIN
-        auto &ls = MMPC_LS;
-        if (lane < NS) {
-#pragma unroll
-            for (int m = 0; m < M; m++) {
-                const double t = ls.ct[m], z = ls.cz[m], dtv = ls.cdt[m];
-                const double it_ = mmpc_rcp(t), dzv = mu * it_ - z - z * it_ * dtv;
-                ls.ct[m] = t + alpha * dtv; ls.cz[m] = z + ad * dzv;
-            }
-#pragma unroll
-            for (int i = 0; i < NSELF; i++) {
-                const double t = ls.st[i], z = ls.sz[i], dtv = ls.sdt[i];
-                const double it_ = mmpc_rcp(t), dzv = mu * it_ - z - z * it_ * dtv;
-                ls.st[i] = t + alpha * dtv; ls.sz[i] = z + ad * dzv;
-            }
-        }
-#pragma unroll
-        for (int p = 0; p < NPASS; p++) {
-            mmpc_sched_fence();
-            const int idx = lane + MMPC_WAVE * p;
-            if (idx < NPAIR) {
-                const int k = idx / NV, v = idx % NV;
-                const double lo = ls.b_lo[p], hi = ls.b_hi[p];
-                const bool alo = lo > -1e299, ahi = hi < 1e299;
-                const double val = XU[idx], dv = DXU[idx];
-                if (alo) { const double z = ls.lo_z[p], it_ = mmpc_rcp(mmpc_box_t(val - lo)); ls.lo_z[p] = z + ad * (mu * it_ - z - z * it_ * dv); }
-                if (ahi) { const double z = ls.hi_z[p], it_ = mmpc_rcp(mmpc_box_t(hi - val)); ls.hi_z[p] = z + ad * (mu * it_ - z + z * it_ * dv); }
-            }
-        }
-        LANES_END
-        LANES_BEGIN
-        for (int i = lane; i < NPAIR; i += MMPC_WAVE) if (i >= NX) XU[i] += alpha * DXU[i];   // x_0 is data
-        for (int i = lane; i < NS * NX; i += MMPC_WAVE) if (i >= NX) LAM[i] += alpha * DLAM[i];
-        for (int i = lane; i < NS; i += MMPC_WAVE) S[i] += alpha * DS[i];
-        LANES_END
+        // ---- first trial of the line search: multipliers with alpha_d, primal variables / slacks with alpha = alpha_p
+        alpha = ap; lspass = 0; lsi = 0;
+        apply_step(alpha, true);
+        in_ls = 1;
+        it++;
     }
 
     MMPC_TS(13)
