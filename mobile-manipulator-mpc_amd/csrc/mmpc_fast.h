@@ -2,16 +2,19 @@
 //
 // Same algorithm, same results as mmpc_core.h (the generic path; see that file for the
 // reference citations), restructured for gfx950:
-//   * horizon N is a template parameter; (x_k,u_k) are stored interleaved ("XU", NV = nx+nu
+//   * horizon N and obstacle count are template parameters; (x_k,u_k) are stored interleaved ("XU", NV = nx+nu
 //     doubles per stage) so that a (stage, variable) pair is one linear index;
-//   * slack/multiplier state of every inequality row lives in REGISTERS:
-//       - box rows: lane <-> (stage, variable) pair, both sides (lo/hi) of NPASS pairs per lane;
-//       - circle / self-collision rows: lane <-> stage;
+//   * the state of every inequality row lives in REGISTERS:
+//       - box rows: lane <-> (stage, variable) pair, NPASS pairs per lane: the two multipliers and the two bounds (the
+//         slack is the distance to the bound - the initial point is pushed inside, see MMPC_BOUND_PUSH);
+//       - circle / self-collision rows: lane <-> stage: slack, multiplier, slack step;
 //     LDS keeps only what is exchanged between lanes (trajectory, stage Hessians -> cost-to-go
-//     matrices, feedback gains, search direction) : ~38 KB for N=20 -> 4 problems per CU;
+//     matrices, feedback gains, search direction) : ~39 KB for N=20 -> 4 problems per CU;
 //   * per-launch constants are copied into LDS once (no global/constant loads in the loop);
-//   * wave-wide reductions use cross-lane shuffles; the Riccati phases use per-lane index
-//     tables precomputed once.
+//   * the Riccati recursion runs on v_mfma_f64_16x16x4_f64 tiles with the cost-to-go matrix kept in accumulator layout
+//     (see MMPC_MFMA below); wave-wide reductions use cross-lane shuffles;
+//   * a line-search trial point is evaluated once, fully: the evaluation of the accepted trial is the evaluation the
+//     next iteration starts from.
 // Written in the same PHASE discipline as mmpc_core.h so that -DMMPC_EMU builds run it on the
 // host (tests only); lane-private state that survives a phase lives in `LS` (struct per lane)
 // and `WR` (reduction inputs).
