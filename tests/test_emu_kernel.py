@@ -193,3 +193,21 @@ def test_emu_pose_reference_controller():
     o2 = coracle.solve_batch(par, x1, ref1, ur, e["U"], obs, X0=e["X"])
     e2 = emu_helper.solve_batch(par, x1, ref1, ur, e["U"], obs, x_guess=e["X"])
     assert (e2["status"] == 0).all() and np.abs(e2["X"] - o2["X"]).max() < TOL
+
+
+@pytest.mark.parametrize("fast", [False, True])
+def test_emu_custom_weights_and_limits(fast):
+    """diagonal weights other than the defaults and tightened input / rate / velocity limits (rows that bind)"""
+    B = 8
+    d = synth.make_batch(B, config_id=21)
+    rng = np.random.default_rng(21)
+    par = nlp.WholeBodyParams()
+    par.ulim = np.array([[-1.5, -2.0, -0.8, -0.8, -0.8], [1.5, 2.0, 0.8, 0.8, 0.8]])
+    par.dulim = np.array([[-1.0, -np.inf, -0.3, -0.3, -0.3], [1.0, np.inf, 0.3, 0.3, 0.3]])
+    par.xlim = par.xlim.copy(); par.xlim[:, 3:5] = [[-1.2, -1.2], [1.2, 1.2]]
+    q = rng.uniform(0.5, 30, 9) * (rng.uniform(size=9) > 0.3)
+    par.Q, par.P = np.diag(q), np.diag(q * rng.uniform(1, 3, 9))
+    par.R, par.W, par.S = np.diag(rng.uniform(0.05, 0.5, 5)), np.diag(rng.uniform(0.05, 0.5, 5)), 3e4
+    d["x_init"] = np.clip(d["x_init"], par.xlim[0], par.xlim[1])
+    r, e = _cmp(par, d, d["obs"], np.zeros((B, 20, 5)), fast=fast)
+    assert (np.abs(e["U"][:, :, 0]) > 1.0 - 1e-6).any()      # the merged box min(ulim, u_last + dulim) = 1.0 binds

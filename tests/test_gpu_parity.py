@@ -289,3 +289,38 @@ def test_pose_reference_controller(mm):
     one = mm.MPCWholeBodyPoseRef(mm.MobileManipulator(0.1), [mm.Obstacles(*obs[0, 0]), mm.Obstacles(*obs[0, 1])], N=N)
     u0 = one.solve(x0[0].copy(), ref[0], ur[0])
     assert np.abs(u0 - o["U"][0, 0]).max() < TOL and one.x_guess.shape == (N + 1, 9)
+
+
+@pytest.mark.gpu
+def test_weights_and_limits_surface(mm):
+    """setWeight(Q,R,P,S,W) and the constructor limits: random DIAGONAL weights with tightened limits (specialised kernel) and
+    DENSE symmetric weights (generic kernel) against the C oracle; also the emulated kernels agree on a subset."""
+    B = 48
+    d = synth.make_batch(B, config_id=21)
+    rng = np.random.default_rng(21)
+    par = nlp.WholeBodyParams()
+    par.ulim = np.array([[-1.5, -2.0, -0.8, -0.8, -0.8], [1.5, 2.0, 0.8, 0.8, 0.8]])
+    par.dulim = np.array([[-1.0, -np.inf, -0.3, -0.3, -0.3], [1.0, np.inf, 0.3, 0.3, 0.3]])
+    par.xlim = par.xlim.copy(); par.xlim[:, 3:5] = [[-1.2, -1.2], [1.2, 1.2]]
+    ctrl = mm.MPCWholeBody(mm.MobileManipulator(0.1), [], [], N=20, max_batch=B, n_obstacles=5,
+                           ulim=par.ulim, xlim=par.xlim, dulim=par.dulim)
+    x = np.clip(d["x_init"], par.xlim[0], par.xlim[1])
+    for dense in (False, True):
+        q = rng.uniform(0.5, 30, 9) * (rng.uniform(size=9) > 0.3)
+        Q = np.diag(q); P = np.diag(q * rng.uniform(1, 3, 9))
+        R = np.diag(rng.uniform(0.05, 0.5, 5)); W = np.diag(rng.uniform(0.05, 0.5, 5))
+        if dense:
+            A = rng.normal(size=(9, 9)) * 0.3; Q = Q + A @ A.T; P = P + A @ A.T
+            C = rng.normal(size=(5, 5)) * 0.1; R = R + C @ C.T
+        S = 3e4
+        par.Q, par.P, par.R, par.W, par.S = Q, P, R, W, S
+        ctrl.reset()
+        ctrl.setWeight(Q=Q, R=R, P=P, S=np.diag([S]), W=W)
+        r = ctrl.solve_batch(x, d["traj_ref"], d["u_ref"], d["obs"])
+        o = coracle.solve_batch(par, x, d["traj_ref"], d["u_ref"], np.zeros((B, 20, 5)), d["obs"], nthreads=8)
+        assert (r["status"] == 0).all() and (o["status"] == 0).all(), dense
+        assert np.abs(r["X"] - o["X"]).max() < 1e-5 and np.abs(r["U"] - o["U"]).max() < 1e-5, dense
+        assert np.abs(r["cost"] / o["cost"] - 1).max() < 1e-8
+        # the limits bind: some inputs sit on the merged box min(ulim, u_last + dulim) = 1.0
+        assert (np.abs(r["U"][:, :, 0]) > 1.0 - 1e-6).any()
+        assert (r["U"] <= par.ulim[1] + 1e-9).all() and (r["U"] >= par.ulim[0] - 1e-9).all()
