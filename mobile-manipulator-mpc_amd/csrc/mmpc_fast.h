@@ -175,7 +175,7 @@ typedef double MmpcAcc __attribute__((ext_vector_type(4)));
 
 struct MmpcFastLayout {
     int XU, S, LAM, XUREF, ULAST, OBS, CST, CV, CD, TRG, HXX, QXU, HUXL, HUUL, HUX02, HUUD, SN, KK, KF, DXU, DS, DLAM,
-        GS, DUMP, RB, RDS, FILT, MISC, total;
+        GS, DUMP, RB, RDS, Q1V, FILT, MISC, total;
 };
 // constants block (CST) offsets
 #define MMPC_C_XLIM 0      // [2][9]
@@ -200,7 +200,7 @@ MMPC_HD MmpcFastLayout mmpc_fast_layout(int M, int obs_per_stage) {
     MMPC_CARVE(HXX, F::NS * F::NXX) MMPC_CARVE(QXU, F::NS * F::NV) MMPC_CARVE(HUXL, F::NU * F::NX)
     MMPC_CARVE(HUUL, F::NUU) MMPC_CARVE(HUX02, F::NS) MMPC_CARVE(HUUD, F::NS * F::NU) MMPC_CARVE(SN, 16)
     MMPC_CARVE(KK, N * F::NU * F::NX) MMPC_CARVE(KF, N * F::NU) MMPC_CARVE(DXU, F::NS * F::NV) MMPC_CARVE(DS, F::NS)
-    MMPC_CARVE(DLAM, F::NS * F::NX) MMPC_CARVE(RB, F::NS * F::NV) MMPC_CARVE(RDS, F::NS) MMPC_CARVE(FILT, 2 * MMPC_FCAP)
+    MMPC_CARVE(DLAM, F::NS * F::NX) MMPC_CARVE(RB, F::NS * F::NV) MMPC_CARVE(RDS, F::NS) MMPC_CARVE(Q1V, F::NV + 2) MMPC_CARVE(FILT, 2 * MMPC_FCAP)
     // scratch of the backward pass lives, where it fits, in arrays that are dead while it runs: the 16x16 exchange tile in
     // the search direction (written by the forward roll-out afterwards), the dump slots in the multiplier step (D1)
     if (F::NS * F::NV >= 256) L.GS = L.DXU; else { MMPC_CARVE(GS, 256) }
@@ -298,7 +298,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
            *QXU = lds + L.QXU, *HUXL = lds + L.HUXL, *HUUL = lds + L.HUUL, *HUX02 = lds + L.HUX02,
            *HUUD = lds + L.HUUD, *SN = lds + L.SN, *KK = lds + L.KK, *KF = lds + L.KF, *DXU = lds + L.DXU,
            *DS = lds + L.DS, *DLAM = lds + L.DLAM, *GS = lds + L.GS, *FILT = lds + L.FILT, *MISC = lds + L.MISC;
-    double *const RB = lds + L.RB, *const RDS = lds + L.RDS;   // residual base r[k][v] and the s_k residual of the current point
+    double *const RB = lds + L.RB, *const RDS = lds + L.RDS, *const Q1V = lds + L.Q1V;   // residual base r[k][v] and the s_k residual of the current point
     const double dt = P.dt, Sw = P.S, tol = P.tol;
 #ifdef MMPC_EMU
     static thread_local MmpcLaneState<KIND, N, MC> ls_all[MMPC_WAVE];
@@ -810,7 +810,8 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                     }
                 }
                 if (k == N - 1 && NSELF) {
-                    // Q1: terminal self rows -> s_{N-1}.  a = v + A^T vN, b = B^T vN, gamma = g_s - vN.c
+                    // Q1: terminal self rows -> s_{N-1}.  a = v + A^T vN, b = B^T vN, gamma = g_s - vN.c.  This lane publishes
+                    // (a, b, gamma, 1/h_ss); the dense rank-one blocks are applied by all lanes in the next phase
                     const double hssN = SN[0], gssN = -(mu * SN[1] + SN[2]);
                     hss += hssN; gss += gssN;
                     const double ih = mmpc_rcp(hss);
@@ -831,23 +832,17 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                     double gam = gss;
 #pragma unroll
                     for (int j = 0; j < NX; j++) gam -= vf[j] * CD[k * NX + j];
-                    // store the un-eliminated block first, then apply the dense rank-one term in LDS
+#pragma unroll
+                    for (int j = 0; j < NX; j++) Q1V[j] = a[j];
+#pragma unroll
+                    for (int c = 0; c < NU; c++) Q1V[NX + c] = b[c];
+                    Q1V[NV] = gam * ih; Q1V[NV + 1] = ih;
 #pragma unroll
                     for (int e = 0; e < NXX; e++) HXX[k * NXX + e] = hxx[e];
 #pragma unroll
-                    for (int i = 0; i < NX; i++) {
+                    for (int j = 0; j < NX; j++) QXU[k * NV + j] = qx[j];
 #pragma unroll
-                        for (int j = 0; j <= i; j++) HXX[k * NXX + i * (i + 1) / 2 + j] -= a[i] * a[j] * ih;
-                        QXU[k * NV + i] = qx[i] + a[i] * gam * ih;
-                    }
-#pragma unroll
-                    for (int c = 0; c < NU; c++) {
-#pragma unroll
-                        for (int j = 0; j < NX; j++) HUXL[c * NX + j] = -b[c] * a[j] * ih;
-#pragma unroll
-                        for (int d = 0; d <= c; d++) HUUL[c * (c + 1) / 2 + d] = -b[c] * b[d] * ih;
-                        QXU[k * NV + NX + c] = RB[k * NV + NX + c] + b[c] * gam * ih;
-                    }
+                    for (int c = 0; c < NU; c++) QXU[k * NV + NX + c] = RB[k * NV + NX + c];
                 } else {
                     if (k == N - 1) {
                         for (int c = 0; c < NU * NX; c++) HUXL[c] = 0.0;
@@ -878,6 +873,33 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                 for (int c = 0; c < NU; c++) HUUD[k * NU + c] = CST[MMPC_C_RW2 + c * NU + c];
             }
             LANES_END
+            if (NSELF) {
+                // ---- dense rank-one blocks of stage N-1 (the elimination of s_{N-1} reaches x_N through the dynamics):
+                //      Hxx -= a a^T/h, Hux = -b a^T/h, Huu = -b b^T/h, q += (a; b) gamma/h
+                LANES_BEGIN
+                const double ih = Q1V[NV + 1], gih = Q1V[NV];
+                for (int e = lane; e < NXX + NU * NX + NUU + NV; e += MMPC_WAVE) {
+                    if (e < NXX) {
+                        int i = 0;
+                        while ((i + 1) * (i + 2) / 2 <= e) i++;
+                        const int j = e - i * (i + 1) / 2;
+                        HXX[(N - 1) * NXX + e] -= Q1V[i] * Q1V[j] * ih;
+                    } else if (e < NXX + NU * NX) {
+                        const int c = (e - NXX) / NX, j = (e - NXX) % NX;
+                        HUXL[c * NX + j] = -Q1V[NX + c] * Q1V[j] * ih;
+                    } else if (e < NXX + NU * NX + NUU) {
+                        const int q = e - NXX - NU * NX;
+                        int c = 0;
+                        while ((c + 1) * (c + 2) / 2 <= q) c++;
+                        const int d2 = q - c * (c + 1) / 2;
+                        HUUL[q] = -Q1V[NX + c] * Q1V[NX + d2] * ih;
+                    } else {
+                        const int j = e - NXX - NU * NX - NUU;
+                        QXU[(N - 1) * NV + j] += Q1V[j] * gih;
+                    }
+                }
+                LANES_END
+            }
             MMPC_TS(3)
             // ---- A1 (pair lanes): barrier terms of the box rows (diagonal entries, unique owners)
             LANES_BEGIN
@@ -1160,11 +1182,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                 const double lo = ls.b_lo[p], hi = ls.b_hi[p];
                 const bool alo = lo > -1e299, ahi = hi < 1e299;
                 const double val = XU[idx], dv = DXU[idx];
-                double e = val - XUREF[idx];
-                if (KIND == 1 && v == 2) e = mmpc_angle_diff(val, XUREF[idx]);
-                double g = w_diag(k, v) * e;
-                if (v >= NX && k < N) g += CST[MMPC_C_WW + v - NX] * (val - ULAST[k * NU + v - NX]);
-                dphi += g * dv;
+                dphi += RB[idx] * dv;   // RB = plain cost gradient of this variable (kept by the evaluation)
                 if (alo) {
                     const double t = mmpc_box_t(val - lo), z = ls.lo_z[p], dtv = dv, it_ = mmpc_rcp(t), dzv = mu * it_ - z - z * it_ * dtv;
                     if (dtv < 0) ap = mmpc_min(ap, -tau * t * mmpc_rcp(dtv));
