@@ -661,18 +661,21 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                 const int k = idx / NV, v = idx % NV;
                 const double lo = ls.b_lo[p], hi = ls.b_hi[p];
                 const bool alo = lo > -1e299, ahi = hi < 1e299;
-                const double val = XU[idx];
+                // every LDS word this pair needs, ahead of the arithmetic and of the per-side blocks (one round trip per pass);
+                // the input-only terms read a valid dummy address for state variables and carry weight 0 there
+                const bool isu = v >= NX && k < N;
+                const int au = isu ? v - NX : 0;
+                const double val = XU[idx], ref = XUREF[idx], rb0 = RB[idx];
+                const double ul = ULAST[(isu ? k : 0) * NU + au], ww0 = CST[MMPC_C_WW + au];
+                const double wq = CST[v < NX ? (k < N ? MMPC_C_WQ : MMPC_C_WP) + v : MMPC_C_WR + v - NX];
+                mmpc_sched_fence();
                 // cost gradient / value (diagonal weights): mpc_wholebody_qref.py:192-201,240-242
-                double e = val - XUREF[idx];
-                if (KIND == 1 && v == 2) e = mmpc_angle_diff(val, XUREF[idx]);
-                const double wq = w_diag(k, v);
-                double g = wq * e;
-                phi += 0.5 * wq * e * e;
-                if (v >= NX && k < N) {
-                    const double e2 = val - ULAST[k * NU + v - NX], ww = CST[MMPC_C_WW + v - NX];
-                    g += ww * e2; phi += 0.5 * ww * e2 * e2;
-                }
-                double r = RB[idx] + g;
+                double e = val - ref;
+                if (KIND == 1 && v == 2) e = mmpc_angle_diff(val, ref);
+                const double wqe = (v < NX || k < N) ? wq : 0.0, ww = isu ? ww0 : 0.0, e2 = val - ul;
+                double g = wqe * e + ww * e2;
+                phi += 0.5 * wqe * e * e + 0.5 * ww * e2 * e2;
+                double r = rb0 + g;
                 if (alo) {
                     const double t = mmpc_box_t(val - lo), z = ls.lo_z[p];
                     r -= z; la.mul(t);
