@@ -519,23 +519,22 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                 ls.st[i] = t + d_alpha * dtv;
             }
         }
-        if (first) {
+        // (same phase: every lane touches only its own registers and its own words of XU / LAM / S)
 #pragma unroll
-            for (int p = 0; p < NPASS; p++) {
-                mmpc_sched_fence();
-                const int idx = lane + MMPC_WAVE * p;
-                if (idx < NPAIR) {
+        for (int p = 0; p < NPASS; p++) {
+            mmpc_sched_fence();
+            const int idx = lane + MMPC_WAVE * p;
+            if (idx < NPAIR) {
+                const double val = XU[idx], dv = DXU[idx];
+                if (first) {
                     const double lo = ls.b_lo[p], hi = ls.b_hi[p];
                     const bool alo = lo > -1e299, ahi = hi < 1e299;
-                    const double val = XU[idx], dv = DXU[idx];
                     if (alo) { const double z = ls.lo_z[p], it_ = mmpc_rcp(mmpc_box_t(val - lo)); ls.lo_z[p] = z + ad * (mu * it_ - z - z * it_ * dv); }
                     if (ahi) { const double z = ls.hi_z[p], it_ = mmpc_rcp(mmpc_box_t(hi - val)); ls.hi_z[p] = z + ad * (mu * it_ - z + z * it_ * dv); }
                 }
+                if (idx >= NX) XU[idx] = val + d_alpha * dv;   // x_0 is data
             }
         }
-        LANES_END
-        LANES_BEGIN
-        for (int i = lane; i < NPAIR; i += MMPC_WAVE) if (i >= NX) XU[i] += d_alpha * DXU[i];   // x_0 is data
         for (int i = lane; i < NS * NX; i += MMPC_WAVE) if (i >= NX) LAM[i] += d_alpha * DLAM[i];
         for (int i = lane; i < NS; i += MMPC_WAVE) S[i] += d_alpha * DS[i];
         LANES_END
@@ -915,15 +914,14 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                     const int k = idx / NV, v = idx % NV;
                     const double lo = ls.b_lo[p], hi = ls.b_hi[p];
                     const bool alo = lo > -1e299, ahi = hi < 1e299;
-                    const double val = XU[idx];
+                    // the diagonal Hessian entry this pair owns (state: HXX[k] diagonal, input: HUUD[k]); loads first
+                    double *hd = v < NX ? HXX + k * NXX + v * (v + 1) / 2 + v : HUUD + (k < N ? k : 0) * NU + v - NX;
+                    const double val = XU[idx], q0 = QXU[idx], h0 = *hd;
+                    mmpc_sched_fence();
                     double wsum = 0.0, gsum = 0.0;
                     if (alo) { const double it_ = mmpc_rcp(mmpc_box_t(val - lo)); wsum += ls.lo_z[p] * it_; gsum -= mu * it_; }
                     if (ahi) { const double it_ = mmpc_rcp(mmpc_box_t(hi - val)); wsum += ls.hi_z[p] * it_; gsum += mu * it_; }
-                    if (alo || ahi) {
-                        QXU[idx] += gsum;
-                        if (v < NX) HXX[k * NXX + v * (v + 1) / 2 + v] += wsum;
-                        else HUUD[k * NU + v - NX] += wsum;
-                    }
+                    if (alo || ahi) { QXU[idx] = q0 + gsum; *hd = h0 + wsum; }
                 }
             }
             LANES_END
