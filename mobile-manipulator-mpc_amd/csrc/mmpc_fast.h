@@ -1113,14 +1113,21 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
         auto &ls = MMPC_LS;
         if (lane < NS) {
             const int k = lane;
-            const double *dx = DXU + k * NV;
+            // lam_k + dlam_k = -(P_k dx_k + p_k): every load ahead of the arithmetic, the stores at the end (a store inside the
+            // row loop makes the compiler wait for each load: it cannot tell DLAM from HXX)
+            double dx[NX], pk[NXX], y[NX];
+#pragma unroll
+            for (int j = 0; j < NX; j++) { dx[j] = DXU[k * NV + j]; y[j] = QXU[k * NV + j] + LAM[k * NX + j]; }
+#pragma unroll
+            for (int e = 0; e < NXX; e++) pk[e] = HXX[k * NXX + e];
+            mmpc_sched_fence();
 #pragma unroll
             for (int i = 0; i < NX; i++) {
-                double v = QXU[k * NV + i];
 #pragma unroll
-                for (int j = 0; j < NX; j++) v += HXX[k * NXX + (i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i)] * dx[j];
-                DLAM[k * NX + i] = -v - LAM[k * NX + i];
+                for (int j = 0; j < NX; j++) y[i] += pk[i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i] * dx[j];
             }
+#pragma unroll
+            for (int i = 0; i < NX; i++) DLAM[k * NX + i] = -y[i];
             double vdx = 0.0;
             constexpr int ny = NSELF ? 6 : 2;
 #pragma unroll
