@@ -555,18 +555,19 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
         auto &ls = MMPC_LS;
         double e_p = 0.0, tzmax = 0.0, tzmin = 1e300, zsum = 0.0, phi = 0.0, th = 0.0, slog = 0.0;
         if (lane < NS) {
-            const int k = lane;
-            const double *xk = XU + k * NV;
-            const double sk = S[k];
+            const int k = lane, k1 = k < N ? k + 1 : k;
+            // every LDS word of this stage first (the stores below would otherwise pin each later load behind them)
+            double xk[NV], xn1[NX], ln[NX], rb[NV], ob[(MC > 0 ? MC : 1) * 3];
+#pragma unroll
+            for (int j = 0; j < NV; j++) { xk[j] = XU[k * NV + j]; rb[j] = 0.0; }
+#pragma unroll
+            for (int j = 0; j < NX; j++) { xn1[j] = XU[k1 * NV + j]; ln[j] = LAM[k1 * NX + j]; rb[j] = k >= 1 ? LAM[k * NX + j] : 0.0; }
+#pragma unroll
+            for (int m = 0; m < M; m++) { const double *o = obs_ptr(k, m); ob[3 * m] = o[0]; ob[3 * m + 1] = o[1]; ob[3 * m + 2] = o[2]; }
+            const double sk = S[k], sks_ld = S[slack_idx(k)];
+            mmpc_sched_fence();
             double sn, cs;
             mmpc_sincos(xk[2], &sn, &cs);
-            double rb[NV];
-#pragma unroll
-            for (int j = 0; j < NV; j++) rb[j] = 0.0;
-            if (k >= 1) {
-#pragma unroll
-                for (int j = 0; j < NX; j++) rb[j] = LAM[k * NX + j];
-            }
             double *cv = CV + k * MMPC_NCV;
             if (k < N) {
                 const double *uk = xk + NX;
@@ -574,14 +575,12 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                              a35 = -dt * xk[4], a45 = dt * xk[3], b30 = dt * cs, b40 = dt * sn;
                 cv[0] = 0.0; cv[1] = 1.0; cv[2] = dt; cv[3] = a32; cv[4] = a42; cv[5] = a43; cv[6] = a34; cv[7] = a35;
                 cv[8] = a45; cv[9] = b30; cv[10] = b40;
-                const double *xn1 = xk + NV;
                 double c[NX];
                 c[0] = xk[0] + dt * xk[3] - xn1[0]; c[1] = xk[1] + dt * xk[4] - xn1[1]; c[2] = xk[2] + dt * xk[5] - xn1[2];
                 c[3] = xk[3] + dt * (uk[0] * cs - xk[4] * xk[5]) - xn1[3];
                 c[4] = xk[4] + dt * (uk[0] * sn + xk[3] * xk[5]) - xn1[4];
                 c[5] = xk[5] + dt * uk[1] - xn1[5];
                 if (KIND == 0) { c[6] = xk[6] + dt * uk[2] - xn1[6]; c[7] = xk[7] + dt * uk[3] - xn1[7]; c[8] = xk[8] + dt * uk[4] - xn1[8]; }
-                const double *ln = LAM + (k + 1) * NX;
 #pragma unroll
                 for (int j = 0; j < NX; j++) { CD[k * NX + j] = c[j]; e_p = mmpc_max(e_p, fabs(c[j])); th += fabs(c[j]); zsum += fabs(ln[j]); }
                 // - A^T lam_{k+1}, - B^T lam_{k+1}  (sparse, base.py:19-26)
@@ -602,10 +601,9 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
             MmpcLogAcc la; la.init();
 #pragma unroll
             for (int m = 0; m < M; m++) {
-                const double *o = obs_ptr(k, m);
-                const double dx = xk[0] - o[0], dy = xk[1] - o[1], m2 = dx * dx + dy * dy, id = mmpc_rsqrt(m2), d = m2 * id;
+                const double dx = xk[0] - ob[3 * m], dy = xk[1] - ob[3 * m + 1], m2 = dx * dx + dy * dy, id = mmpc_rsqrt(m2), d = m2 * id;
                 const double nxv = dx * id, nyv = dy * id;
-                const double h = (o[2] + MMPC_BASE_R) - d - sk;
+                const double h = (ob[3 * m + 2] + MMPC_BASE_R) - d - sk;
                 const double t = ls.ct[m], z = ls.cz[m];
                 rb[0] -= nxv * z; rb[1] -= nyv * z; rds -= z;
                 e_p = mmpc_max(e_p, fabs(h + t)); th += fabs(h + t); la.mul(t);
@@ -617,7 +615,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                 TRG[k * 8 + 0] = sn; TRG[k * 8 + 1] = cs;
 #pragma unroll
                 for (int a = 0; a < 3; a++) { TRG[k * 8 + 2 + a] = dr[a]; TRG[k * 8 + 5 + a] = dz[a]; }
-                const double sks = S[slack_idx(k)];
+                const double sks = sks_ld;
                 double sw = 0.0, sit = 0.0, swr = 0.0, swg[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
                 for (int i = 0; i < NSELF; i++) {
