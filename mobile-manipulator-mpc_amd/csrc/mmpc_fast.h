@@ -128,6 +128,9 @@ MMPC_DEV void mmpc_arm_segments_fast(double q1, double q2, double q3, double dr[
 // state entries the forward kinematics depends on (x, y, psi, q1, q2, q3), as a constant expression
 MMPC_HD constexpr int mmpc_y(int a) { return a < 3 ? a : a + 3; }
 
+#ifndef MMPC_UNROLL_NMAX
+#define MMPC_UNROLL_NMAX 20
+#endif
 #ifndef MMPC_FWD_UNROLL
 #define MMPC_FWD_UNROLL 4   // stages per trip of the forward roll-out loop (measured: 1 -> 4 saves 2.9 k cycles per iteration)
 #endif
@@ -298,6 +301,10 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
     constexpr int NX = F::NX, NU = F::NU, NV = F::NV, NXX = F::NXX, NUU = F::NUU, NSELF = F::NSELF, NS = F::NS;
     constexpr int NPASS = F::NPASS, NPAIR = F::NPAIR, NKB = F::NKB, NGB = F::NGB, GR0 = F::GR0, GR1 = F::GR1;
     constexpr int M = MC;   // number of circle obstacles is a template parameter on this path
+    // stages per trip of the Riccati / forward loops: unrolling saves the per-stage pointer bumps and register shuffles,
+    // but costs registers - it only pays where the kernel does not spill (measured per instantiation)
+    constexpr bool ROOMY = KIND == 0 && N <= MMPC_UNROLL_NMAX;
+    constexpr int RIC_UNROLL = ROOMY ? MMPC_RIC_UNROLL : 1, FWD_UNROLL = ROOMY ? MMPC_FWD_UNROLL : 1;
     const MmpcFastLayout L = mmpc_fast_layout<KIND, N>(M, P.obs_per_stage);
     double *XU = lds + L.XU, *S = lds + L.S, *LAM = lds + L.LAM, *XUREF = lds + L.XUREF, *ULAST = lds + L.ULAST,
            *OBS = lds + L.OBS, *CST = lds + L.CST, *CV = lds + L.CV, *CD = lds + L.CD, *TRG = lds + L.TRG, *HXX = lds + L.HXX,
@@ -944,7 +951,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
 #pragma unroll
             for (int r = 0; r < NKB; r++) { const unsigned o = ls.ab_o[r]; ls.rAB[r] = lds[(o & 0xffffu) + (N - 1) * (int)(o >> 16)]; }
             LANES_END
-#pragma unroll MMPC_RIC_UNROLL
+#pragma unroll RIC_UNROLL
             for (int k = N - 1; k >= 0; k--) {
                 MMPC_TS(5)
                 // R1: T = P [A B | c] + [0 | p]   (P symmetric: its accumulator registers are the A operand)
@@ -1072,7 +1079,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
         LANES_BEGIN
         for (int j = lane; j < NV; j += MMPC_WAVE) DXU[j] = 0.0;
         LANES_END
-#pragma unroll MMPC_FWD_UNROLL
+#pragma unroll FWD_UNROLL
         for (int k = 0; k < N; k++) {
             LANES_BEGIN
             auto &ls = MMPC_LS;
