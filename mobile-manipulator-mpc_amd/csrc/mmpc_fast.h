@@ -1150,23 +1150,27 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
         const double tau = mmpc_max(0.99, 1.0 - mu);
         LANES_BEGIN
         auto &ls = MMPC_LS;
-        double ap = 1.0, ad = 1.0, dphi = 0.0;
+        // fraction to the boundary without divisions or branches: alpha = min(1, tau / max_i(-dt_i / t_i)) (1/t_i is at hand),
+        // likewise for the multipliers with 1/z_i
+        double rp = 0.0, rd = 0.0, dphi = 0.0;
         if (lane < NS) {
             const int k = lane;
             const double *dx = DXU + k * NV;
             const double dsk = DS[k], dsks = DS[slack_idx(k)];
             const double px = XU[k * NV], py = XU[k * NV + 1], sk = S[k];
+            double ob[(MC > 0 ? MC : 1) * 3];
+#pragma unroll
+            for (int m = 0; m < M; m++) { const double *o = obs_ptr(k, m); ob[3 * m] = o[0]; ob[3 * m + 1] = o[1]; ob[3 * m + 2] = o[2]; }
 #pragma unroll
             for (int m = 0; m < M; m++) {
-                const double *o = obs_ptr(k, m);
-                const double ddx = px - o[0], ddy = py - o[1], m2 = ddx * ddx + ddy * ddy, id = mmpc_rsqrt(m2), d = m2 * id;
-                const double hv = (o[2] + MMPC_BASE_R) - d - sk;
+                const double ddx = px - ob[3 * m], ddy = py - ob[3 * m + 1], m2 = ddx * ddx + ddy * ddy, id = mmpc_rsqrt(m2), d = m2 * id;
+                const double hv = (ob[3 * m + 2] + MMPC_BASE_R) - d - sk;
                 const double t = ls.ct[m], z = ls.cz[m];
                 const double jd = -(ddx * dx[0] + ddy * dx[1]) * id - dsk;
                 const double dtv = -(hv + t) - jd, it_ = mmpc_rcp(t), dzv = mu * it_ - z - z * it_ * dtv;
                 ls.cdt[m] = dtv;
-                if (dtv < 0) ap = mmpc_min(ap, -tau * t * mmpc_rcp(dtv));
-                if (dzv < 0) ad = mmpc_min(ad, -tau * z * mmpc_rcp(dzv));
+                rp = mmpc_max(rp, -dtv * it_);
+                rd = mmpc_max(rd, -dzv * mmpc_rcp(z));
                 dphi -= mu * dtv * it_;
             }
             double sn = 0.0, cs = 0.0, dr[3] = {0, 0, 0}, dz[3] = {0, 0, 0};
@@ -1186,8 +1190,8 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                 for (int a = 0; a < 6; a++) jd += g6[a] * dx[mmpc_y(a)];
                 const double dtv = -(hv + t) - jd, it_ = mmpc_rcp(t), dzv = mu * it_ - z - z * it_ * dtv;
                 ls.sdt[i] = dtv;
-                if (dtv < 0) ap = mmpc_min(ap, -tau * t * mmpc_rcp(dtv));
-                if (dzv < 0) ad = mmpc_min(ad, -tau * z * mmpc_rcp(dzv));
+                rp = mmpc_max(rp, -dtv * it_);
+                rd = mmpc_max(rd, -dzv * mmpc_rcp(z));
                 dphi -= mu * dtv * it_;
             }
             dphi += 2 * Sw * S[k] * dsk;
@@ -1204,21 +1208,21 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                 dphi += RB[idx] * dv;   // RB = plain cost gradient of this variable (kept by the evaluation)
                 if (alo) {
                     const double t = mmpc_box_t(val - lo), z = ls.lo_z[p], dtv = dv, it_ = mmpc_rcp(t), dzv = mu * it_ - z - z * it_ * dtv;
-                    if (dtv < 0) ap = mmpc_min(ap, -tau * t * mmpc_rcp(dtv));
-                    if (dzv < 0) ad = mmpc_min(ad, -tau * z * mmpc_rcp(dzv));
+                    rp = mmpc_max(rp, -dtv * it_);
+                    rd = mmpc_max(rd, -dzv * mmpc_rcp(z));
                     dphi -= mu * dtv * it_;
                 }
                 if (ahi) {
                     const double t = mmpc_box_t(hi - val), z = ls.hi_z[p], dtv = -dv, it_ = mmpc_rcp(t), dzv = mu * it_ - z - z * it_ * dtv;
-                    if (dtv < 0) ap = mmpc_min(ap, -tau * t * mmpc_rcp(dtv));
-                    if (dzv < 0) ad = mmpc_min(ad, -tau * z * mmpc_rcp(dzv));
+                    rp = mmpc_max(rp, -dtv * it_);
+                    rd = mmpc_max(rd, -dzv * mmpc_rcp(z));
                     dphi -= mu * dtv * it_;
                 }
             }
         }
-        MMPC_WR(0) = ap; MMPC_WR(1) = ad; MMPC_WR(2) = dphi;
+        MMPC_WR(0) = rp; MMPC_WR(1) = rd; MMPC_WR(2) = dphi;
         LANES_END
-        ap = MMPC_RED_MIN(0); ad = MMPC_RED_MIN(1); dphi = MMPC_RED_SUM(2);
+        { const double rp_ = MMPC_RED_MAX(0), rd_ = MMPC_RED_MAX(1); ap = rp_ > tau ? tau / rp_ : 1.0; ad = rd_ > tau ? tau / rd_ : 1.0; dphi = MMPC_RED_SUM(2); }
 
         MMPC_TS(11)
         if (!filt_init) { nfilt = 0; th_max = 1e4 * mmpc_max(1.0, th0); th_min = 1e-4 * mmpc_max(1.0, th0); filt_init = 1; }
