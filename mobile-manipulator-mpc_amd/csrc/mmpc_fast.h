@@ -290,7 +290,8 @@ static inline double mmpc_emu_red(double (*wr)[8], int i, int op) {
 struct MmpcLogAcc {
     double mant; int ex;
     MMPC_DEV void init() { mant = 1.0; ex = 0; }
-    MMPC_DEV void mul(double t) { int e; mant *= frexp(t, &e); ex += e; if (mant < 1e-200) { mant = frexp(mant, &e); ex += e; } }
+    // (a lane multiplies at most a few dozen mantissas in [0.5, 1) between init() and value(): no underflow, no renormalisation)
+    MMPC_DEV void mul(double t) { int e; mant *= frexp(t, &e); ex += e; }
     MMPC_DEV double value() const { int e = ex; const double l = mmpc_log_mant(mant, &e); return l + (double)e * 0.69314718055994530942; }
 };
 
@@ -686,15 +687,13 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                 double g = wqe * e + ww * e2;
                 phi += 0.5 * wqe * e * e + 0.5 * ww * e2 * e2;
                 double r = rb0 + g;
-                if (alo) {
-                    const double t = mmpc_box_t(val - lo), z = ls.lo_z[p];
-                    r -= z; la.mul(t);
-                    tzmax = mmpc_max(tzmax, t * z); tzmin = mmpc_min(tzmin, t * z); zsum += z;
-                }
-                if (ahi) {
-                    const double t = mmpc_box_t(hi - val), z = ls.hi_z[p];
-                    r += z; la.mul(t);
-                    tzmax = mmpc_max(tzmax, t * z); tzmin = mmpc_min(tzmin, t * z); zsum += z;
+                {   // both sides without branches: an absent side has z = 0 and is given t = 1 (log 1 = 0)
+                    const double tl = alo ? mmpc_box_t(val - lo) : 1.0, zl = ls.lo_z[p], th_ = ahi ? mmpc_box_t(hi - val) : 1.0, zh = ls.hi_z[p];
+                    const double pl = tl * zl, ph = th_ * zh;
+                    r += zh - zl; la.mul(tl); la.mul(th_);
+                    tzmax = mmpc_max(tzmax, mmpc_max(pl, ph));
+                    tzmin = mmpc_min(tzmin, mmpc_min(alo ? pl : 1e300, ahi ? ph : 1e300));
+                    zsum += zl + zh;
                 }
                 RB[idx] = g;   // keep the plain cost gradient for the assembly / directional derivative
                 const bool isvar = v < NX ? (k >= 1) : (k < N);
