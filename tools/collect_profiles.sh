@@ -7,8 +7,6 @@ tag=${1:-r01_f}
 o=gpurun_out/$tag
 mkdir -p $o
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
-python3 bench.py --steps 20 --warmup 3 > $o/bench.json 2> $o/bench.err
-python3 bench.py --config c5 --steps 2 --warmup 1 > $o/bench_c5.json 2> $o/bench_c5.err
 rocprofv3 --kernel-trace --stats -d $o/kt -o run --output-format csv -- python3 bench.py --steps 20 --warmup 3 --no-cpu > $o/kt.log 2>&1
 cp $(find $o/kt -name "*kernel_stats.csv" | head -1) $o/kernel_stats.csv
 # HBM traffic: FETCH_SIZE and WRITE_SIZE in their own passes
@@ -38,4 +36,8 @@ bash tools/pmc_collect.sh $o/pmc > /dev/null
 cp $o/pmc/summary.json $o/pmc_mfma.json
 if [ -f mobile-manipulator-mpc_amd/csrc/libmmpc_stamp.so ]; then python3 tools/probe_stamps.py > $o/phase_stamps.txt 2>&1; fi
 python3 tools/probe_base.py > $o/base_c2.txt 2>&1 || true
+# the bench line reads the PMC summaries of the same build from profiles/<tag>_*.json
+cp $o/pmc_traffic.json profiles/${tag}_pmc_traffic.json; cp $o/pmc_mfma.json profiles/${tag}_pmc_mfma.json
+python3 bench.py --steps 20 --warmup 3 > $o/bench.json 2> $o/bench.err
+python3 bench.py --config c5 --steps 2 --warmup 1 > $o/bench_c5.json 2> $o/bench_c5.err
 tail -1 $o/bench.json
