@@ -212,6 +212,19 @@ def main():
                 eng.solve_batch(hx, d["traj_ref"][:Bl], d["u_ref"][:Bl], d["obs"][:Bl])
             res["host_pointer_api"] = {"value": 3 * Bl / (time.perf_counter() - h0), "unit": "solves/s",
                                        "note": "mmpc_solve_batch with pageable host arrays in and out (PCIe-inclusive, cold start)"}
+            # latency of ONE solve through the reference's own call (controller.solve(x_init, traj_ref, u_ref) -> u0), the
+            # number the closed-loop driver sees per tick (interface_wholebody_qref.py:134); cold start each time
+            import contextlib, io
+            one = mm.MPCWholeBody(robot, [mm.Obstacles(*d["obs"][0, m]) for m in range(M)], [], N=N)
+            lat = []
+            with contextlib.redirect_stdout(io.StringIO()):
+                for b in range(12):
+                    one.reset()
+                    l0 = time.perf_counter()
+                    one.solve(d["x_init"][b].copy(), d["traj_ref"][b], d["u_ref"][b])
+                    lat.append(time.perf_counter() - l0)
+            res["single_solve_latency_ms"] = {"median": 1e3 * float(np.median(lat[2:])), "max": 1e3 * float(np.max(lat[2:])),
+                                              "note": "MPCWholeBody.solve() for one instance, host arrays in, u0 out (10 solves)"}
         if world == 1 and not args.no_cpu:
             from oracle import coracle, nlp
             avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
