@@ -84,6 +84,13 @@ struct MmpcParams {
 // bound push of the initial point (IPOPT's bound_push): a variable with a finite simple bound starts at least this far
 // inside it; the box rows are linear, so their slack then stays equal to the distance to the bound
 #define MMPC_BOUND_PUSH 1e-2
+// proximal term for crawling iterations: after two consecutive steps with alpha < MMPC_PROX_LO the (x,u) Hessian gets
+// + prox I (MMPC_PROX0, x4 per further small step), divided by 4 after a step with alpha > 0.5 (oracle/ipm_numpy.py)
+#define MMPC_PROX0 100.0
+#define MMPC_PROX_LO 0.05
+#define MMPC_PROX_MAX 1e4
+// multiplier safeguard (IPOPT eq. 16): z_i is kept within [mu / (kappa t_i), kappa mu / t_i] at every evaluation
+#define MMPC_KAPPA_SIGMA 1e10
 
 // ---- structure of [A B] = d f / d(x,u) for the diff-drive base (+ integrator arm) -----------
 // robot_models/base.py:19-26, manipulator_3DoF.py:190.  Every column has at most 4 non-zeros.
@@ -187,6 +194,17 @@ MMPC_DEV double mmpc_bound_push(double v, double lo, double hi) {
     return v < lo2 ? lo2 : (v > hi2 ? hi2 : v);
 }
 MMPC_DEV double mmpc_max(double a, double b) { return a > b ? a : b; }
+MMPC_DEV double mmpc_z_safeguard(double z, double t, double mu) {
+    const double p = z * t;
+    if (p > MMPC_KAPPA_SIGMA * mu) return MMPC_KAPPA_SIGMA * mu / t;
+    if (p < mu / MMPC_KAPPA_SIGMA) return mu / (MMPC_KAPPA_SIGMA * t);
+    return z;
+}
+MMPC_DEV void mmpc_prox_update(double alpha, double &prox, int &nsmall) {
+    nsmall = alpha < MMPC_PROX_LO ? nsmall + 1 : 0;
+    if (alpha < MMPC_PROX_LO && (nsmall >= 2 || prox > 0.0)) prox = mmpc_min(MMPC_PROX_MAX, mmpc_max(MMPC_PROX0, 4.0 * prox));
+    else if (alpha > 0.5) prox = prox > MMPC_PROX0 * 1e-3 ? 0.25 * prox : 0.0;
+}
 MMPC_DEV bool mmpc_finite(double v) { return fabs(v) < 1.0e300; }
 
 // planar arm segments, manipulator_3DoF.py:29-73 collapsed with A=q1-q2, B=q1-q2-q3
@@ -496,7 +514,8 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
     }
     LANES_END
 
-    int status = 1, it = 0, nfilt = 0, filt_init = 0, nrows_act = 0;
+    int status = 1, it = 0, nfilt = 0, filt_init = 0, nrows_act = 0, nsmall = 0;
+    double prox = 0.0;
     double E0 = 0.0, th_max = 0.0, th_min = 0.0;
     // number of active rows (uniform): box rows that exist + all non-box rows
     for (int r = 0; r < SL_C; r++) {
@@ -663,14 +682,16 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
         int failed = 0;
         for (int attempt = 0; attempt < 2; attempt++) {
             const bool exact = attempt == 0;
+            const double reg = prox;
             // ---- A1: stage Hessian / gradient assembly
             LANES_BEGIN
             for (int k = lane; k < NS; k += MMPC_WAVE) {
                 double *hxx = HXX + k * NXX, *qx = QX + k * NX;
                 mmpc_state_cost<KIND>(P, k == N, X + k * NX, XREF + k * NREF, nullptr, hxx, exact);
+                for (int j = 0; j < NX; j++) hxx[j * (j + 1) / 2 + j] += reg;
                 for (int j = 0; j < NX; j++) qx[j] = GX[k * NX + j];
                 if (k < N) {
-                    for (int a = 0; a < NU; a++) { HUUD[k * NU + a] = 0.0; QU[k * NU + a] = GU[k * NU + a]; }
+                    for (int a = 0; a < NU; a++) { HUUD[k * NU + a] = reg; QU[k * NU + a] = GU[k * NU + a]; }
                     double h02 = 0.0;
                     if (exact) {
                         // - sum_j lam_{k+1,j} d2 f_j/d(x,u)2 : only f3, f4 are nonlinear (base.py:23-24)
@@ -1190,6 +1211,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
             if (accepted || nfilt == 0) break;
             nfilt = 0;  // filter reset heuristic: the filter blocked every trial step
         }
+        if (!teq) mmpc_prox_update(alpha, prox, nsmall);   // (with the terminal equality the forced correction makes nu grow like prox)
         // ---- update
         LANES_BEGIN
         for (int k = lane; k < NS; k += MMPC_WAVE) {
@@ -1206,8 +1228,9 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                 } else dtv = DTR[k * NR + r - SL_C];
                 const double t = T[k * R + r], z = Z[k * R + r];
                 const double dzv = mu / t - z - (z / t) * dtv;
-                T[k * R + r] = t + alpha * dtv;
-                Z[k * R + r] = z + ad * dzv;
+                const double tn = t + alpha * dtv;
+                T[k * R + r] = tn;
+                Z[k * R + r] = mmpc_z_safeguard(z + ad * dzv, tn, mu);
             }
         }
         LANES_END

@@ -510,7 +510,8 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
     double err_d = 0.0, err_p = 0.0, tzmax = 0.0, tzmin = 0.0, zsum = 0.0, cost_c = 0.0, th_c = 0.0, sumlog = 0.0;
     // line-search state: the evaluation of a trial point IS the evaluation the next iteration starts from (98.6 % of the
     // first trials are accepted), so the loop below evaluates once per trial and never a second time for the accepted one
-    int in_ls = 0, lspass = 0, lsi = 0;
+    int in_ls = 0, lspass = 0, lsi = 0, nsmall = 0;
+    double prox = 0.0;   // proximal term for crawling iterations (mmpc_prox_update)
     double alpha = 0.0, ap = 1.0, ad = 1.0, dphi = 0.0, phi0 = 0.0, th0 = 0.0;
 
     // ---- move to a trial point: the primal variables, the equality multipliers and the slacks of the nonlinear rows by
@@ -522,15 +523,15 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
         if (lane < NS) {
 #pragma unroll
             for (int m = 0; m < M; m++) {
-                const double t = ls.ct[m], z = ls.cz[m], dtv = ls.cdt[m];
-                if (first) { const double it_ = mmpc_rcp(t); ls.cz[m] = z + ad * (mu * it_ - z - z * it_ * dtv); }
-                ls.ct[m] = t + d_alpha * dtv;
+                const double t = ls.ct[m], z = ls.cz[m], dtv = ls.cdt[m], tn = t + d_alpha * dtv;
+                if (first) { const double it_ = mmpc_rcp(t); ls.cz[m] = mmpc_z_safeguard(z + ad * (mu * it_ - z - z * it_ * dtv), tn, mu); }
+                ls.ct[m] = tn;
             }
 #pragma unroll
             for (int i = 0; i < NSELF; i++) {
-                const double t = ls.st[i], z = ls.sz[i], dtv = ls.sdt[i];
-                if (first) { const double it_ = mmpc_rcp(t); ls.sz[i] = z + ad * (mu * it_ - z - z * it_ * dtv); }
-                ls.st[i] = t + d_alpha * dtv;
+                const double t = ls.st[i], z = ls.sz[i], dtv = ls.sdt[i], tn = t + d_alpha * dtv;
+                if (first) { const double it_ = mmpc_rcp(t); ls.sz[i] = mmpc_z_safeguard(z + ad * (mu * it_ - z - z * it_ * dtv), tn, mu); }
+                ls.st[i] = tn;
             }
         }
         // (same phase: every lane touches only its own registers and its own words of XU / LAM / S)
@@ -543,8 +544,9 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                 if (first) {
                     const double lo = ls.b_lo[p], hi = ls.b_hi[p];
                     const bool alo = lo > -1e299, ahi = hi < 1e299;
-                    if (alo) { const double z = ls.lo_z[p], it_ = mmpc_rcp(mmpc_box_t(val - lo)); ls.lo_z[p] = z + ad * (mu * it_ - z - z * it_ * dv); }
-                    if (ahi) { const double z = ls.hi_z[p], it_ = mmpc_rcp(mmpc_box_t(hi - val)); ls.hi_z[p] = z + ad * (mu * it_ - z + z * it_ * dv); }
+                    const double vn = val + d_alpha * dv;
+                    if (alo) { const double z = ls.lo_z[p], it_ = mmpc_rcp(mmpc_box_t(val - lo)); ls.lo_z[p] = mmpc_z_safeguard(z + ad * (mu * it_ - z - z * it_ * dv), mmpc_box_t(vn - lo), mu); }
+                    if (ahi) { const double z = ls.hi_z[p], it_ = mmpc_rcp(mmpc_box_t(hi - val)); ls.hi_z[p] = mmpc_z_safeguard(z + ad * (mu * it_ - z + z * it_ * dv), mmpc_box_t(hi - vn), mu); }
                 }
                 if (idx >= NX) XU[idx] = val + d_alpha * dv;   // x_0 is data
             }
@@ -733,6 +735,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                 if (retry) { apply_step(anext - alpha, false); alpha = anext; continue; }
             }
             in_ls = 0;   // accepted (or every trial rejected: the last one is kept, as IPOPT without restoration would stall too)
+            mmpc_prox_update(alpha, prox, nsmall);
             MMPC_TS(12)
         }
         double sd = zsum / (nrows_act + (double)(NS * NX));
@@ -765,6 +768,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
 #pragma unroll 1
         for (int attempt = 0; attempt < 2; attempt++) {
             const bool exact = attempt == 0;
+            const double reg = prox;
             // ---- A1 (stage lanes): stage Hessian incl. elimination of s_k
             LANES_BEGIN
             auto &ls = MMPC_LS;
@@ -774,7 +778,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
 #pragma unroll
                 for (int e = 0; e < NXX; e++) hxx[e] = 0.0;
 #pragma unroll
-                for (int j = 0; j < NX; j++) { hxx[j * (j + 1) / 2 + j] = CST[(k < N ? MMPC_C_WQ : MMPC_C_WP) + j]; qx[j] = RB[k * NV + j]; }
+                for (int j = 0; j < NX; j++) { hxx[j * (j + 1) / 2 + j] = CST[(k < N ? MMPC_C_WQ : MMPC_C_WP) + j] + reg; qx[j] = RB[k * NV + j]; }
                 double h02 = 0.0;
                 if (k < N && exact) {
                     const double *cv = CV + k * MMPC_NCV;
@@ -882,7 +886,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                 for (int a = 0; a < 6; a++) ls.vx[a] = vx[a];
                 HUX02[k] = h02;
 #pragma unroll
-                for (int c = 0; c < NU; c++) HUUD[k * NU + c] = CST[MMPC_C_RW2 + c * NU + c];
+                for (int c = 0; c < NU; c++) HUUD[k * NU + c] = CST[MMPC_C_RW2 + c * NU + c] + reg;
             }
             LANES_END
             if (NSELF) {

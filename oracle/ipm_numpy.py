@@ -48,11 +48,17 @@ class Options:
     nu_lam = 0.0
     filter = True
     inertia = False
+    inertia_streak = 0      # >0 (experiment, off: it trades the 600-800-iteration cases for others that take 1300+): inertia correction (exact Hessian + delta I) instead of the Gauss-Newton fallback once the
+                            # exact Hessian has failed in this many consecutive iterations (slow linear convergence near saddles)
     slack_reset = False
     delta0 = 1e-4
     delta_min = 1e-20
     delta_max = 1e10
     bound_push = 1e-2
+    kappa_sigma = 1e10
+    # proximal term for crawling iterations: after two consecutive steps with alpha < prox_lo the Hessian gets + prox I on
+    # (x, u) (prox0, then x prox_up per further small step); it is divided by prox_dn after a step with alpha > prox_hi
+    prox = True; prox0 = 100.0; prox_up = 4.0; prox_dn = 4.0; prox_lo = 0.05; prox_hi = 0.5; prox_need = 2; prox_max = 1e4
     rho_eq = 1e4          # augmentation weight of the terminal-xy equality inside the factorisation
 
 
@@ -206,10 +212,15 @@ def solve(prob: nlp.Problem, U0=None, X0=None, opt: Options = None, verbose=Fals
     nu_merit = 1.0
     delta_last = 0.0
     nu_eq = np.zeros(2)
+    prox_cur, nsmall, nstreak = 0.0, 0, 0
     filt = None
     nfail = 0
     it = 0
     for it in range(opt.max_iter + 1):
+        # ---------------- multiplier safeguard (IPOPT eq. 16, kappa_Sigma = 1e10) --------
+        # keeps z_i within [mu / (kappa t_i), kappa mu / t_i]: full dual steps next to tiny primal ones cannot run away
+        for k in range(N + 1):
+            z[k] = np.minimum(np.maximum(z[k], mu / (opt.kappa_sigma * t[k])), opt.kappa_sigma * mu / t[k])
         # ---------------- evaluation ------------------------------------
         ev = _eval_all(prob, rows, X, U, s, 2)
         gX, gU, gs = nlp.cost_grad(prob, X, U, s)
@@ -356,9 +367,13 @@ def solve(prob: nlp.Problem, U0=None, X0=None, opt: Options = None, verbose=Fals
                 Pm[k] = 0.5 * (Pm[k] + Pm[k].T)
                 pv[k] = gx_ + G.T @ kf[k]
             return Pm, pv, K, kf, hss, gss, vx, vxN, pvv, kfv
-        fac = factor(opt.exact_hessian) if opt.exact_hessian else None
+        # (not with the terminal equality: its full correction E dx_N = e is forced whatever the damping, the multipliers
+        #  nu then grow like prox)
+        prox = prox_cur if (opt.prox and not p.terminal_xy_equality) else 0.0
+        fac = factor(opt.exact_hessian, prox) if opt.exact_hessian else None
         nreg = 0
-        if fac is None and opt.exact_hessian and opt.inertia:
+        nstreak = nstreak + 1 if (fac is None and opt.exact_hessian) else 0
+        if fac is None and opt.exact_hessian and (opt.inertia or (opt.inertia_streak and nstreak >= opt.inertia_streak and not p.terminal_xy_equality)):
             # IPOPT-style inertia correction: exact Hessian + delta*I, delta growing until the
             # stage-wise factorisation has only positive pivots
             delta = opt.delta0 if delta_last == 0.0 else max(opt.delta_min, delta_last / 3.0)
@@ -371,7 +386,7 @@ def solve(prob: nlp.Problem, U0=None, X0=None, opt: Options = None, verbose=Fals
                 delta_last = delta
         if fac is None:
             nreg += 1 if opt.exact_hessian else 0
-            fac = factor(False)
+            fac = factor(False, prox)
         Pm, pv, K, kf, hss, gss, vx, vxN, pvv, kfv = fac
         nu_new = np.zeros(2)
         if p.terminal_xy_equality:
@@ -488,6 +503,12 @@ def solve(prob: nlp.Problem, U0=None, X0=None, opt: Options = None, verbose=Fals
                     break
                 alpha *= 0.5
         nfail += (not accepted)
+        if opt.prox:
+            nsmall = nsmall + 1 if alpha < opt.prox_lo else 0
+            if alpha < opt.prox_lo and (nsmall >= opt.prox_need or prox_cur > 0.0):
+                prox_cur = min(opt.prox_max, max(opt.prox0, prox_cur * opt.prox_up))
+            elif alpha > opt.prox_hi:
+                prox_cur = prox_cur / opt.prox_dn if prox_cur > opt.prox0 * 1e-3 else 0.0
         if verbose:
             print(f"      ap {ap:.3f} ad {ad:.3f} alpha {alpha:.4f} ls {ls} nreg {nreg} nu {nu_merit:.2e} dm {dm:.3e}")
         X = X + alpha * dX; U = U + alpha * dU; s = s + alpha * ds

@@ -35,6 +35,10 @@
 #define LMX 8           /* max half-space obstacles */
 #define RMX (2 * NUM + 2 * NXM + MMX + 4 + 6)
 #define FCAP 16
+#define PROX0 100.0
+#define PROX_LO 0.05
+#define PROX_MAX 1e4
+#define KAPPA_SIGMA 1e10
 #define RHO_EQ 1e4     /* augmentation weight of the terminal-xy equality inside the factorisation */
 
 typedef struct {
@@ -412,7 +416,7 @@ static void chol_solve(double L[NUM][NUM], int n, double *b) {
 }
 
 /* stage QP assembly + s Schur complement + Riccati factorisation.  returns 0 on a failed pivot */
-static int factor(work *w, double mu, int use_exact) {
+static int factor(work *w, double mu, int use_exact, double prox) {
     const oracle_cfg *c = w->cfg;
     int nx = w->nx, nu = w->nu, N = w->N;
     for (int k = 0; k <= N; k++) { w->hss[k] = 2 * c->S; w->gss[k] = w->gs[k]; memset(w->vx[k], 0, sizeof(w->vx[k])); }
@@ -421,10 +425,10 @@ static int factor(work *w, double mu, int use_exact) {
         {
             double Hcv[NXM][NXM];
             state_cost(w, k, w->X[k], 0, w->Hxx[k], Hcv);
-            for (int i = 0; i < nx; i++) { for (int j = 0; j < nx; j++) if (use_exact) w->Hxx[k][i][j] += Hcv[i][j]; w->qx[k][i] = w->gX[k][i]; }
+            for (int i = 0; i < nx; i++) { for (int j = 0; j < nx; j++) if (use_exact) w->Hxx[k][i][j] += Hcv[i][j]; w->qx[k][i] = w->gX[k][i]; w->Hxx[k][i][i] += prox; }
         }
         if (k < N) {
-            for (int i = 0; i < nu; i++) { for (int j = 0; j < nu; j++) w->Huu[k][i][j] = w->RW2[i][j]; w->qu[k][i] = w->gU[k][i]; for (int j = 0; j < nx; j++) w->Hux[k][i][j] = 0; }
+            for (int i = 0; i < nu; i++) { for (int j = 0; j < nu; j++) w->Huu[k][i][j] = w->RW2[i][j]; w->Huu[k][i][i] += prox; w->qu[k][i] = w->gU[k][i]; for (int j = 0; j < nx; j++) w->Hux[k][i][j] = 0; }
             if (use_exact) {
                 /* - sum_j lam_{k+1,j} d2 f_j : only f3, f4 (base.py:23-24) are nonlinear */
                 double sn = sin(w->X[k][2]), cs = cos(w->X[k][2]), l3 = w->lam[k + 1][3], l4 = w->lam[k + 1][4], dt = c->dt;
@@ -590,13 +594,19 @@ int mmpc_oracle_solve(const oracle_cfg *cfg, const double *x_init, const double 
     int nrows_act = 0;
     for (int k = 0; k <= N; k++) for (int r = 0; r < w->nrow; r++) if (w->act[k][r]) {
         double v = -w->h[k][r]; w->t[k][r] = v > 1e-2 ? v : 1e-2; w->z[k][r] = mu / w->t[k][r]; nrows_act++; }
-    int status = 1, it = 0, nf = 0;
+    int status = 1, it = 0, nf = 0, nsmall = 0;
+    double prox = 0.0;
     double th_max = 0, th_min = 0, E0 = 0;
     fent filt[FCAP];
     int filt_init = 0, nfilt = 0;
     const double tol = cfg->tol;
     static __thread double Xn[NSM][NXM], Un[NSM][NUM], sn[NSM], tn[NSM][RMX];
     for (it = 0; it <= cfg->max_iter; it++) {
+        /* ---- multiplier safeguard (IPOPT eq. 16): z within [mu/(kappa t), kappa mu/t] */
+        for (int k = 0; k <= N; k++) for (int r = 0; r < w->nrow; r++) if (w->act[k][r]) {
+            double lo_ = mu / (KAPPA_SIGMA * w->t[k][r]), hi_ = KAPPA_SIGMA * mu / w->t[k][r];
+            if (w->z[k][r] < lo_) w->z[k][r] = lo_; else if (w->z[k][r] > hi_) w->z[k][r] = hi_;
+        }
         /* ---- evaluation at the current point */
         eval_rows(w, w->X, w->U, w->s, w->h, 1);
         for (int k = 0; k <= N; k++) {
@@ -669,7 +679,7 @@ int mmpc_oracle_solve(const oracle_cfg *cfg, const double *x_init, const double 
         }
         if (changed) filt_init = 0;
         /* ---- Newton direction */
-        if (!factor(w, mu, 1)) if (!factor(w, mu, 0)) { status = 2; break; }
+        if (!factor(w, mu, 1, prox)) if (!factor(w, mu, 0, prox)) { status = 2; break; }
         w->nu_new[0] = w->nu_new[1] = 0;
         if (cfg->terminal_xy_eq) {
             double d0[NXM] = {0}, Dv[NXM][2], u0[NUM], Uv[NUM][2], t0[NXM], Tv[NXM][2];
@@ -770,6 +780,11 @@ int mmpc_oracle_solve(const oracle_cfg *cfg, const double *x_init, const double 
             nfilt = 0; /* filter reset heuristic: the filter blocked every trial step */
         }
         nf += !accepted;
+        /* proximal term for crawling iterations (oracle/ipm_numpy.py: Options.prox*) */
+        nsmall = alpha < PROX_LO ? nsmall + 1 : 0;
+        if (cfg->terminal_xy_eq) prox = 0.0;   /* the forced correction E dx_N = e makes nu grow like prox */
+        else if (alpha < PROX_LO && (nsmall >= 2 || prox > 0.0)) { prox = prox * 4.0 > PROX0 ? prox * 4.0 : PROX0; if (prox > PROX_MAX) prox = PROX_MAX; }
+        else if (alpha > 0.5) prox = prox > PROX0 * 1e-3 ? prox / 4.0 : 0.0;
         /* ---- update */
         for (int j = 0; j < 2; j++) w->nu_eq[j] += alpha * (w->nu_new[j] - w->nu_eq[j]);
         for (int k = 0; k <= N; k++) {
