@@ -168,8 +168,8 @@ def main():
         by = algorithmic_bytes_per_solve(N, nx, nu, M) * Bl
         traffic = None
         mfma = None
-        tpath = os.path.join(_ROOT, "profiles", "r01_j_pmc_traffic.json")
-        mpath = os.path.join(_ROOT, "profiles", "r01_j_pmc_mfma.json")
+        tpath = os.path.join(_ROOT, "profiles", "r01_k_pmc_traffic.json")
+        mpath = os.path.join(_ROOT, "profiles", "r01_k_pmc_mfma.json")
         if world == 1 and (N, M, Bg) == (20, 5, 8192) and os.path.exists(tpath):
             # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), collected
             # separately with the same command and committed under profiles/ (bench.py cannot run the profiler itself)
@@ -182,7 +182,7 @@ def main():
             mfma = {"insts_per_iter": n_mfma, "busy_cycles_per_iter": c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0),
                     "wave_cycles_per_iter": 4.0 * c.get("SQ_WAVE_CYCLES", 0.0),
                     "executed_tflops": n_mfma * 2048.0 * mean_iters * Bl / (k_ms * 1e-3) / 1e12,
-                    "source": "profiles/r01_j_pmc_mfma.json"}
+                    "source": "profiles/r01_k_pmc_mfma.json"}
             mfma["util"] = mfma["executed_tflops"] / FP64_PEAK_TFLOPS
         res = {
             "metric": "MPC solves/sec, whole-body N=%d batch=%d" % (N, args.batch),
@@ -212,6 +212,7 @@ def main():
                 eng.solve_batch(hx, d["traj_ref"][:Bl], d["u_ref"][:Bl], d["obs"][:Bl])
             res["host_pointer_api"] = {"value": 3 * Bl / (time.perf_counter() - h0), "unit": "solves/s",
                                        "note": "mmpc_solve_batch with pageable host arrays in and out (PCIe-inclusive, cold start)"}
+        if world == 1 and not args.no_cpu:   # (not in the profiler passes: they must only see the batch launches)
             # latency of ONE solve through the reference's own call (controller.solve(x_init, traj_ref, u_ref) -> u0), the
             # number the closed-loop driver sees per tick (interface_wholebody_qref.py:134); cold start each time
             import contextlib, io
