@@ -204,7 +204,7 @@ def main():
                                  if args.scaling == "weak" else [3]),
                        "parallelism": "batch-sharded x%d%s" % (world, " + all-gather(X,U,s)" if world > 1 else "")},
             "solver": {"converged_frac": n_conv / Bg, "mean_iters": mean_iters, "max_iters": it_max,
-                       "max_scaled_kkt": err_max, "lds_bytes_per_problem": eng.lds_bytes},
+                       "max_scaled_kkt": err_max, "lds_bytes_per_problem": eng.lds_bytes, "problems_per_cu": eng.problems_per_cu},
             "roofline": {"bound": "mfma", "kernel": "mmpc_fast_kernel<0,20,5>" if (N, M) == (20, 5) else "mmpc_solve_kernel<0>", "achieved": achieved_tf,
                          "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tf / FP64_PEAK_TFLOPS,
                          "traffic": traffic, "kernel_ms": k_ms, "mfma": mfma,
@@ -303,7 +303,7 @@ def main_c5(args):
                              xc[:, 3] + 0.1 * (u0[:, 0] * c - xc[:, 4] * xc[:, 5]),
                              xc[:, 4] + 0.1 * (u0[:, 0] * s + xc[:, 3] * xc[:, 5]), xc[:, 5] + 0.1 * u0[:, 1],
                              xc[:, 6] + 0.1 * u0[:, 2], xc[:, 7] + 0.1 * u0[:, 3], xc[:, 8] + 0.1 * u0[:, 4]], dim=1)
-            its.append((out["iters"].double().mean(), (out["status"] == 0).double().mean()))
+            its.append((out["iters"].double().mean(), (out["status"] == 0).double().mean(), out["iters"].max()))
         return its
 
     for _ in range(max(1, args.warmup // 2)):
@@ -319,8 +319,9 @@ def main_c5(args):
            "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
            "dtype": "f64", "data": "synthetic",
            "config": {"workload": "C5: whole-body N=30, M=8 moving circle obstacles, batch %d, %d ticks (tick 0 cold)" % (B, T)},
-           "solver": {"mean_iters_per_tick": [float(a) for a, _ in its], "converged_frac_per_tick": [float(b) for _, b in its],
-                      "lds_bytes_per_problem": eng.lds_bytes}}
+           "solver": {"mean_iters_per_tick": [float(a) for a, _, _ in its], "converged_frac_per_tick": [float(b) for _, b, _ in its],
+                      "max_iters_per_tick": [int(c) for _, _, c in its],
+                      "lds_bytes_per_problem": eng.lds_bytes, "problems_per_cu": eng.problems_per_cu}}
     print(json.dumps(res))
 
 

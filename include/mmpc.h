@@ -116,6 +116,9 @@ int mmpc_ik_batch_device(int device, int B, const double *d_q0, const double *d_
 
 /* bytes of LDS one problem instance occupies (one 64-lane workgroup) */
 int mmpc_lds_bytes(mmpc_handle h);
+/* problem instances (workgroups) the runtime keeps resident per compute unit for the kernel this handle launches
+ * (hipOccupancyMaxActiveBlocksPerMultiprocessor: registers allow 4 - one wave per SIMD -, LDS may allow fewer) */
+int mmpc_problems_per_cu(mmpc_handle h);
 const char *mmpc_last_error(mmpc_handle h);
 const char *mmpc_version(void);
 

@@ -22,7 +22,7 @@ class MmpcConfig(C.Structure):
 
 EXPORTS = ["mmpc_create", "mmpc_destroy", "mmpc_set_weights", "mmpc_set_terminal_xy_equality", "mmpc_reset",
            "mmpc_solve_batch", "mmpc_solve_batch_device", "mmpc_get_u_latest", "mmpc_set_u_latest",
-           "mmpc_lds_bytes", "mmpc_last_error", "mmpc_version", "mmpc_ik_batch", "mmpc_ik_batch_device"]
+           "mmpc_lds_bytes", "mmpc_problems_per_cu", "mmpc_last_error", "mmpc_version", "mmpc_ik_batch", "mmpc_ik_batch_device"]
 
 _lib = None
 _dp = C.POINTER(C.c_double)
@@ -37,6 +37,13 @@ def lib():
             raise RuntimeError(
                 "HIP extension %s is missing - build it with __graft_entry__.build() "
                 "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+        # torch ships its own libamdhip64.so.7 / libhsa-runtime64.so.1; libmmpc.so asks for the same sonames.  Whichever is
+        # mapped first serves both, and torch cannot initialise on the system copy ("No HIP GPUs are available" when the first
+        # torch.cuda call comes after a solve) - so the process settles on torch's runtime before the library is opened.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         L.mmpc_create.argtypes = [C.POINTER(MmpcConfig), C.POINTER(C.c_void_p)]
         L.mmpc_destroy.argtypes = [C.c_void_p]
@@ -48,6 +55,7 @@ def lib():
         L.mmpc_get_u_latest.argtypes = [C.c_void_p, C.c_int, _dp]
         L.mmpc_set_u_latest.argtypes = [C.c_void_p, C.c_int, _dp]
         L.mmpc_lds_bytes.argtypes = [C.c_void_p]
+        L.mmpc_problems_per_cu.argtypes = [C.c_void_p]
         L.mmpc_last_error.argtypes = [C.c_void_p]
         L.mmpc_last_error.restype = C.c_char_p
         L.mmpc_version.restype = C.c_char_p
@@ -136,6 +144,10 @@ class Engine:
     @property
     def lds_bytes(self):
         return lib().mmpc_lds_bytes(self._h)
+
+    @property
+    def problems_per_cu(self):
+        return lib().mmpc_problems_per_cu(self._h)
 
     def set_weights(self, Q=None, R=None, P=None, S=None, W=None):
         def m(a, n):

@@ -197,14 +197,22 @@ struct MmpcFastLayout {
 #define MMPC_C_RW2 66      // RW2 [25] (full)
 #define MMPC_C_SIZE 92
 
+// Long horizons (N >= MMPC_SLIM_NMIN) leave the read-only inputs that are touched once or twice per iteration - the
+// reference trajectory, the previous inputs and the per-stage obstacle table - in HBM/L2 instead of LDS: at N = 30, M = 8 that is 63.2 -> 52.6 KB
+// per problem, i.e. three resident problems per CU instead of two.
+#ifndef MMPC_SLIM_NMIN
+#define MMPC_SLIM_NMIN 21
+#endif
 template <int KIND, int N>
 MMPC_HD MmpcFastLayout mmpc_fast_layout(int M, int obs_per_stage) {
     typedef MmpcFastDims<KIND, N> F;
+    constexpr bool SLIM = N >= MMPC_SLIM_NMIN;
     MmpcFastLayout L;
     int o = 0;
 #define MMPC_CARVE(name, n) L.name = o; o += (n); o = (o + 1) & ~1;
     MMPC_CARVE(XU, F::NS * F::NV) MMPC_CARVE(S, F::NS) MMPC_CARVE(LAM, F::NS * F::NX)
-    MMPC_CARVE(XUREF, F::NS * F::NV) MMPC_CARVE(ULAST, F::NS * F::NU) MMPC_CARVE(OBS, (obs_per_stage ? F::NS : 1) * M * 3)
+    MMPC_CARVE(XUREF, SLIM ? 0 : F::NS * F::NV) MMPC_CARVE(ULAST, SLIM ? 0 : F::NS * F::NU)
+    MMPC_CARVE(OBS, obs_per_stage ? (SLIM ? 0 : F::NS * M * 3) : M * 3)
     MMPC_CARVE(CST, MMPC_C_SIZE) MMPC_CARVE(CV, F::NS * MMPC_NCV) MMPC_CARVE(CD, F::NS * F::NX) MMPC_CARVE(TRG, F::NS * 8)
     MMPC_CARVE(HXX, F::NS * F::NXX) MMPC_CARVE(QXU, F::NS * F::NV) MMPC_CARVE(HUXL, F::NU * F::NX)
     MMPC_CARVE(HUUL, F::NUU) MMPC_CARVE(HUX02, F::NS) MMPC_CARVE(HUUD, F::NS * F::NU) MMPC_CARVE(SN, 16)
@@ -305,6 +313,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
     // stages per trip of the Riccati / forward loops: unrolling saves the per-stage pointer bumps and register shuffles,
     // but costs registers - it only pays where the kernel does not spill (measured per instantiation)
     constexpr bool ROOMY = KIND == 0 && N <= MMPC_UNROLL_NMAX;
+    constexpr bool SLIM = N >= MMPC_SLIM_NMIN;   // references and per-stage obstacles are read from HBM/L2 (see mmpc_fast_layout)
     constexpr int RIC_UNROLL = ROOMY ? MMPC_RIC_UNROLL : 1, FWD_UNROLL = ROOMY ? MMPC_FWD_UNROLL : 1;
     const MmpcFastLayout L = mmpc_fast_layout<KIND, N>(M, P.obs_per_stage);
     double *XU = lds + L.XU, *S = lds + L.S, *LAM = lds + L.LAM, *XUREF = lds + L.XUREF, *ULAST = lds + L.ULAST,
@@ -321,7 +330,16 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
     MmpcLaneState<KIND, N, MC> ls_one;
     double wr_one[8];
 #endif
-    auto obs_ptr = [&](int k, int m) -> const double * { return OBS + ((P.obs_per_stage ? k * M : 0) + m) * 3; };
+    const double *const OBSP = (SLIM && P.obs_per_stage) ? io.obs : OBS;
+    auto obs_ptr = [&](int k, int m) -> const double * { return OBSP + ((P.obs_per_stage ? k * M : 0) + m) * 3; };
+    auto ulast_at = [&](int k, int a) -> double {
+        if (!SLIM) return ULAST[k * NU + a];
+        return k < N ? io.u_last[k * NU + a] : 0.0;
+    };
+    auto ref_at = [&](int idx, int k, int v) -> double {
+        if (!SLIM) return XUREF[idx];
+        return v < NX ? io.traj_ref[k * NX + v] : (k < N ? io.u_ref[k * NU + v - NX] : 0.0);
+    };
     auto slack_idx = [&](int k) -> int { return k < N - 1 ? k : N - 1; };
 
     // ------------------------------------------------------------------ load
@@ -339,12 +357,14 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
             ref = k < N ? io.u_ref[k * NU + v - NX] : 0.0;
         }
         XU[i] = val;
-        XUREF[i] = ref;
+        if (!SLIM) XUREF[i] = ref;
     }
-    for (int i = lane; i < NS * NU; i += MMPC_WAVE) ULAST[i] = i < N * NU ? io.u_last[i] : 0.0;
+    if (!SLIM)
+        for (int i = lane; i < NS * NU; i += MMPC_WAVE) ULAST[i] = i < N * NU ? io.u_last[i] : 0.0;
     for (int i = lane; i < NS * NX; i += MMPC_WAVE) LAM[i] = 0.0;
     for (int i = lane; i < NS; i += MMPC_WAVE) S[i] = 0.0;
-    for (int i = lane; i < (P.obs_per_stage ? NS : 1) * M * 3; i += MMPC_WAVE) OBS[i] = io.obs[i];
+    if (!(SLIM && P.obs_per_stage))
+        for (int i = lane; i < (P.obs_per_stage ? NS : 1) * M * 3; i += MMPC_WAVE) OBS[i] = io.obs[i];
     for (int i = lane; i < MMPC_C_SIZE; i += MMPC_WAVE) {
         double v = 0.0;
         if (i < 18) v = P.xlim[i / 9][i % 9];
@@ -429,7 +449,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
             alo = ex && mmpc_finite(lo); ahi = ex && mmpc_finite(hi);
         } else {
             const int a = v - NX;
-            const double ul = ULAST[k * NU + a];
+            const double ul = ulast_at(k, a);
             lo = mmpc_max(CST[MMPC_C_ULIM + a], ul + CST[MMPC_C_DULIM + a]);
             hi = mmpc_min(CST[MMPC_C_ULIM + 5 + a], ul + CST[MMPC_C_DULIM + 5 + a]);
             const bool ex = k < N;
@@ -678,8 +698,8 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                 // the input-only terms read a valid dummy address for state variables and carry weight 0 there
                 const bool isu = v >= NX && k < N;
                 const int au = isu ? v - NX : 0;
-                const double val = XU[idx], ref = XUREF[idx], rb0 = RB[idx];
-                const double ul = ULAST[(isu ? k : 0) * NU + au], ww0 = CST[MMPC_C_WW + au];
+                const double val = XU[idx], ref = ref_at(idx, k, v), rb0 = RB[idx];
+                const double ul = ulast_at(isu ? k : 0, au), ww0 = CST[MMPC_C_WW + au];
                 const double wq = CST[v < NX ? (k < N ? MMPC_C_WQ : MMPC_C_WP) + v : MMPC_C_WR + v - NX];
                 mmpc_sched_fence();
                 // cost gradient / value (diagonal weights): mpc_wholebody_qref.py:192-201,240-242
@@ -1244,10 +1264,11 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
     for (int idx = lane; idx < NPAIR; idx += MMPC_WAVE) {
         const int k = idx / NV, v = idx % NV;
         const double val = XU[idx];
-        double e = val - XUREF[idx];
-        if (KIND == 1 && v == 2) e = mmpc_angle_diff(val, XUREF[idx]);
+        const double ref = ref_at(idx, k, v);
+        double e = val - ref;
+        if (KIND == 1 && v == 2) e = mmpc_angle_diff(val, ref);
         f += 0.5 * w_diag(k, v) * e * e;
-        if (v >= NX && k < N) { const double e2 = val - ULAST[k * NU + v - NX]; f += 0.5 * CST[MMPC_C_WW + v - NX] * e2 * e2; }
+        if (v >= NX && k < N) { const double e2 = val - ulast_at(k, v - NX); f += 0.5 * CST[MMPC_C_WW + v - NX] * e2 * e2; }
         if (v < NX) io.X[k * NX + v] = val;
         else if (k < N) io.U[k * NU + v - NX] = val;
     }

@@ -111,6 +111,7 @@ struct mmpc_handle_s {
     int nx, nu, nref, lds_bytes;
     int fast;               // 1: specialised kernel exists for (kind, N, M)
     int fast_lds_bytes;
+    int per_cu, fast_per_cu;   // resident workgroups (= problems) per CU the runtime reports for the two kernels
     int diag;               // weights are diagonal (required by the specialised kernel)
     int warm;               // 1 once a solve has filled u_latest (x_guess)
     // device-side state and staging (capacity max_batch)
@@ -182,6 +183,7 @@ extern "C" int mmpc_debug_read_stamps(unsigned long long *out16) {
 extern "C" const char *mmpc_version(void) { return "mmpc 0.1 (gfx950)"; }
 static thread_local char g_err[512] = "";   // errors of the handle-less entry points (mmpc_ik_*)
 extern "C" const char *mmpc_last_error(mmpc_handle h) { return h ? h->err : g_err; }
+extern "C" int mmpc_problems_per_cu(mmpc_handle h) { return h ? ((h->fast && h->diag && !h->hp.terminal_xy_eq) ? h->fast_per_cu : h->per_cu) : MMPC_E_ARG; }
 extern "C" int mmpc_lds_bytes(mmpc_handle h) { return h ? ((h->fast && h->diag && !h->hp.terminal_xy_eq) ? h->fast_lds_bytes : h->lds_bytes) : MMPC_E_ARG; }
 
 extern "C" int mmpc_create(const mmpc_config *cfg, mmpc_handle *out) {
@@ -225,13 +227,21 @@ extern "C" int mmpc_create(const mmpc_config *cfg, mmpc_handle *out) {
         HIPCHK(h, hipFuncSetAttribute((const void *)mmpc_solve_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes));
     else
         HIPCHK(h, hipFuncSetAttribute((const void *)mmpc_solve_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes));
-    h->fast = 0; h->fast_lds_bytes = 0;
+    h->per_cu = 0;
+    if (cfg->kind == MMPC_KIND_WHOLEBODY)
+        HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&h->per_cu, mmpc_solve_kernel<0>, MMPC_WAVE, h->lds_bytes));
+    else if (cfg->kind == MMPC_KIND_BASE)
+        HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&h->per_cu, mmpc_solve_kernel<1>, MMPC_WAVE, h->lds_bytes));
+    else
+        HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&h->per_cu, mmpc_solve_kernel<2>, MMPC_WAVE, h->lds_bytes));
+    h->fast = 0; h->fast_lds_bytes = 0; h->fast_per_cu = 0;
     {
 #define MMPC_X(K, NN, MM, WW)                                                                                        \
         if (cfg->kind == K && cfg->N == NN && cfg->M == MM && cfg->L == 0) {                                                                       \
             h->fast = 1;                                                                                               \
             h->fast_lds_bytes = mmpc_fast_layout<K, NN>(MM, p.obs_per_stage).total * (int)sizeof(double);         \
             HIPCHK(h, hipFuncSetAttribute((const void *)mmpc_fast_kernel<K, NN, MM, WW>, hipFuncAttributeMaxDynamicSharedMemorySize, h->fast_lds_bytes)); \
+            HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&h->fast_per_cu, mmpc_fast_kernel<K, NN, MM, WW>, MMPC_WAVE, h->fast_lds_bytes)); \
         }
         MMPC_FAST_LIST(MMPC_X)
 #undef MMPC_X
