@@ -72,12 +72,19 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # MMPC_BENCH_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks (ranks share devices,
+    # the all-gather goes through gloo); the driver's runs use the default, RCCL
+    backend = os.environ.get("MMPC_BENCH_BACKEND", "nccl")
+    local_dev = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     N, M = args.horizon, args.obstacles
     Bg = args.batch * (world if args.scaling == "weak" else 1)       # global number of instances
@@ -99,7 +106,7 @@ def main():
         d = synth.make_batch(Bg, N=N, M=M)
         sl = slice(lo, hi)
     robot = mm.MobileManipulator(0.1)
-    ctrl = mm.MPCWholeBody(robot, [], [], N=N, max_batch=Bl, device=local_rank, n_obstacles=M)
+    ctrl = mm.MPCWholeBody(robot, [], [], N=N, max_batch=Bl, device=local_dev, n_obstacles=M)
     eng = ctrl._engine
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a[sl])).to(dev)
     x_init = t(np.clip(d["x_init"], ctrl.xlim[0], ctrl.xlim[1]))
@@ -107,18 +114,28 @@ def main():
     ulast = torch.zeros((Bl, N, nu), dtype=torch.float64, device=dev)   # cold start: u_latest = 0 (:298-299)
     out = eng.solve_batch_device(x_init, traj, uref, ulast, obs)
     packed = gathered = None
+    pending = [None, None]
     if world > 1:
         rec = sharding.record_len(N, nx, nu)
-        packed = torch.empty((Bl, rec), dtype=torch.float64, device=dev)
-        gathered = torch.empty((Bg, rec), dtype=torch.float64, device=dev)
+        packed = [torch.empty((Bl, rec), dtype=torch.float64, device=dev) for _ in range(2)]
+        gathered = [torch.empty((Bg, rec), dtype=torch.float64, device=dev) for _ in range(2)]
 
     def gather(i):
-        # the one collective of the path: all-gather of the solved (X,U,s) over xGMI (RCCL), inside the timed region
-        sharding.pack_solution(out["X"], out["U"], out["s"], out=packed)
-        sharding.allgather_solutions(packed, Bg, dist, gathered=gathered)
+        # the one collective of the path: all-gather of the solved (X,U,s) over xGMI (RCCL), inside the timed region.
+        # Double-buffered and asynchronous: the gather of step i travels on RCCL's stream while step i+1 is solved; a
+        # buffer pair is reused only after its previous gather has completed, and drain() waits for the last ones.
+        b = i & 1
+        if pending[b] is not None:
+            pending[b].wait()
+            pending[b] = None
+        sharding.pack_solution(out["X"], out["U"], out["s"], out=packed[b])
+        _, pending[b] = sharding.allgather_solutions(packed[b], Bg, dist, gathered=gathered[b], async_op=True)
 
     def drain():
-        pass
+        for b in range(2):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
 
     for i in range(args.warmup):
         eng.solve_batch_device(x_init, traj, uref, ulast, obs, out=out)

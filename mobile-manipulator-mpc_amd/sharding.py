@@ -35,19 +35,21 @@ def unpack_solution(rec, N, nx, nu):
     return rec[:, :a].reshape(B, N + 1, nx), rec[:, a:a + b].reshape(B, N, nu), rec[:, a + b:]
 
 
-def allgather_solutions(packed_local, B_global, dist=None, gathered=None):
+def allgather_solutions(packed_local, B_global, dist=None, gathered=None, async_op=False):
     """All ranks end up with the (B_global, record_len) table in global instance order.
-    Equal shards use one all_gather_into_tensor; ragged shards fall back to all_gather of padded rows."""
+    Equal shards use one all_gather_into_tensor; ragged shards fall back to all_gather of padded rows.
+    async_op=True (equal shards only) returns (gathered, work): the collective runs on the backend's own stream and the
+    caller waits on `work` before it reads `gathered` or reuses `packed_local` - the next batch can be solved meanwhile."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
-        return packed_local
+        return (packed_local, None) if async_op else packed_local
     world, rank = dist.get_world_size(), dist.get_rank()
     rec = packed_local.shape[1]
     if gathered is None:
         gathered = torch.empty((B_global, rec), dtype=packed_local.dtype, device=packed_local.device)
     sizes = [shard_bounds(B_global, world, r)[1] - shard_bounds(B_global, world, r)[0] for r in range(world)]
     if len(set(sizes)) == 1:
-        dist.all_gather_into_tensor(gathered, packed_local.contiguous())
-        return gathered
+        work = dist.all_gather_into_tensor(gathered, packed_local.contiguous(), async_op=async_op)
+        return (gathered, work) if async_op else gathered
     mx = max(sizes)
     pad = torch.zeros((mx, rec), dtype=packed_local.dtype, device=packed_local.device)
     pad[:packed_local.shape[0]] = packed_local
@@ -57,4 +59,4 @@ def allgather_solutions(packed_local, B_global, dist=None, gathered=None):
     for r in range(world):
         gathered[o:o + sizes[r]] = parts[r][:sizes[r]]
         o += sizes[r]
-    return gathered
+    return (gathered, None) if async_op else gathered

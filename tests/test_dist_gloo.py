@@ -29,6 +29,11 @@ def _worker(rank, world, port, B, q):
                             np.zeros((hi - lo, N, nu)), d["obs"][lo:hi])
     packed = sharding.pack_solution(torch.from_numpy(r["X"]), torch.from_numpy(r["U"]), torch.from_numpy(r["s"]))
     table = sharding.allgather_solutions(packed, B, dist)
+    # the asynchronous form bench.py uses (double-buffered: the gather travels while the next batch is solved)
+    table2, work = sharding.allgather_solutions(packed, B, dist, async_op=True)
+    if work is not None:
+        work.wait()
+    assert torch.equal(table2, table)
     X, U, s = sharding.unpack_solution(table, N, nx, nu)
     q.put((rank, X.numpy().copy(), U.numpy().copy(), s.numpy().copy()))
     dist.barrier()
