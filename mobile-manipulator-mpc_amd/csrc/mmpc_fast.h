@@ -24,9 +24,19 @@
 #ifdef MMPC_EMU
 #define MMPC_LS ls_all[lane]
 #define MMPC_WR(i) wr_all[lane][i]
+// value a field of the lane state holds in lane j (the emulator runs the lanes of a phase one after another: a field that
+// is read across lanes and rewritten in the same phase is double-buffered by the parity of the stage)
+#define MMPC_LANE_GET(field, j) (ls_all[j].field)
+#define MMPC_FW_SLOTS 2
+#define MMPC_FW_SLOT(k) ((k) & 1)
+#define LANES_END_REG }
 #else
 #define MMPC_LS ls_one
 #define MMPC_WR(i) wr_one[i]
+#define MMPC_LANE_GET(field, j) mmpc_readlane_f64(ls_one.field, j)
+#define MMPC_FW_SLOTS 1
+#define MMPC_FW_SLOT(k) 0
+#define LANES_END_REG }      // end of a phase whose results travel in registers only: no LDS ordering to enforce
 #endif
 
 // Diagnostic build only (-DMMPC_STAMP): per-phase wave-cycle accounting, accumulated in registers and added to a
@@ -248,14 +258,23 @@ struct MmpcLaneState {
                                                      // stage-(N-1) extra term (Q1 elimination of s_{N-1}) or of the constant 0
     unsigned h_m;                                    // bit r: register r is part of [P | p]; bit 4+r: ... and is stored (lower triangle, p)
     unsigned g_o[F::NGB];                            // GS offset of this lane's entry of the G^T operand (or of the constant 0)
-    unsigned k_o[F::NGB];                            // this lane's entry of the [K | kf] operand in KK / KF: offset | stage stride << 16
+    unsigned k_o, k_s;                               // where this lane stores its gain column: LDS offset | step between inputs << 16, and
+                                                     // the stage stride (lanes that own no column write to a dump slot: step = stride = 0)
     MmpcAcc rP, rT, rM;                              // cost-to-go [P | p], T = P [A B | c], stage matrix M
     double rAB[F::NKB], opa[F::NGB], opb[F::NGB];    // MFMA operands
     double nab[F::NKB], nhm[4];                      // next stage's [A B | c] rows and stage-matrix entries (loaded one stage ahead)
-    unsigned f_c, f_v, f_x;                          // forward roll-out row of [A B]: 4 terms + (5th col | 5th cv<<8 | (a+1)<<16)
+    // forward roll-out, row `lane` of [A B] (base.py:19-26): dx+[i] = dx[i] + sum_{j=2..5} C_j dx[j] + C_u du_a + c[i];
+    // f_v: coefficient ids (into CV[k]) of C_2..C_5, f_x: id of C_u << 8 | (a + 1) << 16 (a: the input of this row, -1 none)
+    unsigned f_v, f_x;
+    double fw[MMPC_FW_SLOTS];                        // dx_k[lane] during the roll-out (exchanged by v_readlane, not LDS)
 };
 
 #ifndef MMPC_EMU
+// broadcast of lane j's value to the whole wave through scalar registers (v_readlane_b32 x 2; j is a constant)
+MMPC_DEV double mmpc_readlane_f64(double v, int j) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), j), hi = __builtin_amdgcn_readlane(__double2hiint(v), j);
+    return __hiloint2double(hi, lo);
+}
 MMPC_DEV double mmpc_wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -424,17 +443,26 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
         for (int r = 0; r < NGB; r++) {
             const int a = 4 * r + g;
             ls.g_o[r] = (unsigned)((a < NU && j < NX) ? L.GS + (NX + a) * 16 + j : L.CV);
-            ls.k_o[r] = a >= NU ? (unsigned)L.CV : j < NX ? (unsigned)(L.KK + a * NX + j) | ((unsigned)(NU * NX) << 16)
-                                                 : j == NV ? (unsigned)(L.KF + a) | ((unsigned)NU << 16) : (unsigned)L.CV;
         }
         {
-            unsigned fc = 0, fv = 0, fx = 0;
+            const bool own = g == 0 && (j < NX || j == NV);
+            ls.k_o = !own ? (unsigned)(L.DUMP + lane) : j < NX ? (unsigned)(L.KK + j) | ((unsigned)NX << 16) : (unsigned)L.KF | (1u << 16);
+            ls.k_s = !own ? 0u : j < NX ? (unsigned)(NU * NX) : (unsigned)NU;
+        }
+        {
+            unsigned fv = 0, fx = 0;
             if (lane < NX) {
-                for (int q = 0; q < 4; q++) { fc |= (unsigned)TB::rcol(lane, q) << (8 * q); fv |= (unsigned)TB::rcv(lane, q) << (8 * q); }
+                // term 0 of the row tables is the diagonal (coefficient 1); the others sit in columns 2..5 or in an input column
+                unsigned cu = 0;
+                for (int q = 1; q < 5; q++) {
+                    const int col = TB::rcol(lane, q), id = TB::rcv(lane, q);
+                    if (id == 0) continue;
+                    if (col >= NX) cu = (unsigned)id; else fv |= (unsigned)id << (8 * (col - 2));
+                }
                 const int a = (lane == 3 || lane == 4) ? 0 : (lane >= 5 ? lane - 4 : -1);
-                fx = (unsigned)TB::rcol(lane, 4) | ((unsigned)TB::rcv(lane, 4) << 8) | ((unsigned)(a + 1) << 16);
+                fx = (cu << 8) | ((unsigned)(a + 1) << 16);
             }
-            ls.f_c = fc; ls.f_v = fv; ls.f_x = fx;
+            ls.f_v = fv; ls.f_x = fx;
         }
     }
     LANES_END
@@ -677,7 +705,6 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
             for (int j = 0; j < NV; j++) RB[k * NV + j] = rb[j];
         }
         MMPC_WR(1) = e_p; MMPC_WR(2) = tzmax; MMPC_WR(3) = tzmin; MMPC_WR(4) = zsum; MMPC_WR(5) = phi; MMPC_WR(6) = th; MMPC_WR(7) = slog;
-        if (lane == 0) MISC[0] = 0.0;
         if (NSELF == 0 && lane == 0) { for (int a = 0; a < 10; a++) SN[a] = 0.0; }
         LANES_END
         MMPC_TS(1)
@@ -789,6 +816,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
         for (int attempt = 0; attempt < 2; attempt++) {
             const bool exact = attempt == 0;
             const double reg = prox;
+            int ric_bad = 0;   // a pivot of this pass was not positive (every lane factorises the same matrix: uniform)
             // ---- A1 (stage lanes): stage Hessian incl. elimination of s_k
             LANES_BEGIN
             auto &ls = MMPC_LS;
@@ -1045,25 +1073,28 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
 #pragma unroll
                         for (int q = i + 1; q < NU; q++) rhs[i] -= Lm[q * (q + 1) / 2 + i] * rhs[q];
                     }
-                    // feedback gain column j (K = -Hh^-1 G; column NV: kf = -Hh^-1 gu)
+                    // feedback gain column j (K = -Hh^-1 G; column NV: kf = -Hh^-1 gu), stored for the forward roll-out by the
+                    // lanes of group 0 (the others write the same value to a dump slot: no branch)
                     const bool kcol = j < NX || j == NV;
-                    if (g == 0 && kcol) {
-                        double *dst = j < NX ? KK + k * NU * NX + j : KF + k * NU;
-                        const int step = j < NX ? NX : 1;
+                    {
+                        double *dst = lds + (ls.k_o & 0xffffu) + k * (int)ls.k_s;
+                        const int step = (int)(ls.k_o >> 16);
 #pragma unroll
                         for (int a = 0; a < NU; a++) dst[a * step] = -rhs[a];
                     }
+                    // operands of P_k = F + G^T K: A[i][a] = G[a][i] (rows i < NX), B[a][j] = K[a][j] with a = 4r+g - every lane
+                    // has solved for the whole column j, so its B entries are already in its registers
 #pragma unroll
-                    for (int r = 0; r < NGB; r++) ls.opa[r] = gop[r];
+                    for (int r = 0; r < NGB; r++) {
+                        double v = 0.0;
+#pragma unroll
+                        for (int a4 = 0; a4 < 4; a4++) if (4 * r + a4 < NU) v = g == a4 ? rhs[4 * r + a4] : v;
+                        ls.opb[r] = kcol ? -v : 0.0;
+                        ls.opa[r] = gop[r];
+                    }
                     // a non-positive pivot: the pass runs to its end and is redone by the caller with the Gauss-Newton Hessian
-                    if (!ok && lane == 0) MISC[0] = 1.0;
+                    if (!ok) ric_bad = 1;
                 }
-                LANES_END
-                // operands of P_k = F + G^T K: A[i][a] = G[a][i] (rows i < NX), B[a][j] = K[a][j], a = 4r+g, read back from KK / KF
-                LANES_BEGIN
-                auto &ls = MMPC_LS;
-#pragma unroll
-                for (int r = 0; r < NGB; r++) { const unsigned o = ls.k_o[r]; ls.opb[r] = lds[(o & 0xffffu) + k * (int)(o >> 16)]; }
                 LANES_END
                 MMPC_TS(7)
                 // R5: [P_k | p_k] = [F | gx] + G^T [K | kf]  (accumulates onto M; rows/columns >= NX keep M's entries)
@@ -1083,13 +1114,10 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                 for (int r = 0; r < NKB; r++) ls.rAB[r] = ls.nab[r];
                 LANES_END
             }
-            if (MISC[0] != 0.0) failed = 1;
+            if (ric_bad) failed = 1;
             if (!failed) break;
             if (attempt == 1) break;
             failed = 0;
-            LANES_BEGIN
-            if (lane == 0) MISC[0] = 0.0;
-            LANES_END
         }
         if (failed) {
 #ifdef MMPC_EMU_DEBUG
@@ -1097,42 +1125,87 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
 #endif
             status = 2; break; }
         MMPC_TS(8)
-        // ---- forward roll-out, one phase per stage: lane i < NX computes dx_{k+1}[i]; the lanes whose
-        //      dynamics row carries an input also produce that input step (base.py:19-26)
-        LANES_BEGIN
-        for (int j = lane; j < NV; j += MMPC_WAVE) DXU[j] = 0.0;
-        LANES_END
-#pragma unroll FWD_UNROLL
-        for (int k = 0; k < N; k++) {
+        // ---- forward roll-out: lane i < NX carries dx_k[i] in a register; a stage broadcasts the NX values through scalar
+        //      registers (v_readlane), forms the input step of its row and the next dx - no LDS round trip on the chain.
+        //      The operands of a stage (gain row, coefficients) do not depend on the chain and are fetched one stage ahead;
+        //      dx and du are stored for the phases that follow, nothing in the loop reads them back.
+        {
+            double nkr[NX], nkf = 0.0, nc0 = 0.0, ncf[5];
             LANES_BEGIN
             auto &ls = MMPC_LS;
-            if (lane < NX) {
-                const int i = lane;
-                const double *cv = CV + k * MMPC_NCV;
-                // which input enters row i: rows 3,4 -> u0; 5 -> u1; 6.. -> u2..   (-1: none)
-                const int a = (int)MMPC_B(ls.f_x, 2) - 1, aa = a < 0 ? 0 : a;
-                double dx[NX], kr[NX], cf[5];
+            for (int j = lane; j < NV; j += MMPC_WAVE) DXU[j] = 0.0;
+            ls.fw[MMPC_FW_SLOT(0)] = 0.0;
+            LANES_END
+#ifndef MMPC_EMU
+            {   // operands of stage 0
+                const int lane = mmpc_lane_id();
+                auto &ls = MMPC_LS;
+                const int i = lane < NX ? lane : 0, a = (int)MMPC_B(ls.f_x, 2) - 1, aa = a < 0 ? 0 : a;
 #pragma unroll
-                for (int j = 0; j < NX; j++) { dx[j] = DXU[k * NV + j]; kr[j] = KK[(k * NU + aa) * NX + j]; }
-                const double kf0 = KF[k * NU + aa], c0 = CD[k * NX + i];
+                for (int j = 0; j < NX; j++) nkr[j] = KK[aa * NX + j];
+                nkf = KF[aa]; nc0 = CD[i];
 #pragma unroll
-                for (int q = 0; q < 4; q++) cf[q] = cv[MMPC_B(ls.f_v, q)];
-                cf[4] = cv[MMPC_B(ls.f_x, 1)];
-                double xs[5];
-#pragma unroll
-                for (int q = 0; q < 4; q++) { const int c = (int)MMPC_B(ls.f_c, q); xs[q] = DXU[k * NV + (c < NX ? c : 0)]; }
-                { const int c = (int)MMPC_B(ls.f_x, 0); xs[4] = DXU[k * NV + (c < NX ? c : 0)]; }
-                mmpc_sched_fence();
-                double du = kf0;
-#pragma unroll
-                for (int j = 0; j < NX; j++) du += kr[j] * dx[j];
-                if (a >= 0 && i != 4) DXU[k * NV + NX + a] = du;
-                double v = c0;
-#pragma unroll
-                for (int q = 0; q < 4; q++) v += cf[q] * ((int)MMPC_B(ls.f_c, q) < NX ? xs[q] : du);
-                v += cf[4] * ((int)MMPC_B(ls.f_x, 0) < NX ? xs[4] : du);
-                DXU[(k + 1) * NV + i] = v;
+                for (int q = 0; q < 4; q++) ncf[q] = CV[MMPC_B(ls.f_v, q)];
+                ncf[4] = CV[MMPC_B(ls.f_x, 1)];
             }
+#endif
+#pragma unroll FWD_UNROLL
+            for (int k = 0; k < N; k++) {
+                LANES_BEGIN
+                auto &ls = MMPC_LS;
+                const int i = lane < NX ? lane : 0, a = (int)MMPC_B(ls.f_x, 2) - 1, aa = a < 0 ? 0 : a;
+                const int fw_st = lane < NX ? NV : 0, fw_dx = lane < NX ? L.DXU + NV + lane : L.DUMP + lane,
+                          fw_du = (lane < NX && a >= 0 && lane != 4) ? L.DXU + NX + a : L.DUMP + lane;
+                double kr[NX], cf[5], kf0, c0;
+#ifdef MMPC_EMU
+                {
+                    const double *cv = CV + k * MMPC_NCV;
+                    for (int j = 0; j < NX; j++) kr[j] = KK[(k * NU + aa) * NX + j];
+                    kf0 = KF[k * NU + aa]; c0 = CD[k * NX + i];
+                    for (int q = 0; q < 4; q++) cf[q] = cv[MMPC_B(ls.f_v, q)];
+                    cf[4] = cv[MMPC_B(ls.f_x, 1)];
+                }
+#else
+#pragma unroll
+                for (int j = 0; j < NX; j++) kr[j] = nkr[j];
+                kf0 = nkf; c0 = nc0;
+#pragma unroll
+                for (int q = 0; q < 5; q++) cf[q] = ncf[q];
+                if (k + 1 < N) {
+                    const double *cv = CV + (k + 1) * MMPC_NCV;
+#pragma unroll
+                    for (int j = 0; j < NX; j++) nkr[j] = KK[((k + 1) * NU + aa) * NX + j];
+                    nkf = KF[(k + 1) * NU + aa]; nc0 = CD[(k + 1) * NX + i];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) ncf[q] = cv[MMPC_B(ls.f_v, q)];
+                    ncf[4] = cv[MMPC_B(ls.f_x, 1)];
+                }
+#endif
+                double dx[NX];
+#pragma unroll
+                for (int j = 0; j < NX; j++) dx[j] = MMPC_LANE_GET(fw[MMPC_FW_SLOT(k)], j);
+                // du_a = kf_a + K_a dx in three partial sums; the terms of dx+ that do not need du meanwhile
+                double d0 = kf0, d1 = 0.0, d2 = 0.0;
+#pragma unroll
+                for (int j = 0; j < NX; j += 3) {
+                    d0 += kr[j] * dx[j];
+                    if (j + 1 < NX) d1 += kr[j + 1] * dx[j + 1];
+                    if (j + 2 < NX) d2 += kr[j + 2] * dx[j + 2];
+                }
+                double v = c0 + ls.fw[MMPC_FW_SLOT(k)];
+                double w = cf[0] * dx[2];
+                v += cf[1] * dx[3];
+                w += cf[2] * dx[4];
+                v += cf[3] * dx[5];
+                const double du = d0 + (d1 + d2);
+                v = (v + w) + cf[4] * du;
+                ls.fw[MMPC_FW_SLOT(k + 1)] = v;
+                // (lanes that own no row / no input write to their dump slot: no branch)
+                lds[fw_du + k * fw_st] = du;
+                lds[fw_dx + k * fw_st] = v;
+                LANES_END_REG
+            }
+            LANES_BEGIN
             LANES_END
         }
         MMPC_TS(9)
