@@ -680,8 +680,14 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
 
         // ============================================================ Newton direction
         int failed = 0;
-        for (int attempt = 0; attempt < 2; attempt++) {
-            const bool exact = attempt == 0;
+        // Hessian ladder: exact Lagrangian Hessian; on a non-positive pivot the same without the curvature of the dynamics
+        // (lam^T d2f) - it keeps the curvature of the constraint rows and of the cost, which plain Gauss-Newton steps
+        // overshoot without (full steps that zig-zag for hundreds of iterations next to a saddle); then Gauss-Newton
+        // (the middle rung is skipped with half-space rows or the terminal equality: there it passes the pivot test with
+        //  directions the line search cuts to nothing)
+        for (int attempt = 0; attempt < 3; attempt++) {
+            if (attempt == 1 && (NHS > 0 || teq)) continue;
+            const bool exact = attempt <= 1, dyn_curv = attempt == 0;
             const double reg = prox;
             // ---- A1: stage Hessian / gradient assembly
             LANES_BEGIN
@@ -693,7 +699,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                 if (k < N) {
                     for (int a = 0; a < NU; a++) { HUUD[k * NU + a] = reg; QU[k * NU + a] = GU[k * NU + a]; }
                     double h02 = 0.0;
-                    if (exact) {
+                    if (dyn_curv) {
                         // - sum_j lam_{k+1,j} d2 f_j/d(x,u)2 : only f3, f4 are nonlinear (base.py:23-24)
                         const double *cv = CV + k * MMPC_NCV;
                         const double l3 = LAM[(k + 1) * NX + 3], l4 = LAM[(k + 1) * NX + 4];
@@ -959,7 +965,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                 LANES_END
             }
             if (!failed) break;
-            if (attempt == 1) break;
+            if (attempt == 2) break;
             failed = 0;
             LANES_BEGIN
             if (lane == 0) MISC[0] = 0.0;

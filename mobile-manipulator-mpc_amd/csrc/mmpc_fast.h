@@ -813,8 +813,9 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
         // ============================================================ Newton direction
         int failed = 0;
 #pragma unroll 1
-        for (int attempt = 0; attempt < 2; attempt++) {
-            const bool exact = attempt == 0;
+        // (Hessian ladder: exact, exact without the curvature of the dynamics, Gauss-Newton - see mmpc_core.h)
+        for (int attempt = 0; attempt < 3; attempt++) {
+            const bool exact = attempt <= 1, dyn_curv = attempt == 0;
             const double reg = prox;
             int ric_bad = 0;   // a pivot of this pass was not positive (every lane factorises the same matrix: uniform)
             // ---- A1 (stage lanes): stage Hessian incl. elimination of s_k
@@ -828,7 +829,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
 #pragma unroll
                 for (int j = 0; j < NX; j++) { hxx[j * (j + 1) / 2 + j] = CST[(k < N ? MMPC_C_WQ : MMPC_C_WP) + j] + reg; qx[j] = RB[k * NV + j]; }
                 double h02 = 0.0;
-                if (k < N && exact) {
+                if (k < N && dyn_curv) {
                     const double *cv = CV + k * MMPC_NCV;
                     const double l3 = LAM[(k + 1) * NX + 3], l4 = LAM[(k + 1) * NX + 4];
                     hxx[5] += l3 * cv[4] - l4 * cv[3];
@@ -1116,7 +1117,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
             }
             if (ric_bad) failed = 1;
             if (!failed) break;
-            if (attempt == 1) break;
+            if (attempt == 2) break;
             failed = 0;
         }
         if (failed) {

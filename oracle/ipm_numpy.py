@@ -47,6 +47,7 @@ class Options:
     piv_frac = 0.0
     nu_lam = 0.0
     filter = True
+    mid_fallback = True     # exact -> exact without dynamics curvature -> Gauss-Newton
     inertia = False
     inertia_streak = 0      # >0 (experiment, off: it trades the 600-800-iteration cases for others that take 1300+): inertia correction (exact Hessian + delta I) instead of the Gauss-Newton fallback once the
                             # exact Hessian has failed in this many consecutive iterations (slow linear convergence near saddles)
@@ -280,7 +281,7 @@ def solve(prob: nlp.Problem, U0=None, X0=None, opt: Options = None, verbose=Fals
             nu_merit = 1.0
             filt = None
         # ---------------- stage QP assembly + Riccati ----------------------
-        def factor(use_exact, delta=0.0):
+        def factor(use_exact, delta=0.0, dyn_curv=True):
             Hxx = []; Hux = []; Huu = []; qx = []; qu = []
             hss = 2 * p.S * np.ones(N + 1)
             gss = gs.copy()
@@ -293,7 +294,7 @@ def solve(prob: nlp.Problem, U0=None, X0=None, opt: Options = None, verbose=Fals
                 Hc = np.zeros((nu, nx)) if k < N else None
                 g = gX[k].copy()
                 gu = gU[k].copy() if k < N else None
-                if k < N and use_exact and opt.curv_dyn:
+                if k < N and use_exact and opt.curv_dyn and dyn_curv:
                     fxx, fux, fuu = nlp.f_hess_contract(p.kind, X[k], U[k], p.dt, lam[k + 1])
                     H -= fxx; Hc -= fux; Hu -= fuu
                 for i, (h, jx, ju, ks, Hr) in enumerate(ev[k]):
@@ -384,6 +385,14 @@ def solve(prob: nlp.Problem, U0=None, X0=None, opt: Options = None, verbose=Fals
                     delta = delta * (100.0 if delta_last == 0.0 else 8.0)
             if fac is not None:
                 delta_last = delta
+        if fac is None and opt.exact_hessian and opt.mid_fallback and not p.terminal_xy_equality and \
+                (prob.hs is None or len(prob.hs) == 0):
+            # middle rung of the fallback ladder: the exact Hessian without the curvature of the dynamics (lam^T d2f).  Plain
+            # Gauss-Newton steps also drop the curvature of the constraint rows and overshoot where that is large: full
+            # steps that zig-zag for hundreds of iterations next to a saddle.  (Not with half-space rows or the terminal
+            # equality: there the rung passes the pivot test with directions the line search cuts to nothing.)
+            nreg += 1
+            fac = factor(True, prox, dyn_curv=False)
         if fac is None:
             nreg += 1 if opt.exact_hessian else 0
             fac = factor(False, prox)

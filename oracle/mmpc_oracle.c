@@ -415,7 +415,10 @@ static void chol_solve(double L[NUM][NUM], int n, double *b) {
     for (int i = n - 1; i >= 0; i--) { double v = b[i]; for (int k = i + 1; k < n; k++) v -= L[k][i] * b[k]; b[i] = v / L[i][i]; }
 }
 
-/* stage QP assembly + s Schur complement + Riccati factorisation.  returns 0 on a failed pivot */
+/* stage QP assembly + s Schur complement + Riccati factorisation.  returns 0 on a failed pivot.
+ * use_exact 2: exact Lagrangian Hessian; 1: the same without the curvature of the dynamics, lam^T d2f (the middle rung of
+ * the fallback ladder: keeps the curvature of the constraint rows and of the cost, which plain Gauss-Newton steps overshoot
+ * without); 0: Gauss-Newton */
 static int factor(work *w, double mu, int use_exact, double prox) {
     const oracle_cfg *c = w->cfg;
     int nx = w->nx, nu = w->nu, N = w->N;
@@ -429,7 +432,7 @@ static int factor(work *w, double mu, int use_exact, double prox) {
         }
         if (k < N) {
             for (int i = 0; i < nu; i++) { for (int j = 0; j < nu; j++) w->Huu[k][i][j] = w->RW2[i][j]; w->Huu[k][i][i] += prox; w->qu[k][i] = w->gU[k][i]; for (int j = 0; j < nx; j++) w->Hux[k][i][j] = 0; }
-            if (use_exact) {
+            if (use_exact == 2) {
                 /* - sum_j lam_{k+1,j} d2 f_j : only f3, f4 (base.py:23-24) are nonlinear */
                 double sn = sin(w->X[k][2]), cs = cos(w->X[k][2]), l3 = w->lam[k + 1][3], l4 = w->lam[k + 1][4], dt = c->dt;
                 w->Hxx[k][2][2] -= dt * w->U[k][0] * (-l3 * cs - l4 * sn);
@@ -679,7 +682,8 @@ int mmpc_oracle_solve(const oracle_cfg *cfg, const double *x_init, const double 
         }
         if (changed) filt_init = 0;
         /* ---- Newton direction */
-        if (!factor(w, mu, 1, prox)) if (!factor(w, mu, 0, prox)) { status = 2; break; }
+        /* (the middle rung is skipped with the terminal equality, like the proximal term: see mmpc_core.h) */
+        if (!factor(w, mu, 2, prox)) if (cfg->terminal_xy_eq || w->nhs > 0 || !factor(w, mu, 1, prox)) if (!factor(w, mu, 0, prox)) { status = 2; break; }
         w->nu_new[0] = w->nu_new[1] = 0;
         if (cfg->terminal_xy_eq) {
             double d0[NXM] = {0}, Dv[NXM][2], u0[NUM], Uv[NUM][2], t0[NXM], Tv[NXM][2];

@@ -34,6 +34,10 @@ for t in range(T):
     top = torch.sort(out["iters"]).values[-4:].tolist()
     print("[%d per CU, %d B LDS] tick %d: %.2f ms  mean iters %.2f  top %s   work/slot at 3 per CU: %.0f iterations" %
           (eng.problems_per_cu, eng.lds_bytes, t, e0.elapsed_time(e1), it.mean().item(), top, it.sum().item() / 768), flush=True)
+    if "--dump" in sys.argv:      # inputs of very slow instances, for offline study with the numpy restatement
+        for b in torch.nonzero(out["iters"] > 400).flatten().tolist():
+            np.savez(os.path.join(ROOT, "gpurun_out", "c5tail_t%d_b%d.npz" % (t, b)), x=x[b].cpu().numpy(), loc=loc[b].cpu().numpy(),
+                     ul=ul[b].cpu().numpy(), obs=obs[b].cpu().numpy(), iters=int(out["iters"][b]))
     ul = out["U"].clone(); u0 = out["U"][:, 0]
     xc = torch.minimum(torch.maximum(x, xlo), xhi)
     c, s = torch.cos(xc[:, 2]), torch.sin(xc[:, 2])
