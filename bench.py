@@ -19,7 +19,7 @@ sys.path.insert(0, _ROOT)
 
 FP64_PEAK_TFLOPS = 78.6      # MI355X FP64 vector = FP64 matrix peak (spec), SURVEY §7
 HBM_PEAK_GBS = 8000.0
-PROFILE_TAG = "r01_m"                             # PMC summaries of this build (tools/collect_profiles.sh <tag>)
+PROFILE_TAG = "r01_n"                             # PMC summaries of this build (tools/collect_profiles.sh <tag>)
 WEAK_SEEDS = (3, 11, 14, 16, 19, 23, 25, 26)       # per-rank seeds of the C4 generator under weak scaling (see main())
 
 
