@@ -277,13 +277,16 @@ def main():
             par = nlp.WholeBodyParams(N=N)
             xi = np.clip(d["x_init"][:ns], par.xlim[0], par.xlim[1])
             coracle.lib()
-            c0 = time.perf_counter()
-            o = coracle.solve_batch(par, xi, d["traj_ref"][:ns], d["u_ref"][:ns], np.zeros((ns, N, nu)), d["obs"][:ns],
-                                    nthreads=cores)
-            ct = time.perf_counter() - c0
+            # bounded sample: passes over the batch until about 10 s of wall time on the host cores (at most 24 passes)
+            c0 = time.perf_counter(); passes = 0
+            while passes < 24 and (passes == 0 or time.perf_counter() - c0 < 10.0):
+                o = coracle.solve_batch(par, xi, d["traj_ref"][:ns], d["u_ref"][:ns], np.zeros((ns, N, nu)), d["obs"][:ns],
+                                        nthreads=cores)
+                passes += 1
+            ct = (time.perf_counter() - c0) / passes
             gX = out["X"][:ns].cpu().numpy()
             res["cpu_baseline"] = {"value": ns / ct, "unit": "solves/s", "cores": cores, "kind": "port",
-                                   "sample": "first %d instances of the same batch, oracle/mmpc_oracle.c (OpenMP), %.1f s" % (ns, ct),
+                                   "sample": "first %d instances of the same batch, oracle/mmpc_oracle.c (OpenMP), %d passes, %.1f s in all" % (ns, passes, ct * passes),
                                    "max_abs_dX_vs_gpu": float(np.abs(gX - o["X"]).max()),
                                    "casadi": "CasADi/IPOPT baseline unavailable on this host" if not _has_casadi() else "importable"}
         print(json.dumps(res))
