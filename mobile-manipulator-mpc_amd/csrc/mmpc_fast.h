@@ -1006,6 +1006,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
 #pragma unroll RIC_UNROLL
             for (int k = N - 1; k >= 0; k--) {
                 MMPC_TS(5)
+                if (ric_bad) break;   // (uniform: every lane factorises the same matrix) the pass is redone one rung down
                 // R1: T = P [A B | c] + [0 | p]   (P symmetric: its accumulator registers are the A operand)
                 MMPC_MFMA(rT, ls.rP[0], ls.rAB[0])
                 MMPC_MFMA(rT, ls.rP[1], ls.rAB[1])
@@ -1093,7 +1094,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                         ls.opb[r] = kcol ? -v : 0.0;
                         ls.opa[r] = gop[r];
                     }
-                    // a non-positive pivot: the pass runs to its end and is redone by the caller with the Gauss-Newton Hessian
+                    // a non-positive pivot: the pass stops at the next stage and is redone one rung down the Hessian ladder
                     if (!ok) ric_bad = 1;
                 }
                 LANES_END
