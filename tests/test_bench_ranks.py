@@ -1,0 +1,36 @@
+"""GPU box: bench.py's multi-rank path (per-rank seeded batches, overlapped all-gather of the solutions, max-over-ranks
+timing, one JSON line from rank 0) rehearsed with two ranks that share the one GPU - the all-gather goes through gloo
+(MMPC_BENCH_BACKEND), the solves through the HIP library.  The driver's own N-GPU runs use RCCL."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.gpu
+def test_two_rank_bench_line():
+    env = dict(os.environ, MMPC_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--batch", "1024"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]          # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 3 and d["unit"] == "solves/s"
+    assert d["config"]["seeds"] == [3, 11] and d["config"]["batch_per_gpu"] == 1024
+    assert d["solver"]["converged_frac"] == 1.0 and d["solver"]["max_scaled_kkt"] <= 1e-8
+    assert d["value"] > 0 and abs(d["value"] - 2 * 1024 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
+    assert "cpu_baseline" not in d                       # rank 0 at N=1 only
