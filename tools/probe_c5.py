@@ -38,6 +38,8 @@ for t in range(T):
         for b in torch.nonzero(out["iters"] > 400).flatten().tolist():
             np.savez(os.path.join(ROOT, "gpurun_out", "c5tail_t%d_b%d.npz" % (t, b)), x=x[b].cpu().numpy(), loc=loc[b].cpu().numpy(),
                      ul=ul[b].cpu().numpy(), obs=obs[b].cpu().numpy(), iters=int(out["iters"][b]))
+    if "--iters" in sys.argv:
+        np.save(os.path.join(ROOT, "gpurun_out", "c5_iters_t%d.npy" % t), out["iters"].cpu().numpy())
     ul = out["U"].clone(); u0 = out["U"][:, 0]
     xc = torch.minimum(torch.maximum(x, xlo), xhi)
     c, s = torch.cos(xc[:, 2]), torch.sin(xc[:, 2])
