@@ -257,6 +257,7 @@ struct MmpcLaneState {
     unsigned h_o[4], h_l[4];                         // stage-matrix entry of register r: LDS offset | stage stride << 16; offset of its
                                                      // stage-(N-1) extra term (Q1 elimination of s_{N-1}) or of the constant 0
     unsigned h_m;                                    // bit r: register r is part of [P | p]; bit 4+r: ... and is stored (lower triangle, p)
+    unsigned p_o[4];                                 // where register r of [P_k | p_k] is stored: h_o[r] for the stored entries, a dump slot otherwise
     unsigned g_o[F::NGB];                            // GS offset of this lane's entry of the G^T operand (or of the constant 0)
     unsigned k_o, k_s;                               // where this lane stores its gain column: LDS offset | step between inputs << 16, and
                                                      // the stage stride (lanes that own no column write to a dump slot: step = stride = 0)
@@ -438,6 +439,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
             }
             ls.h_o[r] = off | (stride << 16);
             ls.h_l[r] = last;
+            ls.p_o[r] = ((ls.h_m >> (4 + r)) & 1u) ? ls.h_o[r] : (unsigned)(L.DUMP + lane);
         }
 #pragma unroll
         for (int r = 0; r < NGB; r++) {
@@ -1107,7 +1109,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     ls.rP[r] = ls.rM[r];
-                    const unsigned o = ((ls.h_m >> (4 + r)) & 1u) ? ls.h_o[r] : (unsigned)(L.DUMP + lane);   // (dump slot: no branch)
+                    const unsigned o = ls.p_o[r];   // (entries that are not stored go to a dump slot: no branch)
                     lds[(o & 0xffffu) + k * (int)(o >> 16)] = ls.rM[r];
                     ls.rM[r] = ls.nhm[r];
                     ls.rT[r] = (r < NKB && (lane & 15) == NV) ? ls.rP[r] : 0.0;
