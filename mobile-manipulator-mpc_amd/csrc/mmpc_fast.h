@@ -160,10 +160,11 @@ struct MmpcFastDims {
     static constexpr int NS = N + 1;
     static constexpr int NPAIR = NS * NV;
     static constexpr int NPASS = (NPAIR + MMPC_WAVE - 1) / MMPC_WAVE;
-    // Riccati recursion on 16x16 MFMA tiles: K-blocks (4 rows each) that cover the state rows / the input rows,
-    // accumulator registers that hold the input rows NX..NV-1 of the stage matrix
-    static constexpr int NKB = (NX + 3) / 4, NGB = (NU + 3) / 4, GR0 = NX / 4, GR1 = (NV - 1) / 4;
-    static_assert(NV + 1 <= 16, "stage matrix [x u | gradient] must fit one 16x16 tile");
+    // Riccati recursion on 16x16 MFMA tiles in homogeneous form: tile index t < NX is state t, t = NX the constant 1 (its
+    // row and column carry the gradient), NX < t <= NV input t-NX-1.  K-blocks (4 rows each) that cover the (x, 1) rows /
+    // the input rows, accumulator registers that hold the input rows NX+1..NV of the stage matrix
+    static constexpr int NKB = (NX + 1 + 3) / 4, NGB = (NU + 3) / 4, GR0 = (NX + 1) / 4, GR1 = NV / 4;
+    static_assert(NV + 1 <= 16, "stage matrix over (x, 1, u) must fit one 16x16 tile");
 };
 
 // ---- v_mfma_f64_16x16x4_f64: D = A B + C on one wavefront.  Lane l supplies A[l&15][l>>4] and B[l>>4][l&15] and holds
@@ -187,8 +188,13 @@ struct MmpcAcc {
             ls.ACC[r_] = s_;                                                                                           \
         }                                                                                                              \
     } }
+#define MMPC_MFMA0(ACC, AEXPR, BEXPR) { for (int lane = 0; lane < MMPC_WAVE; lane++) for (int r_ = 0; r_ < 4; r_++) ls_all[lane].ACC[r_] = 0.0; \
+    MMPC_MFMA(ACC, AEXPR, BEXPR) }
 #else
 typedef double MmpcAcc __attribute__((ext_vector_type(4)));
+// (first product of a chain: zero accumulator input, no register initialisation)
+#define MMPC_MFMA0(ACC, AEXPR, BEXPR) { auto &ls = ls_one; const MmpcAcc z_ = {0.0, 0.0, 0.0, 0.0};                     \
+    ls.ACC = __builtin_amdgcn_mfma_f64_16x16x4f64((AEXPR), (BEXPR), z_, 0, 0, 0); }
 #define MMPC_MFMA(ACC, AEXPR, BEXPR) { auto &ls = ls_one; ls.ACC = __builtin_amdgcn_mfma_f64_16x16x4f64((AEXPR), (BEXPR), ls.ACC, 0, 0, 0); }
 #endif
 
@@ -401,17 +407,22 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
     {
         auto &ls = MMPC_LS;
         const int g = lane >> 4, j = lane & 15;
+        // tile index -> index in the (x, u | gradient) numbering of the stage arrays: state t, gradient NV, input NX+a, 99 = outside
+        auto lg = [&](int t) -> int { return t < NX ? t : t == NX ? NV : t <= NV ? t - 1 : 99; };
+        const int jl = lg(j);
 #pragma unroll
         for (int r = 0; r < NKB; r++) {
-            // operand entry [A B | c][m][j], m = 4r+g: a coefficient of CV[k] (ids 0,1,2 are the constants 0,1,dt),
-            // the defect c_k[m] in column NV, or the constant 0 (stride 0) outside the matrix
+            // operand entry of the homogeneous dynamics [A B c; 0 0 1] (rows over (x, 1), columns over (x, 1, u)), row m = 4r+g:
+            // a coefficient of CV[k] (ids 0,1,2 are the constants 0,1,dt), the defect c_k[m] in the column of the 1, the 1
+            // itself, or the constant 0 (stride 0) outside the matrix
             const int m = 4 * r + g;
             unsigned off = (unsigned)L.CV, stride = 0;
-            if (m < NX && j < NV) {
+            if (m < NX && jl < NV) {
                 int id = 0;
-                for (int q = 0; q < 4; q++) if (TB::crow(j, q) == m && TB::ccv(j, q) != 0) id = TB::ccv(j, q);
+                for (int q = 0; q < 4; q++) if (TB::crow(jl, q) == m && TB::ccv(jl, q) != 0) id = TB::ccv(jl, q);
                 off = (unsigned)(L.CV + id); stride = id >= 3 ? MMPC_NCV : 0;
-            } else if (m < NX && j == NV) { off = (unsigned)(L.CD + m); stride = NX; }
+            } else if (m < NX && jl == NV) { off = (unsigned)(L.CD + m); stride = NX; }
+            else if (m == NX && jl == NV) off = (unsigned)(L.CV + 1);
             ls.ab_o[r] = off | (stride << 16);
         }
         ls.h_m = 0u;
@@ -420,7 +431,9 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
             // stage matrix [Hxx Hxu q_x; Hux Huu q_u] entry (i, j), i = g+4r, as one LDS word per stage (offset + k*stride):
             // Hxx: packed HXX[k];  Hux: only (0,2) is non-zero (HUX02[k]);  Huu: constant R2+W2 off the diagonal, HUUD[k] on it;
             // column NV: gradient QXU[k].  Stage N-1 adds the dense rank-one blocks HUXL / HUUL.
-            const int i = g + 4 * r;
+            // (i, j below are already in the numbering of the stage arrays; the gradient sits in row AND column NV of the
+            //  symmetric homogeneous form)
+            const int i = lg(g + 4 * r), j = jl;
             unsigned off = (unsigned)L.CV, stride = 0, last = (unsigned)L.CV;
             if (i < NX && j < NX) {
                 off = (unsigned)(L.HXX + (i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i)); stride = NXX;
@@ -436,6 +449,9 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
             } else if (i < NV && j == NV) {
                 off = (unsigned)(L.QXU + i); stride = NV;
                 if (i < NX) ls.h_m |= (1u << r) | (16u << r);
+            } else if (i == NV && j < NX) {   // transposed gradient: part of the cost-to-go, not stored a second time
+                off = (unsigned)(L.QXU + j); stride = NV;
+                ls.h_m |= (1u << r);
             }
             ls.h_o[r] = off | (stride << 16);
             ls.h_l[r] = last;
@@ -444,10 +460,10 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
 #pragma unroll
         for (int r = 0; r < NGB; r++) {
             const int a = 4 * r + g;
-            ls.g_o[r] = (unsigned)((a < NU && j < NX) ? L.GS + (NX + a) * 16 + j : L.CV);
+            ls.g_o[r] = (unsigned)((a < NU && j <= NX) ? L.GS + (NX + 1 + a) * 16 + j : L.CV);
         }
         {
-            const bool own = g == 0 && (j < NX || j == NV);
+            const bool own = g == 0 && j <= NX;
             ls.k_o = !own ? (unsigned)(L.DUMP + lane) : j < NX ? (unsigned)(L.KK + j) | ((unsigned)NX << 16) : (unsigned)L.KF | (1u << 16);
             ls.k_s = !own ? 0u : j < NX ? (unsigned)(NU * NX) : (unsigned)NU;
         }
@@ -991,8 +1007,8 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
             }
             LANES_END
             MMPC_TS(4)
-            // ---- R0: terminal cost-to-go [P_N | p_N] = stage-N Hessian and gradient, in accumulator layout;
-            //      operands of stage N-1: rAB = [A B | c] rows 4r+g, rM = stage matrix (accumulator input), rT = [0 | p_N]
+            // ---- R0: terminal cost-to-go [P_N p_N; p_N^T .] = stage-N Hessian and gradient, in accumulator layout;
+            //      operands of stage N-1: rAB = homogeneous dynamics rows 4r+g, rM = stage matrix (accumulator input)
             LANES_BEGIN
             auto &ls = MMPC_LS;
 #pragma unroll
@@ -1000,7 +1016,6 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                 const unsigned o = ls.h_o[r];
                 ls.rP[r] = ((ls.h_m >> r) & 1u) ? lds[(o & 0xffffu) + N * (int)(o >> 16)] : 0.0;
                 ls.rM[r] = lds[(o & 0xffffu) + (N - 1) * (int)(o >> 16)] + lds[ls.h_l[r]];
-                ls.rT[r] = (r < NKB && (lane & 15) == NV) ? ls.rP[r] : 0.0;
             }
 #pragma unroll
             for (int r = 0; r < NKB; r++) { const unsigned o = ls.ab_o[r]; ls.rAB[r] = lds[(o & 0xffffu) + (N - 1) * (int)(o >> 16)]; }
@@ -1009,11 +1024,12 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
             for (int k = N - 1; k >= 0; k--) {
                 MMPC_TS(5)
                 if (ric_bad) break;   // (uniform: every lane factorises the same matrix) the pass is redone one rung down
-                // R1: T = P [A B | c] + [0 | p]   (P symmetric: its accumulator registers are the A operand)
-                MMPC_MFMA(rT, ls.rP[0], ls.rAB[0])
+                // R1: T = [P p; p^T .] [A B c; 0 0 1]   (symmetric: its accumulator registers are the A operand; the affine
+                // part rides along as row / column NX, so the chain starts from a zero accumulator)
+                MMPC_MFMA0(rT, ls.rP[0], ls.rAB[0])
                 MMPC_MFMA(rT, ls.rP[1], ls.rAB[1])
                 if (NKB > 2) MMPC_MFMA(rT, ls.rP[NKB > 2 ? 2 : 0], ls.rAB[NKB > 2 ? 2 : 0])
-                // R2: M = [A B | c]^T T + stage matrix  ->  [F G^T gx; G Hh gu]
+                // R2: M = [A B c; 0 0 1]^T T + stage matrix  ->  [F gx G^T; gx^T . gu^T; G gu Hh]
                 MMPC_MFMA(rM, ls.rAB[0], ls.rT[0])
                 MMPC_MFMA(rM, ls.rAB[1], ls.rT[1])
                 if (NKB > 2) MMPC_MFMA(rM, ls.rAB[NKB > 2 ? 2 : 0], ls.rT[NKB > 2 ? 2 : 0])
@@ -1033,8 +1049,8 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
 #pragma unroll
                     for (int a = 0; a < NU; a++) {
 #pragma unroll
-                        for (int b = 0; b <= a; b++) Hm[a * (a + 1) / 2 + b] = GS[(NX + a) * 16 + NX + b];
-                        rhs[a] = GS[(NX + a) * 16 + j];
+                        for (int b = 0; b <= a; b++) Hm[a * (a + 1) / 2 + b] = GS[(NX + 1 + a) * 16 + NX + 1 + b];
+                        rhs[a] = GS[(NX + 1 + a) * 16 + j];
                     }
 #pragma unroll
                     for (int r = 0; r < NGB; r++) gop[r] = lds[ls.g_o[r]];
@@ -1077,9 +1093,9 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
 #pragma unroll
                         for (int q = i + 1; q < NU; q++) rhs[i] -= Lm[q * (q + 1) / 2 + i] * rhs[q];
                     }
-                    // feedback gain column j (K = -Hh^-1 G; column NV: kf = -Hh^-1 gu), stored for the forward roll-out by the
+                    // feedback gain column j (K = -Hh^-1 G; column NX: kf = -Hh^-1 gu), stored for the forward roll-out by the
                     // lanes of group 0 (the others write the same value to a dump slot: no branch)
-                    const bool kcol = j < NX || j == NV;
+                    const bool kcol = j <= NX;
                     {
                         double *dst = lds + (ls.k_o & 0xffffu) + k * (int)ls.k_s;
                         const int step = (int)(ls.k_o >> 16);
@@ -1101,7 +1117,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                 }
                 LANES_END
                 MMPC_TS(7)
-                // R5: [P_k | p_k] = [F | gx] + G^T [K | kf]  (accumulates onto M; rows/columns >= NX keep M's entries)
+                // R5: [P_k p_k; p_k^T .] = [F gx; gx^T .] + [G gu]^T [K | kf]  (accumulates onto M; rows/columns > NX keep M's entries)
                 MMPC_MFMA(rM, ls.opa[0], ls.opb[0])
                 if (NGB > 1) MMPC_MFMA(rM, ls.opa[NGB > 1 ? 1 : 0], ls.opb[NGB > 1 ? 1 : 0])
                 LANES_BEGIN
@@ -1112,7 +1128,6 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                     const unsigned o = ls.p_o[r];   // (entries that are not stored go to a dump slot: no branch)
                     lds[(o & 0xffffu) + k * (int)(o >> 16)] = ls.rM[r];
                     ls.rM[r] = ls.nhm[r];
-                    ls.rT[r] = (r < NKB && (lane & 15) == NV) ? ls.rP[r] : 0.0;
                 }
 #pragma unroll
                 for (int r = 0; r < NKB; r++) ls.rAB[r] = ls.nab[r];
