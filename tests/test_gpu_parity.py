@@ -28,6 +28,20 @@ def test_wholebody_c3_parity(mm):
     assert np.array_equal(r["u0"], r["U"][:, 0, :])
 
 
+@pytest.mark.parametrize("N,M", [(20, 3), (20, 4), (12, 2)])
+def test_wholebody_other_shapes(mm, N, M):
+    """(20, 3) is the demo's obstacle count and has a specialised kernel; the other shapes go through the generic one."""
+    B = 96
+    d = synth.make_batch(B, N=N, M=M, config_id=40 + M)
+    ctrl = _wb(mm, N, M, B)
+    r = ctrl.solve_batch(d["x_init"], d["traj_ref"], d["u_ref"], d["obs"])
+    o = coracle.solve_batch(nlp.WholeBodyParams(N=N), d["x_init"], d["traj_ref"], d["u_ref"], np.zeros((B, N, 5)), d["obs"], nthreads=8)
+    assert (r["status"] == 0).all() and (o["status"] == 0).all()
+    same = np.abs(r["cost"] / o["cost"] - 1) < 1e-6
+    assert same.mean() >= 0.98
+    assert np.abs(r["X"][same] - o["X"][same]).max() < TOL and np.abs(r["U"][same] - o["U"][same]).max() < TOL
+
+
 def test_wholebody_warm_started_ticks(mm):
     """3 receding-horizon ticks: handle keeps u_latest (U init and U_last, unshifted; :303,:310,:330)."""
     B = 32
