@@ -245,6 +245,28 @@ def main():
             res["schedule_hint"] = {"in_timed_steps": "longest-first order from the previous solve of the same batch (exact)",
                                     "first_solve_ms": cold_ms, "first_solve_value": Bl / (cold_ms * 1e-3), "unit": "solves/s",
                                     "note": "no hint: workgroups in batch order; every instance still converges to the same result"}
+            # Two batches in flight (two handles, two HIP streams, alternating): the drain of one launch - waves still
+            # iterating on its slowest instances while CUs idle - is filled by the next launch.  What a deployment that
+            # pipelines independent batches gets; reported beside `value`, which stays the one-stream figure.
+            eng.reset()
+            ctrl2 = mm.MPCWholeBody(robot, [], [], N=N, max_batch=Bl, device=local_dev, n_obstacles=M)
+            engs, outs = (eng, ctrl2._engine), (out, None)
+            streams = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+            pipe = {}
+            for label, hinted in (("hinted", True), ("first_solves", False)):
+                outs = list(outs)
+                for rep in range(2 + args.steps):
+                    if rep == 2:
+                        torch.cuda.synchronize(); p0 = time.perf_counter()
+                    for q in range(2):
+                        if not hinted:
+                            engs[q].reset()
+                        with torch.cuda.stream(streams[q]):
+                            outs[q] = engs[q].solve_batch_device(x_init, traj, uref, ulast, obs, out=outs[q])
+                torch.cuda.synchronize()
+                pipe[label] = 2 * args.steps * Bl / (time.perf_counter() - p0)
+            res["two_streams"] = {"value_hinted": pipe["hinted"], "value_first_solves": pipe["first_solves"], "unit": "solves/s",
+                                  "note": "two handles on two HIP streams, %d launches each; not the headline figure" % args.steps}
             # PCIe-inclusive rate of the host-pointer entry point (mmpc_solve_batch: H2D, solve, D2H of X,U,s,...): a note
             # beside `value`, which is always the device-resident rate
             hx = np.clip(d["x_init"][:Bl], ctrl.xlim[0], ctrl.xlim[1])
