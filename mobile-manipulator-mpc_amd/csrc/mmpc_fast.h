@@ -258,18 +258,18 @@ struct MmpcLaneState {
     double st[4], sz[4], sdt[4];
     // s_k elimination data of stage `lane`
     double hss, gss, vx[6];
-    // Riccati recursion on MFMA tiles (lane = 16 g + j; accumulator register r <-> row g + 4 r, column j)
-    unsigned ab_o[F::NKB];                           // [A B | c] operand rows 4r+g, column j: LDS offset | stage stride << 16
+    // Riccati recursion on MFMA tiles over (x, 1, u) (lane = 16 g + j; accumulator register r <-> row g + 4 r, column j)
+    unsigned ab_o[F::NKB];                           // [A c B; 0 1 0] operand rows 4r+g, column j: LDS offset | stage stride << 16
     unsigned h_o[4], h_l[4];                         // stage-matrix entry of register r: LDS offset | stage stride << 16; offset of its
                                                      // stage-(N-1) extra term (Q1 elimination of s_{N-1}) or of the constant 0
-    unsigned h_m;                                    // bit r: register r is part of [P | p]; bit 4+r: ... and is stored (lower triangle, p)
+    unsigned h_m;                                    // bit r: register r is part of [P p; p^T .]; bit 4+r: ... and is stored (lower triangle, p)
     unsigned p_o[4];                                 // where register r of [P_k | p_k] is stored: h_o[r] for the stored entries, a dump slot otherwise
     unsigned g_o[F::NGB];                            // GS offset of this lane's entry of the G^T operand (or of the constant 0)
     unsigned k_o, k_s;                               // where this lane stores its gain column: LDS offset | step between inputs << 16, and
                                                      // the stage stride (lanes that own no column write to a dump slot: step = stride = 0)
-    MmpcAcc rP, rT, rM;                              // cost-to-go [P | p], T = P [A B | c], stage matrix M
+    MmpcAcc rP, rT, rM;                              // cost-to-go [P p; p^T .], its product T with the dynamics, stage matrix M
     double rAB[F::NKB], opa[F::NGB], opb[F::NGB];    // MFMA operands
-    double nab[F::NKB], nhm[4];                      // next stage's [A B | c] rows and stage-matrix entries (loaded one stage ahead)
+    double nab[F::NKB], nhm[4];                      // next stage's dynamics rows and stage-matrix entries (loaded one stage ahead)
     // forward roll-out, row `lane` of [A B] (base.py:19-26): dx+[i] = dx[i] + sum_{j=2..5} C_j dx[j] + C_u du_a + c[i];
     // f_v: coefficient ids (into CV[k]) of C_2..C_5, f_x: id of C_u << 8 | (a + 1) << 16 (a: the input of this row, -1 none)
     unsigned f_v, f_x;
@@ -346,7 +346,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
            *OBS = lds + L.OBS, *CST = lds + L.CST, *CV = lds + L.CV, *CD = lds + L.CD, *TRG = lds + L.TRG, *HXX = lds + L.HXX,
            *QXU = lds + L.QXU, *HUXL = lds + L.HUXL, *HUUL = lds + L.HUUL, *HUX02 = lds + L.HUX02,
            *HUUD = lds + L.HUUD, *SN = lds + L.SN, *KK = lds + L.KK, *KF = lds + L.KF, *DXU = lds + L.DXU,
-           *DS = lds + L.DS, *DLAM = lds + L.DLAM, *GS = lds + L.GS, *FILT = lds + L.FILT, *MISC = lds + L.MISC;
+           *DS = lds + L.DS, *DLAM = lds + L.DLAM, *GS = lds + L.GS, *FILT = lds + L.FILT;
     double *const RB = lds + L.RB, *const RDS = lds + L.RDS, *const Q1V = lds + L.Q1V;   // residual base r[k][v] and the s_k residual of the current point
     const double dt = P.dt, Sw = P.S, tol = P.tol;
 #ifdef MMPC_EMU
