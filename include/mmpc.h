@@ -114,6 +114,15 @@ int mmpc_ik_batch(int device, int B, const double *q0, const double *target_xz, 
 int mmpc_ik_batch_device(int device, int B, const double *d_q0, const double *d_target_xz, double *d_q, int *d_status,
                          int *d_iters, void *stream);
 
+/* Opt-in warm start for the device-pointer entry point (no reference counterpart: the reference starts every solve from
+ * U = U_last, X = tile(x_init), mu = IPOPT's default, mpc_wholebody_qref.py:301-303).  d_u_guess [B][N][nu] (device memory
+ * that stays valid until it is replaced or cleared with NULL) becomes the initial U of the following
+ * mmpc_solve_batch_device calls - separate from d_u_last, which stays the U_last PARAMETER of the cost and of the rate
+ * bounds -, their d_x_guess the initial X, mu_init the initial barrier parameter.  A receding-horizon caller passes the
+ * previous optimum shifted by one stage, the roll-out of the dynamics under it, and mu_init = 0.1: the same NLP, solved
+ * in fewer than half the iterations.  mmpc_set_warm_start(h, NULL, 1.0) restores the default. */
+int mmpc_set_warm_start(mmpc_handle h, const double *d_u_guess, double mu_init);
+
 /* bytes of LDS one problem instance occupies (one 64-lane workgroup) */
 int mmpc_lds_bytes(mmpc_handle h);
 /* problem instances (workgroups) the runtime keeps resident per compute unit for the kernel this handle launches

@@ -22,7 +22,7 @@ class MmpcConfig(C.Structure):
 
 EXPORTS = ["mmpc_create", "mmpc_destroy", "mmpc_set_weights", "mmpc_set_terminal_xy_equality", "mmpc_reset",
            "mmpc_solve_batch", "mmpc_solve_batch_device", "mmpc_get_u_latest", "mmpc_set_u_latest",
-           "mmpc_lds_bytes", "mmpc_problems_per_cu", "mmpc_last_error", "mmpc_version", "mmpc_ik_batch", "mmpc_ik_batch_device"]
+           "mmpc_lds_bytes", "mmpc_problems_per_cu", "mmpc_set_warm_start", "mmpc_last_error", "mmpc_version", "mmpc_ik_batch", "mmpc_ik_batch_device"]
 
 _lib = None
 _dp = C.POINTER(C.c_double)
@@ -56,6 +56,7 @@ def lib():
         L.mmpc_set_u_latest.argtypes = [C.c_void_p, C.c_int, _dp]
         L.mmpc_lds_bytes.argtypes = [C.c_void_p]
         L.mmpc_problems_per_cu.argtypes = [C.c_void_p]
+        L.mmpc_set_warm_start.argtypes = [C.c_void_p, C.c_void_p, C.c_double]
         L.mmpc_last_error.argtypes = [C.c_void_p]
         L.mmpc_last_error.restype = C.c_char_p
         L.mmpc_version.restype = C.c_char_p
@@ -160,6 +161,16 @@ class Engine:
         Q, P, R, W = m(Q, self.nref), m(P, self.nref), m(R, self.nu), m(W, self.nu)
         Sv = -1.0 if S is None else float(np.ravel(S)[0])
         self._chk(lib().mmpc_set_weights(self._h, _d(Q), _d(R), _d(P), Sv, _d(W)), "mmpc_set_weights")
+
+    def set_warm_start(self, u_guess=None, mu_init=1.0):
+        """mmpc_set_warm_start: `u_guess` (B,N,nu) cuda float64 tensor (kept alive by the engine) or None, initial barrier
+        parameter `mu_init`.  Applies to the following solve_batch_device calls (their x_guess is the initial X)."""
+        if u_guess is not None and (not u_guess.is_cuda or not u_guess.is_contiguous()
+                                    or tuple(u_guess.shape[1:]) != (self.N, self.nu)):
+            raise ValueError("u_guess must be a contiguous cuda float64 tensor (B, N, nu)")
+        self._u_guess = u_guess
+        self._chk(lib().mmpc_set_warm_start(self._h, C.c_void_p(u_guess.data_ptr()) if u_guess is not None else None,
+                                            float(mu_init)), "mmpc_set_warm_start")
 
     def set_terminal_xy_equality(self, on):
         self._chk(lib().mmpc_set_terminal_xy_equality(self._h, int(bool(on))), "mmpc_set_terminal_xy_equality")

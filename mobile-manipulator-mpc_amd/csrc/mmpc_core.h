@@ -64,6 +64,9 @@ struct MmpcParams {
     double ulim[2][5], xlim[2][9], dulim[2][5];
     int L;                   // half-space ("manipulation") obstacles (whole-body kind), 0..8
     double hs[8][6];         // point (3), normal (3)   (demo_wholebody_qref.py:21-33)
+    // opt-in (mmpc_set_warm_start): initial guess of U as [B][N][nu], separate from the U_last parameter of the cost and of
+    // the rate bounds; null = the reference's protocol (U starts at U_last, mpc_wholebody_qref.py:303,310)
+    const double *u_guess;
 };
 
 // robot_models/manipulator_3DoF.py:18-22, mobile_manipulator.py:14-15, base.py:15,
@@ -183,6 +186,7 @@ MMPC_HD MmpcLayout mmpc_layout(int N, int M, int obs_per_stage, int nhs = 0) {
 
 struct MmpcIO {
     const double *x_init, *traj_ref, *u_ref, *u_last, *x_guess, *obs;  // this problem's slices
+    const double *u_guess;                                             // (or null)
     double *X, *U, *s, *cost, *err;
     int *status, *iters;
 };
@@ -448,7 +452,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
     for (int i = lane; i < N * NU; i += MMPC_WAVE) {
         UREF[i] = io.u_ref[i];
         ULAST[i] = io.u_last[i];
-        U[i] = io.u_last[i];  // :303,:310
+        U[i] = io.u_guess ? io.u_guess[i] : io.u_last[i];  // :303,:310
     }
     for (int i = lane; i < NS; i += MMPC_WAVE) S[i] = 0.0;  // :304
     if (lane < 4) NUEQ[lane] = 0.0;
@@ -965,7 +969,13 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                 LANES_END
             }
             if (!failed) break;
-            if (attempt == 2) break;
+            if (attempt == 2) {
+                // even the Gauss-Newton pass lost a pivot (round-off under barrier weights z/t ~ 1e9 and more): raise the
+                // proximal term until the pass goes through (not with the terminal equality, where it is off)
+                if (teq || prox >= MMPC_PROX_MAX) break;
+                prox = mmpc_min(MMPC_PROX_MAX, mmpc_max(MMPC_PROX0, 4.0 * prox));
+                attempt = 1;
+            }
             failed = 0;
             LANES_BEGIN
             if (lane == 0) MISC[0] = 0.0;

@@ -379,7 +379,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
             val = (P.use_xguess && k >= 1) ? io.x_guess[k * NX + v] : x0;
             ref = io.traj_ref[k * NX + v];
         } else {
-            val = k < N ? io.u_last[k * NU + v - NX] : 0.0;
+            val = k < N ? (io.u_guess ? io.u_guess[k * NU + v - NX] : io.u_last[k * NU + v - NX]) : 0.0;
             ref = k < N ? io.u_ref[k * NU + v - NX] : 0.0;
         }
         XU[i] = val;
@@ -1135,7 +1135,13 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
             }
             if (ric_bad) failed = 1;
             if (!failed) break;
-            if (attempt == 2) break;
+            if (attempt == 2) {
+                // even the Gauss-Newton pass lost a pivot: round-off of the recursion under barrier weights z/t ~ 1e9 and
+                // more.  Same remedy as for crawling iterations - the proximal term, raised until the pass goes through
+                if (prox >= MMPC_PROX_MAX) break;
+                prox = mmpc_min(MMPC_PROX_MAX, mmpc_max(MMPC_PROX0, 4.0 * prox));
+                attempt = 1;
+            }
             failed = 0;
         }
         if (failed) {

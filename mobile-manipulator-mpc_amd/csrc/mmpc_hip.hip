@@ -34,6 +34,7 @@ __global__ __launch_bounds__(MMPC_WAVE) void mmpc_solve_kernel(
     io.u_ref = u_ref + (size_t)b * N * D::NU;
     io.u_last = u_last + (size_t)b * N * D::NU;
     io.x_guess = x_guess ? x_guess + (size_t)b * (N + 1) * D::NX : nullptr;
+    io.u_guess = P.u_guess ? P.u_guess + (size_t)b * N * D::NU : nullptr;
     io.obs = obs + (size_t)b * so;
     io.X = X + (size_t)b * (N + 1) * D::NX;
     io.U = U + (size_t)b * N * D::NU;
@@ -67,6 +68,7 @@ __global__ __launch_bounds__(MMPC_WAVE, WPE) void mmpc_fast_kernel(
     io.u_ref = u_ref + (size_t)b * N * D::NU;
     io.u_last = u_last + (size_t)b * N * D::NU;
     io.x_guess = x_guess ? x_guess + (size_t)b * (N + 1) * D::NX : nullptr;
+    io.u_guess = P.u_guess ? P.u_guess + (size_t)b * N * D::NU : nullptr;
     io.obs = obs + (size_t)b * so;
     io.X = X + (size_t)b * (N + 1) * D::NX;
     io.U = U + (size_t)b * N * D::NU;
@@ -206,7 +208,7 @@ extern "C" int mmpc_create(const mmpc_config *cfg, mmpc_handle *out) {
     MmpcParams &p = h->hp;
     p.N = cfg->N; p.M = cfg->M; p.obs_per_stage = cfg->obs_per_stage ? 1 : 0;
     p.max_iter = cfg->max_iter > 0 ? cfg->max_iter : 2000;   // the reference passes ipopt.max_iter 2000 (mpc_wholebody_qref.py:280)
-    p.use_xguess = 0; p.terminal_xy_eq = 0;
+    p.use_xguess = 0; p.terminal_xy_eq = 0; p.u_guess = nullptr;
     p.dt = cfg->dt; p.tol = cfg->tol > 0 ? cfg->tol : 1e-8; p.mu_init = cfg->mu_init > 0 ? cfg->mu_init : 1.0;
     for (int r = 0; r < 2; r++) {
         for (int j = 0; j < 5; j++) { p.ulim[r][j] = cfg->ulim[r][j]; p.dulim[r][j] = cfg->dulim[r][j]; }
@@ -348,6 +350,14 @@ static int launch(mmpc_handle h, int B, const double *x_init, const double *traj
         h->order_B = B;
     }
     return MMPC_OK;
+}
+
+extern "C" int mmpc_set_warm_start(mmpc_handle h, const double *d_u_guess, double mu_init) {
+    if (!h || !(mu_init > 0.0)) return fail(h, MMPC_E_ARG, "mmpc_set_warm_start: %s%s", "mu_init must be positive");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    h->hp.u_guess = d_u_guess;
+    h->hp.mu_init = mu_init;
+    return upload_params(h);
 }
 
 extern "C" int mmpc_solve_batch_device(mmpc_handle h, int B, const double *d_x_init, const double *d_traj_ref,

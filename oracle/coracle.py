@@ -72,7 +72,7 @@ def _p(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
 
-def solve_batch(par, x_init, traj_ref, u_ref, u_last, obs, X0=None, nthreads=1, **kw):
+def solve_batch(par, x_init, traj_ref, u_ref, u_last, obs, X0=None, nthreads=1, U0=None, **kw):
     """x_init (B,nx) [already clipped], traj_ref (B,N+1,nx), u_ref/u_last (B,N,nu), obs (B,M,3)|(B,N+1,M,3)."""
     x_init = np.ascontiguousarray(x_init, float); traj_ref = np.ascontiguousarray(traj_ref, float)
     u_ref = np.ascontiguousarray(u_ref, float); u_last = np.ascontiguousarray(u_last, float)
@@ -86,8 +86,10 @@ def solve_batch(par, x_init, traj_ref, u_ref, u_last, obs, X0=None, nthreads=1, 
     status = np.zeros(B, np.int32); iters = np.zeros(B, np.int32); cost = np.zeros(B); err = np.zeros(B)
     if X0 is not None:
         X0 = np.ascontiguousarray(X0, float)
-    lib().mmpc_oracle_solve_batch(C.byref(cfg), B, _p(x_init), _p(traj_ref), _p(u_ref), _p(u_last),
-                                  _p(X0) if X0 is not None else None, _p(obs), _p(X), _p(U), _p(s),
+    if U0 is not None:
+        U0 = np.ascontiguousarray(U0, float)
+    lib().mmpc_oracle_solve_batch_guess(C.byref(cfg), B, _p(x_init), _p(traj_ref), _p(u_ref), _p(u_last),
+                                  _p(X0) if X0 is not None else None, _p(U0) if U0 is not None else None, _p(obs), _p(X), _p(U), _p(s),
                                   status.ctypes.data_as(C.POINTER(C.c_int)), iters.ctypes.data_as(C.POINTER(C.c_int)),
                                   _p(cost), _p(err), int(nthreads))
     return dict(X=X, U=U, s=s, status=status, iters=iters, cost=cost, err=err)

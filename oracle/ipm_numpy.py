@@ -396,6 +396,15 @@ def solve(prob: nlp.Problem, U0=None, X0=None, opt: Options = None, verbose=Fals
         if fac is None:
             nreg += 1 if opt.exact_hessian else 0
             fac = factor(False, prox)
+            # if even the Gauss-Newton pass loses a pivot (round-off under huge barrier weights) the proximal term is raised
+            # until the pass goes through (not with the terminal equality, where it is off)
+            while fac is None and opt.prox and not p.terminal_xy_equality and prox_cur < opt.prox_max:
+                prox_cur = min(opt.prox_max, max(opt.prox0, prox_cur * opt.prox_up))
+                prox = prox_cur
+                fac = factor(False, prox)
+            if fac is None:
+                status = 2
+                break
         Pm, pv, K, kf, hss, gss, vx, vxN, pvv, kfv = fac
         nu_new = np.zeros(2)
         if p.terminal_xy_equality:

@@ -683,7 +683,16 @@ int mmpc_oracle_solve(const oracle_cfg *cfg, const double *x_init, const double 
         if (changed) filt_init = 0;
         /* ---- Newton direction */
         /* (the middle rung is skipped with the terminal equality, like the proximal term: see mmpc_core.h) */
-        if (!factor(w, mu, 2, prox)) if (cfg->terminal_xy_eq || w->nhs > 0 || !factor(w, mu, 1, prox)) if (!factor(w, mu, 0, prox)) { status = 2; break; }
+        if (!factor(w, mu, 2, prox)) if (cfg->terminal_xy_eq || w->nhs > 0 || !factor(w, mu, 1, prox)) {
+            /* Gauss-Newton; if even that loses a pivot (round-off under huge barrier weights) the proximal term is raised
+             * until the pass goes through (not with the terminal equality, where it is off) */
+            int okf = factor(w, mu, 0, prox);
+            while (!okf && !cfg->terminal_xy_eq && prox < PROX_MAX) {
+                prox = prox * 4.0 > PROX0 ? prox * 4.0 : PROX0; if (prox > PROX_MAX) prox = PROX_MAX;
+                okf = factor(w, mu, 0, prox);
+            }
+            if (!okf) { status = 2; break; }
+        }
         w->nu_new[0] = w->nu_new[1] = 0;
         if (cfg->terminal_xy_eq) {
             double d0[NXM] = {0}, Dv[NXM][2], u0[NUM], Uv[NUM][2], t0[NXM], Tv[NXM][2];
@@ -812,9 +821,18 @@ int mmpc_oracle_solve(const oracle_cfg *cfg, const double *x_init, const double 
 }
 
 /* batch driver (OpenMP over instances when compiled with -fopenmp).  obs stride = M*3 or (N+1)*M*3 */
+int mmpc_oracle_solve_batch_guess(const oracle_cfg *cfg, int B, const double *x_init, const double *traj_ref, const double *u_ref,
+                                  const double *u_last, const double *X0, const double *U0, const double *obs, double *Xo, double *Uo,
+                                  double *so, int *status, int *iters, double *cost, double *err, int nthreads);
 int mmpc_oracle_solve_batch(const oracle_cfg *cfg, int B, const double *x_init, const double *traj_ref, const double *u_ref,
                             const double *u_last, const double *X0, const double *obs, double *Xo, double *Uo, double *so,
                             int *status, int *iters, double *cost, double *err, int nthreads) {
+    return mmpc_oracle_solve_batch_guess(cfg, B, x_init, traj_ref, u_ref, u_last, X0, 0, obs, Xo, Uo, so, status, iters, cost, err, nthreads);
+}
+/* U0 (or NULL): initial U separate from the U_last parameter - the opt-in warm start of include/mmpc.h (mmpc_set_warm_start) */
+int mmpc_oracle_solve_batch_guess(const oracle_cfg *cfg, int B, const double *x_init, const double *traj_ref, const double *u_ref,
+                                  const double *u_last, const double *X0, const double *U0, const double *obs, double *Xo, double *Uo,
+                                  double *so, int *status, int *iters, double *cost, double *err, int nthreads) {
     int nx = cfg->kind == 0 ? 9 : 6, nu = cfg->kind == 0 ? 5 : 2, N = cfg->N;
     size_t so_ = (size_t)(cfg->obs_per_stage ? (N + 1) : 1) * cfg->M * 3;
     (void)nthreads;
@@ -823,7 +841,8 @@ int mmpc_oracle_solve_batch(const oracle_cfg *cfg, int B, const double *x_init, 
 #endif
     for (int b = 0; b < B; b++) {
         status[b] = mmpc_oracle_solve(cfg, x_init + (size_t)b * nx, traj_ref + (size_t)b * (N + 1) * (cfg->pose_ref ? 4 : nx), u_ref + (size_t)b * N * nu,
-                                      u_last + (size_t)b * N * nu, X0 ? X0 + (size_t)b * (N + 1) * nx : 0, 0, obs + (size_t)b * so_,
+                                      u_last + (size_t)b * N * nu, X0 ? X0 + (size_t)b * (N + 1) * nx : 0,
+                                      U0 ? U0 + (size_t)b * N * nu : 0, obs + (size_t)b * so_,
                                       Xo + (size_t)b * (N + 1) * nx, Uo + (size_t)b * N * nu, so + (size_t)b * (N + 1),
                                       iters + b, cost + b, err + b);
     }

@@ -28,6 +28,7 @@ static void run(const MmpcParams *P, int B, const double *x_init, const double *
         io.u_ref = u_ref + (size_t)b * N * D::NU;
         io.u_last = u_last + (size_t)b * N * D::NU;
         io.x_guess = x_guess ? x_guess + (size_t)b * (N + 1) * D::NX : nullptr;
+        io.u_guess = P->u_guess ? P->u_guess + (size_t)b * N * D::NU : nullptr;
         io.obs = obs + (size_t)b * so;
         io.X = X + (size_t)b * (N + 1) * D::NX;
         io.U = U + (size_t)b * N * D::NU;
@@ -56,6 +57,7 @@ static void run_fast(const MmpcParams *P, int B, const double *x_init, const dou
         io.u_ref = u_ref + (size_t)b * N * D::NU;
         io.u_last = u_last + (size_t)b * N * D::NU;
         io.x_guess = x_guess ? x_guess + (size_t)b * (N + 1) * D::NX : nullptr;
+        io.u_guess = P->u_guess ? P->u_guess + (size_t)b * N * D::NU : nullptr;
         io.obs = obs + (size_t)b * so;
         io.X = X + (size_t)b * (N + 1) * D::NX;
         io.U = U + (size_t)b * N * D::NU;

@@ -19,7 +19,7 @@ class MmpcParams(C.Structure):
                 ("Q2", C.c_double * 81), ("P2", C.c_double * 81), ("RW2", C.c_double * 25),
                 ("R2", C.c_double * 25), ("W2", C.c_double * 25),
                 ("ulim", (C.c_double * 5) * 2), ("xlim", (C.c_double * 9) * 2), ("dulim", (C.c_double * 5) * 2),
-                ("L", C.c_int), ("hs", (C.c_double * 6) * 8)]
+                ("L", C.c_int), ("hs", (C.c_double * 6) * 8), ("u_guess", C.c_void_p)]
 
 
 def build(asan=False):
@@ -64,7 +64,7 @@ def _p(a):
     return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
 
 
-def solve_batch(par, x_init, traj_ref, u_ref, u_last, obs, x_guess=None, reverse=False, asan=False, fast=False, **kw):
+def solve_batch(par, x_init, traj_ref, u_ref, u_last, obs, x_guess=None, reverse=False, asan=False, fast=False, u_guess=None, **kw):
     lib = C.CDLL(build(asan))
     assert lib.mmpc_emu_params_size() == C.sizeof(MmpcParams)
     x_init = np.ascontiguousarray(x_init, float); traj_ref = np.ascontiguousarray(traj_ref, float)
@@ -76,6 +76,9 @@ def solve_batch(par, x_init, traj_ref, u_ref, u_last, obs, x_guess=None, reverse
     N, nx, nu = par.N, par.nx, par.nu
     M = obs.shape[-2]
     prm = make_params(par, M, obs.ndim == 4, x_guess is not None, **kw)
+    if u_guess is not None:
+        u_guess = np.ascontiguousarray(u_guess, float)
+        prm.u_guess = u_guess.ctypes.data
     X = np.zeros((B, N + 1, nx)); U = np.zeros((B, N, nu)); s = np.zeros((B, N + 1))
     status = np.zeros(B, np.int32); iters = np.zeros(B, np.int32); cost = np.zeros(B); err = np.zeros(B)
     fn = lib.mmpc_emu_solve_fast if fast else lib.mmpc_emu_solve
