@@ -52,6 +52,10 @@ for t in range(T):
             for b in bad:
                 np.savez(os.path.join(ROOT, "gpurun_out", "c5warmfail_t%d_b%d.npz" % (t, b)), x=x[b].cpu().numpy(), loc=loc[b].cpu().numpy(),
                          ul=ul[b].cpu().numpy(), obs=obs[b].cpu().numpy(), ug=ug[b].cpu().numpy(), xg=xg[b].cpu().numpy())
+    if "--dump-slow" in sys.argv and SHIFTED and t >= 1:
+        for b in torch.nonzero(out["iters"] > 120).flatten().tolist()[:6]:
+            np.savez(os.path.join(ROOT, "gpurun_out", "c5warmslow_t%d_b%d.npz" % (t, b)), x=x[b].cpu().numpy(), loc=loc[b].cpu().numpy(),
+                     ul=ul[b].cpu().numpy(), obs=obs[b].cpu().numpy(), ug=ug[b].cpu().numpy(), xg=xg[b].cpu().numpy(), iters=int(out["iters"][b]))
     it = out["iters"].double()
     top = torch.sort(out["iters"]).values[-4:].tolist()
     print("[%d per CU, %d B LDS] tick %d: %.2f ms  mean iters %.2f  top %s   work/slot at 3 per CU: %.0f iterations" %
