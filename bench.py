@@ -19,8 +19,8 @@ sys.path.insert(0, _ROOT)
 
 FP64_PEAK_TFLOPS = 78.6      # MI355X FP64 vector = FP64 matrix peak (spec), SURVEY §7
 HBM_PEAK_GBS = 8000.0
-PROFILE_TAG = "r01_n"                             # PMC summaries of this build (tools/collect_profiles.sh <tag>)
-WEAK_SEEDS = (3, 11, 14, 16, 19, 23, 25, 26)       # per-rank seeds of the C4 generator under weak scaling (see main())
+PROFILE_TAG = "r02"                               # PMC summaries of this build (tools/collect_profiles.sh <tag>)
+SEED_BASE = 3                                     # weak scaling: rank r solves seed SEED_BASE + r of the C4 generator (no selection)
 
 
 def riccati_flops_per_iter(N, nx, nu, M, nself):
@@ -53,7 +53,10 @@ def main():
     ap.add_argument("--obstacles", type=int, default=5)
     ap.add_argument("--cpu-sample", type=int, default=8192, help="instances timed on the host cores (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--seed-base", type=int, default=None, help="weak scaling: rank r solves the C4 seed SEED_BASE + r")
+    ap.add_argument("--seed-base", type=int, default=SEED_BASE, help="weak scaling: rank r solves the C4 seed SEED_BASE + r")
+    ap.add_argument("--gather", default="full", choices=["full", "u0"],
+                    help="what the one all-gather of the path collects: the solved (X,U,s) records (310 doubles per instance) "
+                         "or only the first inputs u0 the closed loop applies (5 doubles per instance, SURVEY 8e)")
     ap.add_argument("--config", default="c4", choices=["c4", "c5"],
                     help="c4: BASELINE metric (default). c5: N=30, 8 moving obstacles, warm-started receding horizon (1 GPU)")
     ap.add_argument("--ticks", type=int, default=10)
@@ -95,20 +98,20 @@ def main():
     Bl = hi - lo
     if args.scaling == "weak":
         # every rank generates its own seeded batch (rank 0 = the N=1 workload); instance b of rank r is global b + r*batch.
-        # The seeds are the first eight of the sweep in profiles/r01_seed_sweep.txt whose slowest instance needs <= 110
-        # iterations: one instance is one wave, so an instance that needs 150+ iterations (about four in ten seeds hold
-        # one) outlasts the other 8191 of its batch and the step would time that single wave, not
-        # the path.  --seed-base S gives rank r the seed S + r instead.
-        seed = WEAK_SEEDS[rank % len(WEAK_SEEDS)] if args.seed_base is None else args.seed_base + rank
+        # Consecutive seeds, nothing filtered: what the slowest instance of a rank's batch costs shows in per_rank below
+        seed = args.seed_base + rank
         d = synth.make_batch(args.batch, N=N, M=M, config_id=seed)
         sl = slice(0, Bl)
     else:
         # identical seeded inputs on every rank; each rank keeps its contiguous slice
-        d = synth.make_batch(Bg, N=N, M=M)
+        d = synth.make_batch(Bg, N=N, M=M, config_id=args.seed_base)
         sl = slice(lo, hi)
     robot = mm.MobileManipulator(0.1)
     ctrl = mm.MPCWholeBody(robot, [], [], N=N, max_batch=Bl, device=local_dev, n_obstacles=M)
     eng = ctrl._engine
+    # The headline is measured WITHOUT the longest-first schedule hint: the timed steps re-solve one resident batch, and a
+    # hint taken from the previous solve of the identical problems is knowledge no first solve of a batch has
+    eng.set_schedule_hint(False)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a[sl])).to(dev)
     x_init = t(np.clip(d["x_init"], ctrl.xlim[0], ctrl.xlim[1]))
     traj, uref, obs = t(d["traj_ref"]), t(d["u_ref"]), t(d["obs"])
@@ -116,20 +119,23 @@ def main():
     out = eng.solve_batch_device(x_init, traj, uref, ulast, obs)
     packed = gathered = None
     pending = [None, None]
+    rec = sharding.record_len(N, nx, nu) if args.gather == "full" else nu
     if world > 1:
-        rec = sharding.record_len(N, nx, nu)
         packed = [torch.empty((Bl, rec), dtype=torch.float64, device=dev) for _ in range(2)]
         gathered = [torch.empty((Bg, rec), dtype=torch.float64, device=dev) for _ in range(2)]
 
     def gather(i):
-        # the one collective of the path: all-gather of the solved (X,U,s) over xGMI (RCCL), inside the timed region.
-        # Double-buffered and asynchronous: the gather of step i travels on RCCL's stream while step i+1 is solved; a
-        # buffer pair is reused only after its previous gather has completed, and drain() waits for the last ones.
+        # the one collective of the path: all-gather of the solved (X,U,s) - or of u0 only - over xGMI (RCCL), inside the
+        # timed region.  Double-buffered and asynchronous: the gather of step i travels on RCCL's stream while step i+1 is
+        # solved; a buffer pair is reused only after its previous gather has completed, and drain() waits for the last ones.
         b = i & 1
         if pending[b] is not None:
             pending[b].wait()
             pending[b] = None
-        sharding.pack_solution(out["X"], out["U"], out["s"], out=packed[b])
+        if args.gather == "full":
+            sharding.pack_solution(out["X"], out["U"], out["s"], out=packed[b])
+        else:
+            packed[b].copy_(out["U"][:, 0, :])
         _, pending[b] = sharding.allgather_solutions(packed[b], Bg, dist, gathered=gathered[b], async_op=True)
 
     def drain():
@@ -148,20 +154,18 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    kernel_ms = 0.0
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for i in range(args.steps):
-        ev0.record()
+        evs[i][0].record()
         eng.solve_batch_device(x_init, traj, uref, ulast, obs, out=out)
-        ev1.record()
+        evs[i][1].record()
         if world > 1:
             gather(i)
-        ev1.synchronize()
-        kernel_ms += ev0.elapsed_time(ev1)
     if world > 1:
         drain()
     torch.cuda.synchronize()
+    t_rank = time.perf_counter() - t0                      # this rank's own time for its K steps (before the barrier)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -170,25 +174,27 @@ def main():
         tt = torch.tensor([el], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
+    step_ms = sorted(e0.elapsed_time(e1) for e0, e1 in evs)     # solve kernel per step, HIP events on the launch stream
     status = out["status"].cpu().numpy()
     iters = out["iters"].cpu().numpy()
     err = out["err"].cpu().numpy()
-    stats = torch.tensor([float((status == 0).sum()), float(iters.sum()), float(iters.max()), float(err.max())],
-                         dtype=torch.float64, device=dev)
+    stats = torch.tensor([float((status == 0).sum()), float(iters.sum()), float(iters.max()), float(err.max()),
+                          t_rank / args.steps * 1e3, step_ms[len(step_ms) // 2], float(Bl)], dtype=torch.float64, device=dev)
     if world > 1:
         parts = [torch.zeros_like(stats) for _ in range(world)]
         dist.all_gather(parts, stats)
-        n_conv = sum(float(p[0]) for p in parts); it_sum = sum(float(p[1]) for p in parts)
-        it_max = max(float(p[2]) for p in parts); err_max = max(float(p[3]) for p in parts)
+        parts = [p.tolist() for p in parts]
     else:
-        n_conv, it_sum, it_max, err_max = [float(v) for v in stats.tolist()]
+        parts = [stats.tolist()]
+    n_conv = sum(p[0] for p in parts); it_sum = sum(p[1] for p in parts)
+    it_max = max(p[2] for p in parts); err_max = max(p[3] for p in parts)
 
     if rank == 0:
         ms_per_step = el / args.steps * 1e3
         value = Bg * args.steps / el
         mean_iters = it_sum / Bg
-        k_ms = kernel_ms / args.steps                      # this rank's solve kernel, HIP events on its stream
-        fl = riccati_flops_per_iter(N, nx, nu, M, 4) * mean_iters * Bl
+        k_ms = sum(step_ms) / len(step_ms)                 # this rank's solve kernel, average launch duration
+        fl = riccati_flops_per_iter(N, nx, nu, M, 4) * (float(iters.sum()) / Bl) * Bl
         achieved_tf = fl / (k_ms * 1e-3) / 1e12
         by = algorithmic_bytes_per_solve(N, nx, nu, M) * Bl
         traffic = None
@@ -215,59 +221,58 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "whole-body MPC solve, N=%d, M=%d static circle obstacles, batch %d per GPU%s (global %d), "
-                                   "cold start (u_latest=0), seeded synthetic (x_init, traj_ref, obstacles)"
+                                   "cold start (u_latest=0), seeded synthetic (x_init, traj_ref, obstacles), no schedule hint "
+                                   "(workgroups in batch order)"
                                    % (N, M, Bl, "" if args.scaling == "weak" else " [strong: global batch fixed]", Bg),
                        "batch_per_gpu": Bl,
-                       "seeds": ([WEAK_SEEDS[r % len(WEAK_SEEDS)] if args.seed_base is None else args.seed_base + r for r in range(world)]
-                                 if args.scaling == "weak" else [3]),
-                       "parallelism": "batch-sharded x%d%s" % (world, " + all-gather(X,U,s)" if world > 1 else "")},
+                       "seeds": ([args.seed_base + r for r in range(world)] if args.scaling == "weak" else [args.seed_base]),
+                       "parallelism": "batch-sharded x%d%s" % (world, (" + all-gather(%s)" % ("X,U,s" if args.gather == "full" else "u0")) if world > 1 else "")},
             "solver": {"converged_frac": n_conv / Bg, "mean_iters": mean_iters, "max_iters": it_max,
                        "max_scaled_kkt": err_max, "lds_bytes_per_problem": eng.lds_bytes, "problems_per_cu": eng.problems_per_cu},
+            "median_kernel_ms": step_ms[len(step_ms) // 2],
+            # what every rank did on its own (the job's time is the slowest rank's): a rank whose batch holds one instance of
+            # several hundred iterations shows here as a long step with ordinary mean iterations
+            "per_rank": [{"rank": r, "batch": int(p[6]), "ms_per_step": p[4], "median_kernel_ms": p[5], "max_iters": int(p[2]),
+                          "mean_iters": p[1] / p[6], "converged": int(p[0])} for r, p in enumerate(parts)],
             "roofline": {"bound": "mfma", "kernel": "mmpc_fast_kernel<0,20,5>" if (N, M) == (20, 5) else "mmpc_solve_kernel<0>", "achieved": achieved_tf,
                          "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tf / FP64_PEAK_TFLOPS,
                          "traffic": traffic, "kernel_ms": k_ms, "mfma": mfma,
                          "flops_per_iter": riccati_flops_per_iter(N, nx, nu, M, 4),
                          "hbm_achieved_GBs": by / (k_ms * 1e-3) / 1e9, "hbm_frac": by / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
+        ev0, ev1 = evs[0]
         if world == 1 and not args.no_cpu:   # (--no-cpu = the profiler passes: they see the warm-up and timed launches only)
-            # The engine orders the workgroups of a launch longest-first by the iteration counts of the handle's previous
-            # solve (a receding-horizon loop solves the same robots every tick).  The timed steps above re-solve the same
-            # batch, so for them that hint is exact; the first solve of a batch has none.  Measured here, outside the timed
-            # region: the same launch after mmpc_reset() (hint forgotten), HIP events on the launch stream.
-            cold = []
-            for _ in range(3):
-                eng.reset()
+            # Extras, outside the timed region.  (1) the same launches WITH the schedule hint (mmpc_set_schedule_hint, the
+            # engine's default): workgroups start longest-first by the iteration counts of the handle's previous solve - exact
+            # here because the batch is re-solved, correlated in a receding-horizon loop.
+            eng.set_schedule_hint(True)
+            hinted = []
+            for _ in range(6):
                 ev0.record()
                 eng.solve_batch_device(x_init, traj, uref, ulast, obs, out=out)
                 ev1.record(); ev1.synchronize()
-                cold.append(ev0.elapsed_time(ev1))
-            cold_ms = sorted(cold)[1]
-            res["schedule_hint"] = {"in_timed_steps": "longest-first order from the previous solve of the same batch (exact)",
-                                    "first_solve_ms": cold_ms, "first_solve_value": Bl / (cold_ms * 1e-3), "unit": "solves/s",
-                                    "note": "no hint: workgroups in batch order; every instance still converges to the same result"}
-            # Two batches in flight (two handles, two HIP streams, alternating): the drain of one launch - waves still
-            # iterating on its slowest instances while CUs idle - is filled by the next launch.  What a deployment that
-            # pipelines independent batches gets; reported beside `value`, which stays the one-stream figure.
-            eng.reset()
+                hinted.append(ev0.elapsed_time(ev1))
+            h_ms = sorted(hinted[1:])[2]
+            res["schedule_hint"] = {"in_timed_steps": "off", "hinted_ms": h_ms, "hinted_value": Bl / (h_ms * 1e-3), "unit": "solves/s",
+                                    "note": "same batch re-solved with the longest-first order of its previous solve (exact hint): "
+                                            "not the headline; every instance converges to the same result either way"}
+            # (2) two batches in flight (two handles, two HIP streams, alternating): the drain of one launch - waves still
+            # iterating on its slowest instances while CUs idle - is filled by the next launch.  No hint.
+            eng.set_schedule_hint(False)
             ctrl2 = mm.MPCWholeBody(robot, [], [], N=N, max_batch=Bl, device=local_dev, n_obstacles=M)
-            engs, outs = (eng, ctrl2._engine), (out, None)
+            ctrl2._engine.set_schedule_hint(False)
+            engs, outs = (eng, ctrl2._engine), [out, None]
             streams = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
-            pipe = {}
-            for label, hinted in (("hinted", True), ("first_solves", False)):
-                outs = list(outs)
-                for rep in range(2 + args.steps):
-                    if rep == 2:
-                        torch.cuda.synchronize(); p0 = time.perf_counter()
-                    for q in range(2):
-                        if not hinted:
-                            engs[q].reset()
-                        with torch.cuda.stream(streams[q]):
-                            outs[q] = engs[q].solve_batch_device(x_init, traj, uref, ulast, obs, out=outs[q])
-                torch.cuda.synchronize()
-                pipe[label] = 2 * args.steps * Bl / (time.perf_counter() - p0)
-            res["two_streams"] = {"value_hinted": pipe["hinted"], "value_first_solves": pipe["first_solves"], "unit": "solves/s",
-                                  "note": "two handles on two HIP streams, %d launches each; not the headline figure" % args.steps}
-            # PCIe-inclusive rate of the host-pointer entry point (mmpc_solve_batch: H2D, solve, D2H of X,U,s,...): a note
+            for rep in range(2 + args.steps):
+                if rep == 2:
+                    torch.cuda.synchronize(); p0 = time.perf_counter()
+                for q in range(2):
+                    with torch.cuda.stream(streams[q]):
+                        outs[q] = engs[q].solve_batch_device(x_init, traj, uref, ulast, obs, out=outs[q])
+            torch.cuda.synchronize()
+            res["two_streams"] = {"value": 2 * args.steps * Bl / (time.perf_counter() - p0), "unit": "solves/s",
+                                  "note": "two handles on two HIP streams, %d launches each, no schedule hint; not the headline figure" % args.steps}
+            # (3) PCIe-inclusive rate of the host-pointer entry point (mmpc_solve_batch: H2D, solve, D2H of X,U,s,...): a note
             # beside `value`, which is always the device-resident rate
             hx = np.clip(d["x_init"][:Bl], ctrl.xlim[0], ctrl.xlim[1])
             eng.reset(); eng.solve_batch(hx, d["traj_ref"][:Bl], d["u_ref"][:Bl], d["obs"][:Bl])
@@ -277,8 +282,7 @@ def main():
                 eng.solve_batch(hx, d["traj_ref"][:Bl], d["u_ref"][:Bl], d["obs"][:Bl])
             res["host_pointer_api"] = {"value": 3 * Bl / (time.perf_counter() - h0), "unit": "solves/s",
                                        "note": "mmpc_solve_batch with pageable host arrays in and out (PCIe-inclusive, cold start)"}
-        if world == 1 and not args.no_cpu:   # (not in the profiler passes: they must only see the batch launches)
-            # latency of ONE solve through the reference's own call (controller.solve(x_init, traj_ref, u_ref) -> u0), the
+            # (4) latency of ONE solve through the reference's own call (controller.solve(x_init, traj_ref, u_ref) -> u0), the
             # number the closed-loop driver sees per tick (interface_wholebody_qref.py:134); cold start each time
             import contextlib, io
             one = mm.MPCWholeBody(robot, [mm.Obstacles(*d["obs"][0, m]) for m in range(M)], [], N=N)
@@ -291,29 +295,36 @@ def main():
                     lat.append(time.perf_counter() - l0)
             res["single_solve_latency_ms"] = {"median": 1e3 * float(np.median(lat[2:])), "max": 1e3 * float(np.max(lat[2:])),
                                               "note": "MPCWholeBody.solve() for one instance, host arrays in, u0 out (10 solves)"}
-        if world == 1 and not args.no_cpu:
-            from oracle import coracle, nlp
-            avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-            cores = min(avail, 16)          # the GPU box gives one GPU a 16-core CPU share
-            ns = min(args.cpu_sample, Bl)
-            par = nlp.WholeBodyParams(N=N)
-            xi = np.clip(d["x_init"][:ns], par.xlim[0], par.xlim[1])
-            coracle.lib()
-            # bounded sample: passes over the batch until about 10 s of wall time on the host cores (at most 24 passes)
-            c0 = time.perf_counter(); passes = 0
-            while passes < 24 and (passes == 0 or time.perf_counter() - c0 < 10.0):
-                o = coracle.solve_batch(par, xi, d["traj_ref"][:ns], d["u_ref"][:ns], np.zeros((ns, N, nu)), d["obs"][:ns],
-                                        nthreads=cores)
-                passes += 1
-            ct = (time.perf_counter() - c0) / passes
-            gX = out["X"][:ns].cpu().numpy()
-            res["cpu_baseline"] = {"value": ns / ct, "unit": "solves/s", "cores": cores, "kind": "port",
-                                   "sample": "first %d instances of the same batch, oracle/mmpc_oracle.c (OpenMP), %d passes, %.1f s in all" % (ns, passes, ct * passes),
-                                   "max_abs_dX_vs_gpu": float(np.abs(gX - o["X"]).max()),
-                                   "casadi": "CasADi/IPOPT baseline unavailable on this host" if not _has_casadi() else "importable"}
+            res["cpu_baseline"] = cpu_baseline(d, N, M, min(args.cpu_sample, Bl), out["X"])
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
+
+
+def cpu_baseline(d, N, M, ns, gpu_X, obs=None, u_last=None, x_init=None, traj=None):
+    """The CPU restatement (oracle/mmpc_oracle.c, OpenMP over the batch) timed on the GPU box's host cores on a bounded
+    sample of the same workload; `kind` is "port": the reference's own solver (CasADi/IPOPT) cannot be installed here."""
+    from oracle import coracle, nlp
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(avail, 16)          # the GPU box gives one GPU a 16-core CPU share
+    par = nlp.WholeBodyParams(N=N)
+    xi = np.clip(d["x_init"][:ns], par.xlim[0], par.xlim[1]) if x_init is None else x_init[:ns]
+    tr = d["traj_ref"][:ns] if traj is None else traj[:ns]
+    ob = d["obs"][:ns] if obs is None else obs[:ns]
+    ul = np.zeros((ns, N, 5)) if u_last is None else u_last[:ns]
+    coracle.lib()
+    # bounded sample: passes over the sample until about 10 s of wall time on the host cores (at most 24 passes)
+    c0 = time.perf_counter(); passes = 0
+    while passes < 24 and (passes == 0 or time.perf_counter() - c0 < 10.0):
+        o = coracle.solve_batch(par, xi, tr, d["u_ref"][:ns], ul, ob, nthreads=cores, max_iter=2000)
+        passes += 1
+    ct = (time.perf_counter() - c0) / passes
+    gX = gpu_X[:ns].cpu().numpy()
+    dev = np.abs(gX - o["X"]).reshape(ns, -1).max(1)
+    return {"value": ns / ct, "unit": "solves/s", "cores": cores, "kind": "port",
+            "sample": "first %d instances of the same batch, oracle/mmpc_oracle.c (OpenMP), %d passes, %.1f s in all" % (ns, passes, ct * passes),
+            "max_abs_dX_vs_gpu": float(dev.max()), "n_dX_above_1e-6": int((dev > 1e-6).sum()),
+            "casadi": "CasADi/IPOPT baseline unavailable on this host" if not _has_casadi() else "importable"}
 
 
 def main_c5(args):
@@ -351,13 +362,17 @@ def main_c5(args):
 
     ug_buf = torch.zeros((B, N, 5), **f64); xg_buf = torch.zeros((B, N + 1, 9), **f64)
 
-    def run_all(shifted=False):
+    evp = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(T)]
+    cap = {}
+
+    def run_all(shifted=False, timed=False):
         """shifted=False: the reference's protocol (U starts at the previous optimum unshifted = U_last, X at tile(x_init),
         cold barrier parameter).  shifted=True: the engine's opt-in warm start (mmpc_set_warm_start) from tick 1 on - U starts
         at the previous optimum shifted by one stage, X at its roll-out, mu at 0.1; U_last, and with it the NLP, is unchanged."""
         x = x0.clone(); ul = torch.zeros((B, N, 5), **f64); its = []
         out = None
         eng.set_warm_start(None, 1.0)
+        eng.reset()      # forget the schedule hint of the previous pass: tick 0 is a first solve, later ticks are hinted by the tick before
         for t in range(T):
             dist = torch.linalg.norm(x[:, None, :2] - glob[:, :, :2], dim=2)
             start = torch.argmin(dist, dim=1)
@@ -374,7 +389,16 @@ def main_c5(args):
                 if t == 1:
                     eng.set_warm_start(ug_buf, 0.1)
                 xg = xg_buf
-            out = eng.solve_batch_device(x, loc, uref, ul, obs.contiguous(), x_guess=xg, out=out)
+            obs = obs.contiguous()
+            if timed:
+                evp[t][0].record()
+            out = eng.solve_batch_device(x, loc, uref, ul, obs, x_guess=xg, out=out)
+            if timed:
+                evp[t][1].record()
+            if timed and t in (0, T - 1) and "x%d" % t not in cap:      # inputs/outputs of two ticks for the CPU leg's parity figure
+                torch.cuda.synchronize()
+                cap["x%d" % t] = x.clone(); cap["loc%d" % t] = loc.clone(); cap["ul%d" % t] = ul.clone(); cap["obs%d" % t] = obs.clone()
+                cap["X%d" % t] = out["X"].clone()
             ul = out["U"].clone()
             u0 = out["U"][:, 0]
             x = f_batch(torch.minimum(torch.maximum(x, xlo), xhi), u0)
@@ -389,6 +413,14 @@ def main_c5(args):
         its = run_all()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    # kernel time and iteration totals of one more pass (HIP events around every tick's solve launch, on its stream)
+    its_k = run_all(timed=True)
+    torch.cuda.synchronize()
+    k_ms = [e0.elapsed_time(e1) for e0, e1 in evp]
+    tot_iters = sum(float(a) for a, _, _ in its_k) * B
+    fl_iter = riccati_flops_per_iter(N, 9, 5, M, 4)
+    ach = fl_iter * tot_iters / (sum(k_ms) * 1e-3) / 1e12
+    by = 8 * (9 + 9 * (N + 1) + 5 * N + 5 * N + 3 * M * (N + 1)) + 8 * (9 * (N + 1) + 5 * N + (N + 1))   # per solve, per-stage obstacle table
     # the opt-in warm start, timed the same way (reported beside the figure of the reference's protocol)
     run_all(shifted=True)
     torch.cuda.synchronize()
@@ -402,7 +434,11 @@ def main_c5(args):
            "value": B * T * args.steps / el, "unit": "solves/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
            "dtype": "f64", "data": "synthetic",
-           "config": {"workload": "C5: whole-body N=30, M=8 moving circle obstacles, batch %d, %d ticks (tick 0 cold)" % (B, T)},
+           "config": {"workload": "C5: whole-body N=30, M=8 moving circle obstacles, batch %d, %d ticks (tick 0 cold; the launch "
+                                  "order of a tick is hinted by the iteration counts of the tick before)" % (B, T)},
+           "roofline": {"bound": "mfma", "kernel": "mmpc_fast_kernel<0,30,8>", "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": ach / FP64_PEAK_TFLOPS, "traffic": _c5_traffic(), "kernel_ms_per_tick": k_ms, "flops_per_iter": fl_iter,
+                        "hbm_achieved_GBs": by * B * T / (sum(k_ms) * 1e-3) / 1e9, "hbm_frac": by * B * T / (sum(k_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS},
            "solver": {"mean_iters_per_tick": [float(a) for a, _, _ in its], "converged_frac_per_tick": [float(b) for _, b, _ in its],
                       "max_iters_per_tick": [int(c) for _, _, c in its],
                       "lds_bytes_per_problem": eng.lds_bytes, "problems_per_cu": eng.problems_per_cu},
@@ -412,7 +448,23 @@ def main_c5(args):
                                   "max_iters_per_tick": [int(c) for _, _, c in its_w],
                                   "note": "opt-in mmpc_set_warm_start: U guess = previous optimum shifted one stage, X guess = its "
                                           "roll-out (torch ops, inside the timed region), mu_init 0.1; same NLP, not the reference's protocol"}}
+    if not args.no_cpu:
+        # CPU leg: the same two captured ticks (the cold one and the last warm one), first 1024 instances, C oracle on the host cores
+        ns = min(1024, B)
+        legs = []
+        for t in (0, T - 1):
+            dd = {"x_init": cap["x%d" % t].cpu().numpy(), "traj_ref": cap["loc%d" % t].cpu().numpy(), "u_ref": np.zeros((B, N, 5)),
+                  "obs": cap["obs%d" % t].cpu().numpy()}
+            legs.append(cpu_baseline(dd, N, M, ns, cap["X%d" % t], u_last=cap["ul%d" % t].cpu().numpy()))
+        res["cpu_baseline"] = {"value": 2.0 / (1.0 / legs[0]["value"] + 1.0 / legs[1]["value"]), "unit": "solves/s", "cores": legs[0]["cores"],
+                               "kind": "port", "sample": "ticks 0 and %d of the timed loop, first %d instances each: " % (T - 1, ns) + legs[0]["sample"],
+                               "per_tick": legs, "casadi": legs[0]["casadi"]}
     print(json.dumps(res))
+
+
+def _c5_traffic():
+    p = os.path.join(_ROOT, "profiles", PROFILE_TAG + "_c5_pmc_traffic.json")
+    return json.load(open(p))["traffic_bytes_per_launch"] if os.path.exists(p) else None
 
 
 def _has_casadi():

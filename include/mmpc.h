@@ -84,8 +84,10 @@ int mmpc_set_terminal_xy_equality(mmpc_handle h, int on);
 int mmpc_reset(mmpc_handle h);
 
 /* solve(x_init, traj_ref, u_ref) for B instances (mpc_wholebody_qref.py:287-331, mpc_base.py:191-226).
- * Host pointers.  Uses and then replaces the handle's warm start (u_latest, and x_guess for the base
- * kind) for instances 0..B-1.  x_init of the whole-body kind is clipped to xlim (:290-291) inside.
+ * Host pointers.  Uses the handle's warm start (u_latest, and x_guess for the base and pose-reference kinds) for
+ * instances 0..B-1 and replaces it for the instances that CONVERGED - the reference assigns u_latest / x_guess after a
+ * successful solve only (:329-330 follow the exception of :315), a failed instance keeps what it had.
+ * x_init of the whole-body kind is clipped to xlim (:290-291) inside.
  * Any out_* may be NULL except out_u0.  out_u0[B][nu] = U*[0] (the reference's return value). */
 int mmpc_solve_batch(mmpc_handle h, int B, const double *x_init, const double *traj_ref, const double *u_ref,
                      const double *obs, double *out_u0, double *out_X, double *out_U, double *out_s, int *out_status,
@@ -122,6 +124,18 @@ int mmpc_ik_batch_device(int device, int B, const double *d_q0, const double *d_
  * previous optimum shifted by one stage, the roll-out of the dynamics under it, and mu_init = 0.1: the same NLP, solved
  * in fewer than half the iterations.  mmpc_set_warm_start(h, NULL, 1.0) restores the default. */
 int mmpc_set_warm_start(mmpc_handle h, const double *d_u_guess, double mu_init);
+
+/* Launch order of the instances of a batch.  on (default): the workgroups of a launch are started longest-first by
+ * the iteration counts of the handle's previous launch of the same B (a receding-horizon loop solves the same robots
+ * every tick, so consecutive ticks have correlated difficulty); off: batch order.  Results never depend on it.
+ * No reference counterpart (the reference solves one instance at a time). */
+int mmpc_set_schedule_hint(mmpc_handle h, int on);
+
+/* Streams and threads: a handle owns device state that its launches read and write (parameter block, schedule hint,
+ * warm start).  Calls on one handle must come from one host thread at a time.  Launches may use different streams:
+ * a launch on another stream than the handle's previous one is ordered after it (event wait), and the entry points
+ * that change the parameter block or the warm start (mmpc_set_weights, mmpc_set_terminal_xy_equality,
+ * mmpc_set_warm_start, mmpc_reset, mmpc_get/set_u_latest) wait for the handle's launches in flight first. */
 
 /* bytes of LDS one problem instance occupies (one 64-lane workgroup) */
 int mmpc_lds_bytes(mmpc_handle h);

@@ -22,7 +22,7 @@ class MmpcConfig(C.Structure):
 
 EXPORTS = ["mmpc_create", "mmpc_destroy", "mmpc_set_weights", "mmpc_set_terminal_xy_equality", "mmpc_reset",
            "mmpc_solve_batch", "mmpc_solve_batch_device", "mmpc_get_u_latest", "mmpc_set_u_latest",
-           "mmpc_lds_bytes", "mmpc_problems_per_cu", "mmpc_set_warm_start", "mmpc_last_error", "mmpc_version", "mmpc_ik_batch", "mmpc_ik_batch_device"]
+           "mmpc_lds_bytes", "mmpc_problems_per_cu", "mmpc_set_warm_start", "mmpc_set_schedule_hint", "mmpc_last_error", "mmpc_version", "mmpc_ik_batch", "mmpc_ik_batch_device"]
 
 _lib = None
 _dp = C.POINTER(C.c_double)
@@ -57,6 +57,7 @@ def lib():
         L.mmpc_lds_bytes.argtypes = [C.c_void_p]
         L.mmpc_problems_per_cu.argtypes = [C.c_void_p]
         L.mmpc_set_warm_start.argtypes = [C.c_void_p, C.c_void_p, C.c_double]
+        L.mmpc_set_schedule_hint.argtypes = [C.c_void_p, C.c_int]
         L.mmpc_last_error.argtypes = [C.c_void_p]
         L.mmpc_last_error.restype = C.c_char_p
         L.mmpc_version.restype = C.c_char_p
@@ -165,12 +166,18 @@ class Engine:
     def set_warm_start(self, u_guess=None, mu_init=1.0):
         """mmpc_set_warm_start: `u_guess` (B,N,nu) cuda float64 tensor (kept alive by the engine) or None, initial barrier
         parameter `mu_init`.  Applies to the following solve_batch_device calls (their x_guess is the initial X)."""
-        if u_guess is not None and (not u_guess.is_cuda or not u_guess.is_contiguous()
-                                    or tuple(u_guess.shape[1:]) != (self.N, self.nu)):
-            raise ValueError("u_guess must be a contiguous cuda float64 tensor (B, N, nu)")
+        if u_guess is not None:
+            import torch
+            if (not u_guess.is_cuda or u_guess.dtype != torch.float64 or not u_guess.is_contiguous()
+                    or u_guess.device.index != self.device or tuple(u_guess.shape[1:]) != (self.N, self.nu)):
+                raise ValueError("u_guess must be a contiguous cuda:%d float64 tensor (B, N, nu)" % self.device)
         self._u_guess = u_guess
         self._chk(lib().mmpc_set_warm_start(self._h, C.c_void_p(u_guess.data_ptr()) if u_guess is not None else None,
                                             float(mu_init)), "mmpc_set_warm_start")
+
+    def set_schedule_hint(self, on):
+        """mmpc_set_schedule_hint: longest-first launch order from the previous launch's iteration counts (default on)."""
+        self._chk(lib().mmpc_set_schedule_hint(self._h, int(bool(on))), "mmpc_set_schedule_hint")
 
     def set_terminal_xy_equality(self, on):
         self._chk(lib().mmpc_set_terminal_xy_equality(self._h, int(bool(on))), "mmpc_set_terminal_xy_equality")
@@ -218,9 +225,17 @@ class Engine:
         for t_, shp in ((x_init, (B, nx)), (traj_ref, (B, N + 1, self.nref)), (u_ref, (B, N, nu)), (u_last, (B, N, nu))):
             if tuple(t_.shape) != shp or t_.dtype != torch.float64 or not t_.is_cuda or not t_.is_contiguous():
                 raise ValueError("device tensor must be contiguous cuda float64 of shape %s" % (shp,))
-        if tuple(obs.shape) != self.obs_shape(B) or obs.dtype != torch.float64 or not obs.is_contiguous():
+        if tuple(obs.shape) != self.obs_shape(B) or obs.dtype != torch.float64 or not obs.is_cuda or not obs.is_contiguous():
             raise ValueError("obs must be contiguous cuda float64 of shape %s" % (self.obs_shape(B),))
+        if x_guess is not None and (tuple(x_guess.shape) != (B, N + 1, nx) or x_guess.dtype != torch.float64
+                                    or not x_guess.is_cuda or not x_guess.is_contiguous()):
+            raise ValueError("x_guess must be contiguous cuda float64 of shape %s" % ((B, N + 1, nx),))
         dev = x_init.device
+        for t_ in (traj_ref, u_ref, u_last, obs, x_guess):
+            if t_ is not None and t_.device != dev:
+                raise ValueError("all device tensors of one call must live on %s" % dev)
+        if getattr(self, "_u_guess", None) is not None and self._u_guess.shape[0] < B:
+            raise ValueError("the u_guess set by set_warm_start holds %d instances, this call has %d" % (self._u_guess.shape[0], B))
         if out is None:
             out = dict(X=torch.empty((B, N + 1, nx), dtype=torch.float64, device=dev),
                        U=torch.empty((B, N, nu), dtype=torch.float64, device=dev),

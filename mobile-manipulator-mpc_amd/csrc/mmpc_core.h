@@ -56,7 +56,7 @@ __device__ __forceinline__ int mmpc_lane_id() { int l = (int)threadIdx.x; asm vo
 
 // Per-launch constants (device memory, read through the scalar cache).
 struct MmpcParams {
-    int N, M, obs_per_stage, max_iter, use_xguess, terminal_xy_eq;
+    int N, M, obs_per_stage, max_iter, use_xguess /* unused: the X guess is a launch argument (null = tile(x_init)) */, terminal_xy_eq;
     double dt, tol, mu_init, S;
     double Q2[81], P2[81];   // Q+Q^T, P+P^T (row-major, leading dimension NX)
     double RW2[25];          // (R+R^T)+(W+W^T), leading dimension NU
@@ -446,7 +446,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
         double x0 = io.x_init[j];
         if (KIND != 1) x0 = mmpc_max(mmpc_min(x0, P.xlim[1][j]), P.xlim[0][j]);  // :290-291
         if (i < NS * NREF) XREF[i] = io.traj_ref[i];
-        X[i] = (P.use_xguess && i >= NX) ? io.x_guess[i] : x0;  // :302 / mpc_base.py:200
+        X[i] = (io.x_guess && i >= NX) ? io.x_guess[i] : x0;  // :302 / mpc_base.py:200
         LAM[i] = 0.0;
     }
     for (int i = lane; i < N * NU; i += MMPC_WAVE) {

@@ -163,7 +163,8 @@ struct MmpcFastDims {
     // Riccati recursion on 16x16 MFMA tiles in homogeneous form: tile index t < NX is state t, t = NX the constant 1 (its
     // row and column carry the gradient), NX < t <= NV input t-NX-1.  K-blocks (4 rows each) that cover the (x, 1) rows /
     // the input rows, accumulator registers that hold the input rows NX+1..NV of the stage matrix
-    static constexpr int NKB = (NX + 1 + 3) / 4, NGB = (NU + 3) / 4, GR0 = (NX + 1) / 4, GR1 = NV / 4;
+    static constexpr int NKB = (NX + 1 + 3) / 4;
+    static constexpr int NPU = NU * (NU - 1) / 2;   // couplings between the inputs of a stage kept for the gain back-substitution
     static_assert(NV + 1 <= 16, "stage matrix over (x, 1, u) must fit one 16x16 tile");
 };
 
@@ -199,8 +200,8 @@ typedef double MmpcAcc __attribute__((ext_vector_type(4)));
 #endif
 
 struct MmpcFastLayout {
-    int XU, S, LAM, XUREF, ULAST, OBS, CST, CV, CD, TRG, HXX, QXU, HUXL, HUUL, HUX02, HUUD, SN, KK, KF, DXU, DS, DLAM,
-        GS, DUMP, RB, RDS, Q1V, FILT, MISC, total;
+    int XU, S, LAM, XUREF, ULAST, OBS, CST, CV, CD, TRG, HXX, QXU, HUXL, HUUL, HUX02, HUUD, SN, KK, KF, KU, DXU, DS, DLAM,
+        DUMP, RB, RDS, Q1V, FILT, MISC, total;
 };
 // constants block (CST) offsets
 #define MMPC_C_XLIM 0      // [2][9]
@@ -232,11 +233,10 @@ MMPC_HD MmpcFastLayout mmpc_fast_layout(int M, int obs_per_stage) {
     MMPC_CARVE(CST, MMPC_C_SIZE) MMPC_CARVE(CV, F::NS * MMPC_NCV) MMPC_CARVE(CD, F::NS * F::NX) MMPC_CARVE(TRG, F::NS * 8)
     MMPC_CARVE(HXX, F::NS * F::NXX) MMPC_CARVE(QXU, F::NS * F::NV) MMPC_CARVE(HUXL, F::NU * F::NX)
     MMPC_CARVE(HUUL, F::NUU) MMPC_CARVE(HUX02, F::NS) MMPC_CARVE(HUUD, F::NS * F::NU) MMPC_CARVE(SN, 16)
-    MMPC_CARVE(KK, N * F::NU * F::NX) MMPC_CARVE(KF, N * F::NU) MMPC_CARVE(DXU, F::NS * F::NV) MMPC_CARVE(DS, F::NS)
+    MMPC_CARVE(KK, N * F::NU * F::NX) MMPC_CARVE(KF, N * F::NU) MMPC_CARVE(KU, N * F::NPU) MMPC_CARVE(DXU, F::NS * F::NV) MMPC_CARVE(DS, F::NS)
     MMPC_CARVE(DLAM, F::NS * F::NX) MMPC_CARVE(RB, F::NS * F::NV) MMPC_CARVE(RDS, F::NS) MMPC_CARVE(Q1V, F::NV + 2) MMPC_CARVE(FILT, 2 * MMPC_FCAP)
-    // scratch of the backward pass lives, where it fits, in arrays that are dead while it runs: the 16x16 exchange tile in
-    // the search direction (written by the forward roll-out afterwards), the dump slots in the multiplier step (D1)
-    if (F::NS * F::NV >= 256) L.GS = L.DXU; else { MMPC_CARVE(GS, 256) }
+    // scratch of the backward pass lives, where it fits, in an array that is dead while it runs: the dump slots in the
+    // multiplier step (D1)
     if (F::NS * F::NX >= MMPC_WAVE) L.DUMP = L.DLAM; else { MMPC_CARVE(DUMP, MMPC_WAVE) } MMPC_CARVE(MISC, 8)
 #undef MMPC_CARVE
     L.total = o;
@@ -264,11 +264,10 @@ struct MmpcLaneState {
                                                      // stage-(N-1) extra term (Q1 elimination of s_{N-1}) or of the constant 0
     unsigned h_m;                                    // bit r: register r is part of [P p; p^T .]; bit 4+r: ... and is stored (lower triangle, p)
     unsigned p_o[4];                                 // where register r of [P_k | p_k] is stored: h_o[r] for the stored entries, a dump slot otherwise
-    unsigned g_o[F::NGB];                            // GS offset of this lane's entry of the G^T operand (or of the constant 0)
-    unsigned k_o, k_s;                               // where this lane stores its gain column: LDS offset | step between inputs << 16, and
-                                                     // the stage stride (lanes that own no column write to a dump slot: step = stride = 0)
+    unsigned kr_o[F::NU];                            // where this lane stores its entry of the normalised pivot row of input a: LDS
+                                                     // offset | stage stride << 16 (gain row / kf / coupling; a dump slot otherwise)
     MmpcAcc rP, rT, rM;                              // cost-to-go [P p; p^T .], its product T with the dynamics, stage matrix M
-    double rAB[F::NKB], opa[F::NGB], opb[F::NGB];    // MFMA operands
+    double rAB[F::NKB], opa, opb;                    // MFMA operands
     double nab[F::NKB], nhm[4];                      // next stage's dynamics rows and stage-matrix entries (loaded one stage ahead)
     // forward roll-out, row `lane` of [A B] (base.py:19-26): dx+[i] = dx[i] + sum_{j=2..5} C_j dx[j] + C_u du_a + c[i];
     // f_v: coefficient ids (into CV[k]) of C_2..C_5, f_x: id of C_u << 8 | (a + 1) << 16 (a: the input of this row, -1 none)
@@ -334,7 +333,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
     typedef MmpcFastDims<KIND, N> F;
     typedef MmpcTab<KIND> TB;
     constexpr int NX = F::NX, NU = F::NU, NV = F::NV, NXX = F::NXX, NUU = F::NUU, NSELF = F::NSELF, NS = F::NS;
-    constexpr int NPASS = F::NPASS, NPAIR = F::NPAIR, NKB = F::NKB, NGB = F::NGB, GR0 = F::GR0, GR1 = F::GR1;
+    constexpr int NPASS = F::NPASS, NPAIR = F::NPAIR, NKB = F::NKB, NPU = F::NPU;
     constexpr int M = MC;   // number of circle obstacles is a template parameter on this path
     // stages per trip of the Riccati / forward loops: unrolling saves the per-stage pointer bumps and register shuffles,
     // but costs registers - it only pays where the kernel does not spill (measured per instantiation)
@@ -346,7 +345,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
            *OBS = lds + L.OBS, *CST = lds + L.CST, *CV = lds + L.CV, *CD = lds + L.CD, *TRG = lds + L.TRG, *HXX = lds + L.HXX,
            *QXU = lds + L.QXU, *HUXL = lds + L.HUXL, *HUUL = lds + L.HUUL, *HUX02 = lds + L.HUX02,
            *HUUD = lds + L.HUUD, *SN = lds + L.SN, *KK = lds + L.KK, *KF = lds + L.KF, *DXU = lds + L.DXU,
-           *DS = lds + L.DS, *DLAM = lds + L.DLAM, *GS = lds + L.GS, *FILT = lds + L.FILT;
+           *DS = lds + L.DS, *DLAM = lds + L.DLAM, *KU = lds + L.KU, *FILT = lds + L.FILT;
     double *const RB = lds + L.RB, *const RDS = lds + L.RDS, *const Q1V = lds + L.Q1V;   // residual base r[k][v] and the s_k residual of the current point
     const double dt = P.dt, Sw = P.S, tol = P.tol;
 #ifdef MMPC_EMU
@@ -376,7 +375,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
         if (v < NX) {
             double x0 = io.x_init[v];
             if (KIND == 0) x0 = mmpc_max(mmpc_min(x0, P.xlim[1][v]), P.xlim[0][v]);
-            val = (P.use_xguess && k >= 1) ? io.x_guess[k * NX + v] : x0;
+            val = (io.x_guess && k >= 1) ? io.x_guess[k * NX + v] : x0;
             ref = io.traj_ref[k * NX + v];
         } else {
             val = k < N ? (io.u_guess ? io.u_guess[k * NU + v - NX] : io.u_last[k * NU + v - NX]) : 0.0;
@@ -458,14 +457,17 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
             ls.p_o[r] = ((ls.h_m >> (4 + r)) & 1u) ? ls.h_o[r] : (unsigned)(L.DUMP + lane);
         }
 #pragma unroll
-        for (int r = 0; r < NGB; r++) {
-            const int a = 4 * r + g;
-            ls.g_o[r] = (unsigned)((a < NU && j <= NX) ? L.GS + (NX + 1 + a) * 16 + j : L.CV);
-        }
-        {
-            const bool own = g == 0 && j <= NX;
-            ls.k_o = !own ? (unsigned)(L.DUMP + lane) : j < NX ? (unsigned)(L.KK + j) | ((unsigned)NX << 16) : (unsigned)L.KF | (1u << 16);
-            ls.k_s = !own ? 0u : j < NX ? (unsigned)(NU * NX) : (unsigned)NU;
+        for (int a = 0; a < NU; a++) {
+            // pivot row of input a = row NX+1+a of the stage matrix, held by lane group (NX+1+a) & 3: its entry in column j,
+            // divided by the pivot, is a gain-row entry (j < NX), the feed-forward (j = NX) or the coupling to a later input
+            const int ta = NX + 1 + a;
+            unsigned off = (unsigned)(L.DUMP + lane), stride = 0;
+            if (g == (ta & 3)) {
+                if (j < NX) { off = (unsigned)(L.KK + a * NX + j); stride = NU * NX; }
+                else if (j == NX) { off = (unsigned)(L.KF + a); stride = NU; }
+                else if (j > ta && j <= NV) { const int b2 = j - NX - 1; off = (unsigned)(L.KU + a * (2 * NU - a - 1) / 2 + (b2 - a - 1)); stride = NPU; }
+            }
+            ls.kr_o[a] = off | (stride << 16);
         }
         {
             unsigned fv = 0, fx = 0;
@@ -1033,93 +1035,40 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                 MMPC_MFMA(rM, ls.rAB[0], ls.rT[0])
                 MMPC_MFMA(rM, ls.rAB[1], ls.rT[1])
                 if (NKB > 2) MMPC_MFMA(rM, ls.rAB[NKB > 2 ? 2 : 0], ls.rT[NKB > 2 ? 2 : 0])
-                // the input rows [G Hh gu] go through LDS to the lanes that solve with them
-                LANES_BEGIN
-                auto &ls = MMPC_LS;
-#pragma unroll
-                for (int r = GR0; r <= GR1; r++) GS[((lane >> 4) + 4 * r) * 16 + (lane & 15)] = ls.rM[r];
-                LANES_END
                 MMPC_TS(6)
-                // R3/R4: L D L^T of Hh in registers (every lane), one right-hand side per column j = lane & 15
+                // operands of the next stage travel while this one eliminates its inputs
                 LANES_BEGIN
                 auto &ls = MMPC_LS;
-                {
-                    const int g = lane >> 4, j = lane & 15;
-                    double Hm[NUU], rhs[NU], gop[NGB];
+                if (k > 0) {
 #pragma unroll
-                    for (int a = 0; a < NU; a++) {
+                    for (int r = 0; r < NKB; r++) { const unsigned o = ls.ab_o[r]; ls.nab[r] = lds[(o & 0xffffu) + (k - 1) * (int)(o >> 16)]; }
 #pragma unroll
-                        for (int b = 0; b <= a; b++) Hm[a * (a + 1) / 2 + b] = GS[(NX + 1 + a) * 16 + NX + 1 + b];
-                        rhs[a] = GS[(NX + 1 + a) * 16 + j];
-                    }
-#pragma unroll
-                    for (int r = 0; r < NGB; r++) gop[r] = lds[ls.g_o[r]];
-                    // operands of the next stage travel while this one factorises
-                    if (k > 0) {
-#pragma unroll
-                        for (int r = 0; r < NKB; r++) { const unsigned o = ls.ab_o[r]; ls.nab[r] = lds[(o & 0xffffu) + (k - 1) * (int)(o >> 16)]; }
-#pragma unroll
-                        for (int r = 0; r < 4; r++) { const unsigned o = ls.h_o[r]; ls.nhm[r] = lds[(o & 0xffffu) + (k - 1) * (int)(o >> 16)]; }
-                    }
-                    mmpc_sched_fence();
-                    double Lm[NUU], V[NUU];   // unit lower factor (inverse pivots on its diagonal), V[i][q] = L[i][q] d_q
-                    bool ok = true;
-#pragma unroll
-                    for (int jj = 0; jj < NU; jj++) {
-                        double d = Hm[jj * (jj + 1) / 2 + jj];
-#pragma unroll
-                        for (int q = 0; q < jj; q++) d -= V[jj * (jj + 1) / 2 + q] * Lm[jj * (jj + 1) / 2 + q];
-                        ok = ok && d > 0.0;   // (NaN fails too; what a bad pivot produces is discarded by the caller)
-                        const double id = mmpc_rcp3(d);
-                        Lm[jj * (jj + 1) / 2 + jj] = id;
-#pragma unroll
-                        for (int i = jj + 1; i < NU; i++) {
-                            double v = Hm[i * (i + 1) / 2 + jj];
-#pragma unroll
-                            for (int q = 0; q < jj; q++) v -= V[i * (i + 1) / 2 + q] * Lm[jj * (jj + 1) / 2 + q];
-                            V[i * (i + 1) / 2 + jj] = v;
-                            Lm[i * (i + 1) / 2 + jj] = v * id;
-                        }
-                    }
-#pragma unroll
-                    for (int i = 1; i < NU; i++) {
-#pragma unroll
-                        for (int q = 0; q < i; q++) rhs[i] -= Lm[i * (i + 1) / 2 + q] * rhs[q];
-                    }
-#pragma unroll
-                    for (int i = 0; i < NU; i++) rhs[i] *= Lm[i * (i + 1) / 2 + i];
-#pragma unroll
-                    for (int i = NU - 2; i >= 0; i--) {
-#pragma unroll
-                        for (int q = i + 1; q < NU; q++) rhs[i] -= Lm[q * (q + 1) / 2 + i] * rhs[q];
-                    }
-                    // feedback gain column j (K = -Hh^-1 G; column NX: kf = -Hh^-1 gu), stored for the forward roll-out by the
-                    // lanes of group 0 (the others write the same value to a dump slot: no branch)
-                    const bool kcol = j <= NX;
-                    {
-                        double *dst = lds + (ls.k_o & 0xffffu) + k * (int)ls.k_s;
-                        const int step = (int)(ls.k_o >> 16);
-#pragma unroll
-                        for (int a = 0; a < NU; a++) dst[a * step] = -rhs[a];
-                    }
-                    // operands of P_k = F + G^T K: A[i][a] = G[a][i] (rows i < NX), B[a][j] = K[a][j] with a = 4r+g - every lane
-                    // has solved for the whole column j, so its B entries are already in its registers
-#pragma unroll
-                    for (int r = 0; r < NGB; r++) {
-                        double v = 0.0;
-#pragma unroll
-                        for (int a4 = 0; a4 < 4; a4++) if (4 * r + a4 < NU) v = g == a4 ? rhs[4 * r + a4] : v;
-                        ls.opb[r] = kcol ? -v : 0.0;
-                        ls.opa[r] = gop[r];
-                    }
-                    // a non-positive pivot: the pass stops at the next stage and is redone one rung down the Hessian ladder
-                    if (!ok) ric_bad = 1;
+                    for (int r = 0; r < 4; r++) { const unsigned o = ls.h_o[r]; ls.nhm[r] = lds[(o & 0xffffu) + (k - 1) * (int)(o >> 16)]; }
                 }
-                LANES_END
+                LANES_END_REG
+                // R3: the inputs are eliminated one at a time ON the tile (block L D L^T = Schur complement): for input a with
+                // pivot row c = M[NX+1+a][.] and pivot d = c[NX+1+a] > 0,  M <- M - c c^T / d  is one rank-one MFMA whose only
+                // non-zero K-slot is supplied by the lane group that already holds the row in its accumulator (row index mod
+                // 4 = lane group = K-slot: no lane movement, no LDS exchange).  What is left in rows / columns (x, 1) after
+                // the last input is [P_k p_k; p_k^T .].  The normalised rows c / d are kept: u_a = -(c/d) . (dx, 1, u_b>a),
+                // from which the gains are formed for all stages at once after the pass.
+#pragma unroll
+                for (int a = 0; a < NU; a++) {
+                    LANES_BEGIN
+                    auto &ls = MMPC_LS;
+                    const int ta = NX + 1 + a, ra = ta >> 2, ga = ta & 3;
+                    const double d = MMPC_LANE_GET(rM[ra], 16 * ga + ta);
+                    if (!(d > 0.0)) ric_bad = 1;   // (NaN fails too) the pass stops at the next stage and is redone one rung down
+                    const double c = ls.rM[ra], w = c * mmpc_rcp3(d);
+                    const bool own = (lane >> 4) == ga;
+                    ls.opa = own ? -w : 0.0;
+                    ls.opb = own ? c : 0.0;
+                    const unsigned o = ls.kr_o[a];   // (lanes that hold no entry of the row write to their dump slot: no branch)
+                    lds[(o & 0xffffu) + k * (int)(o >> 16)] = w;
+                    LANES_END_REG
+                    MMPC_MFMA(rM, ls.opa, ls.opb)
+                }
                 MMPC_TS(7)
-                // R5: [P_k p_k; p_k^T .] = [F gx; gx^T .] + [G gu]^T [K | kf]  (accumulates onto M; rows/columns > NX keep M's entries)
-                MMPC_MFMA(rM, ls.opa[0], ls.opb[0])
-                if (NGB > 1) MMPC_MFMA(rM, ls.opa[NGB > 1 ? 1 : 0], ls.opb[NGB > 1 ? 1 : 0])
                 LANES_BEGIN
                 auto &ls = MMPC_LS;
 #pragma unroll
@@ -1149,6 +1098,27 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
             fprintf(stderr, "riccati failed twice it %d\n", it);
 #endif
             status = 2; break; }
+        // ---- gains of all stages from the normalised pivot rows, by back-substitution over the inputs (the last eliminated
+        //      input depends on x only): K_a = -(w_a[x,1] + sum_{b>a} w_a[u_b] K_b), in place, one lane per (stage, column)
+        LANES_BEGIN
+        for (int i = lane; i < N * (NX + 1); i += MMPC_WAVE) {
+            const int k = i / (NX + 1), j = i % (NX + 1);
+            double kv[NU], cu[NPU > 0 ? NPU : 1];
+#pragma unroll
+            for (int a = 0; a < NU; a++) kv[a] = j < NX ? KK[(k * NU + a) * NX + j] : KF[k * NU + a];
+#pragma unroll
+            for (int q = 0; q < NPU; q++) cu[q] = KU[k * NPU + q];
+#pragma unroll
+            for (int a = NU - 1; a >= 0; a--) {
+                double v = kv[a];
+#pragma unroll
+                for (int b2 = a + 1; b2 < NU; b2++) v += cu[a * (2 * NU - a - 1) / 2 + (b2 - a - 1)] * kv[b2];
+                kv[a] = -v;
+            }
+#pragma unroll
+            for (int a = 0; a < NU; a++) { if (j < NX) KK[(k * NU + a) * NX + j] = kv[a]; else KF[k * NU + a] = kv[a]; }
+        }
+        LANES_END
         MMPC_TS(8)
         // ---- forward roll-out: lane i < NX carries dx_k[i] in a register; a stage broadcasts the NX values through scalar
         //      registers (v_readlane), forms the input step of its row and the next dx - no LDS round trip on the chain.

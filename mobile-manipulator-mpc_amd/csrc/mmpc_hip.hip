@@ -106,6 +106,32 @@ __global__ void mmpc_gather_u0(int B, int NU, int stride, const double *__restri
     if (i < B * NU) u0[i] = U[(size_t)(i / NU) * stride + (i % NU)];
 }
 
+// Warm-start bookkeeping of the host-pointer entry point.  The reference assigns u_latest / x_guess only after a
+// successful solve (mpc_wholebody_qref.py:329-330 come after the exception of :315): a failed instance keeps its
+// previous warm start.  warm[b] = 1 once instance b has a converged solution in its rows.
+__global__ void mmpc_keep_converged(int B, int nU, int nX, const int *__restrict__ status, const double *__restrict__ U,
+                                    const double *__restrict__ X, double *__restrict__ u_latest, double *__restrict__ x_guess,
+                                    int *__restrict__ warm) {
+    const int b = blockIdx.x;
+    if (b >= B || status[b] != MMPC_STATUS_CONVERGED) return;
+    for (int i = threadIdx.x; i < nU; i += blockDim.x) u_latest[(size_t)b * nU + i] = U[(size_t)b * nU + i];
+    for (int i = threadIdx.x; i < nX; i += blockDim.x) x_guess[(size_t)b * nX + i] = X[(size_t)b * nX + i];
+    if (threadIdx.x == 0) warm[b] = 1;
+}
+// X guess of the instances that have no converged solution yet = what a null guess means: tile(x_init), clipped to xlim
+// for the whole-body kinds (:290-291,:302; mpc_base.py:191-207 does not clip)
+__global__ void mmpc_cold_xguess(int B, int NS, int NX, int clip, const MmpcParams *__restrict__ P, const int *__restrict__ warm,
+                                 const double *__restrict__ x_init, double *__restrict__ x_guess) {
+    const int b = blockIdx.x;
+    if (b >= B || warm[b]) return;
+    for (int i = threadIdx.x; i < NS * NX; i += blockDim.x) {
+        const int j = i % NX;
+        double v = x_init[(size_t)b * NX + j];
+        if (clip) v = fmax(fmin(v, P->xlim[1][j]), P->xlim[0][j]);
+        x_guess[(size_t)b * NS * NX + i] = v;
+    }
+}
+
 struct mmpc_handle_s {
     mmpc_config cfg;
     MmpcParams hp;          // host copy
@@ -115,7 +141,14 @@ struct mmpc_handle_s {
     int fast_lds_bytes;
     int per_cu, fast_per_cu;   // resident workgroups (= problems) per CU the runtime reports for the two kernels
     int diag;               // weights are diagonal (required by the specialised kernel)
-    int warm;               // 1 once a solve has filled u_latest (x_guess)
+    // one stream at a time: launches of a handle share device state (params, schedule hint, warm start), so work on a
+    // new stream is ordered after the handle's previous launch through `ev` (recorded after every launch)
+    hipEvent_t ev;
+    hipStream_t last_stream;
+    int ev_valid;
+    int hint_on;            // longest-first schedule hint from the previous launch (mmpc_set_schedule_hint)
+    int no_lpt_env, force_generic_env;   // MMPC_NO_LPT / MMPC_FORCE_GENERIC, read once at create (diagnostics)
+    int *d_warm;            // per instance: 1 once a CONVERGED solve has filled its u_latest / x_guess rows
     // device-side state and staging (capacity max_batch)
     double *d_x_init, *d_traj, *d_uref, *d_obs, *d_ulatest, *d_xguess, *d_X, *d_U, *d_s, *d_cost, *d_err, *d_u0;
     int *d_status, *d_iters;
@@ -167,8 +200,10 @@ static void update_diag(mmpc_handle h) {
     h->diag = d;
 }
 
+// (waits for the handle's launches in flight - on whatever stream they were made - before the parameter block changes)
 static int upload_params(mmpc_handle h) {
     update_diag(h);
+    if (h->ev_valid) HIPCHK(h, hipEventSynchronize(h->ev));
     HIPCHK(h, hipMemcpy(h->dp, &h->hp, sizeof(MmpcParams), hipMemcpyHostToDevice));
     return MMPC_OK;
 }
@@ -266,8 +301,16 @@ extern "C" int mmpc_create(const mmpc_config *cfg, mmpc_handle *out) {
     HIPCHK(h, hipMalloc(&h->d_status, B * 4));
     HIPCHK(h, hipMalloc(&h->d_iters, B * 4));
     HIPCHK(h, hipMalloc(&h->d_order, B * 4));
+    HIPCHK(h, hipMalloc(&h->d_warm, B * 4));
     h->order_B = 0;
+    h->hint_on = 1;
+    h->no_lpt_env = getenv("MMPC_NO_LPT") != nullptr;
+    h->force_generic_env = getenv("MMPC_FORCE_GENERIC") != nullptr;
+    HIPCHK(h, hipEventCreateWithFlags(&h->ev, hipEventDisableTiming));
+    h->ev_valid = 0; h->last_stream = nullptr;
     HIPCHK(h, hipMemset(h->d_ulatest, 0, B * N * nu * 8));
+    HIPCHK(h, hipMemset(h->d_xguess, 0, B * (N + 1) * nx * 8));
+    HIPCHK(h, hipMemset(h->d_warm, 0, B * 4));
     int rc = upload_params(h);
     if (rc) return rc;
     h->err[0] = 0;
@@ -277,7 +320,10 @@ extern "C" int mmpc_create(const mmpc_config *cfg, mmpc_handle *out) {
 extern "C" int mmpc_destroy(mmpc_handle h) {
     if (!h) return MMPC_E_ARG;
     void *ptrs[] = {h->dp, h->d_x_init, h->d_traj, h->d_uref, h->d_obs, h->d_ulatest, h->d_xguess, h->d_X, h->d_U,
-                    h->d_s, h->d_cost, h->d_err, h->d_u0, h->d_status, h->d_iters, h->d_order};
+                    h->d_s, h->d_cost, h->d_err, h->d_u0, h->d_status, h->d_iters, h->d_order, h->d_warm};
+    (void)hipSetDevice(h->cfg.device);
+    if (h->ev_valid) (void)hipEventSynchronize(h->ev);
+    if (h->ev) (void)hipEventDestroy(h->ev);
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete h;
     return MMPC_OK;
@@ -311,8 +357,9 @@ extern "C" int mmpc_reset(mmpc_handle h) {
     if (!h) return MMPC_E_ARG;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const size_t n = (size_t)h->cfg.max_batch * h->cfg.N * h->nu * 8;
+    if (h->ev_valid) HIPCHK(h, hipEventSynchronize(h->ev));
     HIPCHK(h, hipMemset(h->d_ulatest, 0, n));
-    h->warm = 0;
+    HIPCHK(h, hipMemset(h->d_warm, 0, (size_t)h->cfg.max_batch * 4));
     h->order_B = 0;
     return MMPC_OK;
 }
@@ -320,14 +367,12 @@ extern "C" int mmpc_reset(mmpc_handle h) {
 static int launch(mmpc_handle h, int B, const double *x_init, const double *traj, const double *uref, const double *ulast,
                   const double *xguess, const double *obs, double *X, double *U, double *s, int *status, int *iters,
                   double *cost, double *err, hipStream_t st) {
-    // use_xguess is a launch-time property: keep the device params in sync
-    const int want = xguess ? 1 : 0;
-    if (h->hp.use_xguess != want) {
-        h->hp.use_xguess = want;
-        HIPCHK(h, hipMemcpyAsync(h->dp, &h->hp, sizeof(MmpcParams), hipMemcpyHostToDevice, st));
-    }
-    const bool use_fast = h->fast && h->diag && !h->hp.terminal_xy_eq && !getenv("MMPC_FORCE_GENERIC");
-    const int *order = (h->order_B == B && B <= h->cfg.max_batch && !getenv("MMPC_NO_LPT")) ? h->d_order : nullptr;
+    // (the X guess is a launch argument: null = tile(x_init); nothing in the device parameter block changes per launch)
+    // a launch on another stream than the previous one waits for it: both touch the handle's schedule hint
+    if (h->ev_valid && st != h->last_stream) HIPCHK(h, hipStreamWaitEvent(st, h->ev, 0));
+    const bool use_fast = h->fast && h->diag && !h->hp.terminal_xy_eq && !h->force_generic_env;
+    const bool lpt = h->hint_on && !h->no_lpt_env;
+    const int *order = (lpt && h->order_B == B && B <= h->cfg.max_batch) ? h->d_order : nullptr;
     if (use_fast) {
 #define MMPC_X(K, NN, MM, WW)                                                                                          \
         if (h->cfg.kind == K && h->cfg.N == NN && h->cfg.M == MM)                                                                          \
@@ -345,10 +390,19 @@ static int launch(mmpc_handle h, int B, const double *x_init, const double *traj
         hipLaunchKernelGGL(mmpc_solve_kernel<2>, dim3(B), dim3(MMPC_WAVE), h->lds_bytes, st, h->dp, B, x_init, traj, uref,
                            ulast, xguess, obs, X, U, s, status, iters, cost, err, order);
     HIPCHK(h, hipGetLastError());
-    if (B <= h->cfg.max_batch && B > 256 && !getenv("MMPC_NO_LPT")) {
+    if (lpt && B <= h->cfg.max_batch && B > 256) {
         hipLaunchKernelGGL(mmpc_lpt_order, dim3(1), dim3(1024), 0, st, B, iters, h->d_order);
         h->order_B = B;
     }
+    HIPCHK(h, hipEventRecord(h->ev, st));
+    h->ev_valid = 1; h->last_stream = st;
+    return MMPC_OK;
+}
+
+extern "C" int mmpc_set_schedule_hint(mmpc_handle h, int on) {
+    if (!h) return MMPC_E_ARG;
+    h->hint_on = on ? 1 : 0;
+    h->order_B = 0;
     return MMPC_OK;
 }
 
@@ -387,13 +441,19 @@ extern "C" int mmpc_solve_batch(mmpc_handle h, int B, const double *x_init, cons
     if (nobs) HIPCHK(h, hipMemcpyAsync(h->d_obs, obs, b * nobs * 8, hipMemcpyHostToDevice, st));
     // the base kind and the pose-reference kind warm-start X as well (mpc_base.py:194-201, mpc_wholebody.py:134-139); the
     // joint-reference whole-body controller never does (mpc_wholebody_qref.py:301-302)
-    const double *xg = (h->cfg.kind != MMPC_KIND_WHOLEBODY && h->warm) ? h->d_xguess : nullptr;
+    const double *xg = nullptr;
+    if (h->cfg.kind != MMPC_KIND_WHOLEBODY) {
+        if (h->ev_valid && st != h->last_stream) HIPCHK(h, hipStreamWaitEvent(st, h->ev, 0));
+        hipLaunchKernelGGL(mmpc_cold_xguess, dim3(B), dim3(64), 0, st, B, (int)N + 1, (int)nx, h->cfg.kind != MMPC_KIND_BASE ? 1 : 0,
+                           h->dp, h->d_warm, h->d_x_init, h->d_xguess);
+        xg = h->d_xguess;
+    }
     int rc = launch(h, B, h->d_x_init, h->d_traj, h->d_uref, h->d_ulatest, xg, h->d_obs, h->d_X, h->d_U, h->d_s,
                     h->d_status, h->d_iters, h->d_cost, h->d_err, st);
     if (rc) return rc;
-    // u_latest <- U*, x_guess <- X*  (:329-330)
-    HIPCHK(h, hipMemcpyAsync(h->d_ulatest, h->d_U, b * N * nu * 8, hipMemcpyDeviceToDevice, st));
-    HIPCHK(h, hipMemcpyAsync(h->d_xguess, h->d_X, b * (N + 1) * nx * 8, hipMemcpyDeviceToDevice, st));
+    // u_latest <- U*, x_guess <- X*  (:329-330), for the instances that converged
+    hipLaunchKernelGGL(mmpc_keep_converged, dim3(B), dim3(64), 0, st, B, (int)(N * nu), (int)((N + 1) * nx), h->d_status, h->d_U,
+                       h->d_X, h->d_ulatest, h->d_xguess, h->d_warm);
     hipLaunchKernelGGL(mmpc_gather_u0, dim3((B * (int)nu + 255) / 256), dim3(256), 0, st, B, (int)nu, (int)(N * nu), h->d_U, h->d_u0);
     HIPCHK(h, hipMemcpyAsync(out_u0, h->d_u0, b * nu * 8, hipMemcpyDeviceToHost, st));
     if (out_X) HIPCHK(h, hipMemcpyAsync(out_X, h->d_X, b * (N + 1) * nx * 8, hipMemcpyDeviceToHost, st));
@@ -402,20 +462,22 @@ extern "C" int mmpc_solve_batch(mmpc_handle h, int B, const double *x_init, cons
     if (out_status) HIPCHK(h, hipMemcpyAsync(out_status, h->d_status, b * 4, hipMemcpyDeviceToHost, st));
     if (out_iters) HIPCHK(h, hipMemcpyAsync(out_iters, h->d_iters, b * 4, hipMemcpyDeviceToHost, st));
     if (out_cost) HIPCHK(h, hipMemcpyAsync(out_cost, h->d_cost, b * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipEventRecord(h->ev, st));
     HIPCHK(h, hipStreamSynchronize(st));
-    h->warm = 1;
     return MMPC_OK;
 }
 
 extern "C" int mmpc_get_u_latest(mmpc_handle h, int B, double *u_latest) {
     if (!h || !u_latest || B < 1 || B > h->cfg.max_batch) return MMPC_E_ARG;
     HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (h->ev_valid) HIPCHK(h, hipEventSynchronize(h->ev));
     HIPCHK(h, hipMemcpy(u_latest, h->d_ulatest, (size_t)B * h->cfg.N * h->nu * 8, hipMemcpyDeviceToHost));
     return MMPC_OK;
 }
 extern "C" int mmpc_set_u_latest(mmpc_handle h, int B, const double *u_latest) {
     if (!h || !u_latest || B < 1 || B > h->cfg.max_batch) return MMPC_E_ARG;
     HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (h->ev_valid) HIPCHK(h, hipEventSynchronize(h->ev));
     HIPCHK(h, hipMemcpy(h->d_ulatest, u_latest, (size_t)B * h->cfg.N * h->nu * 8, hipMemcpyHostToDevice));
     return MMPC_OK;
 }

@@ -1,7 +1,16 @@
 #!/bin/bash
-# one GPU round: parity tests, bench line, phase stamps (run through gpurun from the repo root)
-mkdir -p gpurun_out; timeout -k 10 400 python -m pytest tests -m gpu -x -q > gpurun_out/gpu_tests.log 2>&1; tail -2 gpurun_out/gpu_tests.log
-timeout -k 10 300 python bench.py --steps 10 --warmup 3 > gpurun_out/bench_cycle.json 2> gpurun_out/bench_cycle.err
-python -c "
-import json; d=json.loads(open('gpurun_out/bench_cycle.json').read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['cpu_baseline']['max_abs_dX_vs_gpu'], d['solver'])"
-if [ -f mobile-manipulator-mpc_amd/csrc/libmmpc_stamp.so ]; then timeout -k 10 300 python tools/probe_stamps.py > gpurun_out/stamps_cycle.txt 2>&1; cat gpurun_out/stamps_cycle.txt; fi
+# one GPU round: parity tests, bench line (run through gpurun from the repo root).  Steps are chained with && so that
+# nothing is started on the GPU after a step that was killed or timed out.
+mkdir -p gpurun_out
+timeout -k 10 900 python -m pytest tests -m gpu -x -q -s > gpurun_out/gpu_tests.log 2>&1; rc=$?
+tail -5 gpurun_out/gpu_tests.log
+[ $rc -eq 0 ] || { echo "gpu tests rc=$rc"; exit $rc; }
+timeout -k 10 300 python bench.py --steps 20 --warmup 3 > gpurun_out/bench_cycle.json 2> gpurun_out/bench_cycle.err || { tail -5 gpurun_out/bench_cycle.err; exit 1; }
+python - <<'PY'
+import json
+d = json.loads(open('gpurun_out/bench_cycle.json').read().strip().splitlines()[-1])
+print("value %.0f ms/step %.3f median kernel %.3f | hinted %.3f ms | two streams %.0f | cpu %.0f dX %.2e (>1e-6: %d) | %s" % (
+    d['value'], d['ms_per_step'], d['median_kernel_ms'], d['schedule_hint']['hinted_ms'], d['two_streams']['value'],
+    d['cpu_baseline']['value'], d['cpu_baseline']['max_abs_dX_vs_gpu'], d['cpu_baseline']['n_dX_above_1e-6'], d['solver']))
+print("roofline frac %.4f" % d['roofline']['frac'])
+PY
