@@ -125,11 +125,13 @@ int mmpc_ik_batch_device(int device, int B, const double *d_q0, const double *d_
  * in fewer than half the iterations.  mmpc_set_warm_start(h, NULL, 1.0) restores the default. */
 int mmpc_set_warm_start(mmpc_handle h, const double *d_u_guess, double mu_init);
 
-/* Launch order of the instances of a batch.  on (default): the workgroups of a launch are started longest-first by
- * the iteration counts of the handle's previous launch of the same B (a receding-horizon loop solves the same robots
- * every tick, so consecutive ticks have correlated difficulty); off: batch order.  Results never depend on it.
- * No reference counterpart (the reference solves one instance at a time). */
-int mmpc_set_schedule_hint(mmpc_handle h, int on);
+/* Launch order of the workgroups (= instances) of a batch.  A batch takes as long as its last wave, so the instances
+ * that need the most interior-point iterations should start first.  mode 1 (default): longest-first by the iteration counts
+ * of the handle's previous launch of the same B when there is one (a receding-horizon loop solves the same robots every
+ * tick), else by an a-priori difficulty key computed from this batch's own data (how deep the reference path cuts into an
+ * inflated obstacle disc); mode 2: always the a-priori key (no memory of earlier launches); mode 0: batch order.
+ * Results never depend on the order.  No reference counterpart (the reference solves one instance at a time). */
+int mmpc_set_schedule_hint(mmpc_handle h, int mode);
 
 /* Streams and threads: a handle owns device state that its launches read and write (parameter block, schedule hint,
  * warm start).  Calls on one handle must come from one host thread at a time.  Launches may use different streams:

@@ -10,6 +10,7 @@ LIB_PATH = os.environ.get("MMPC_LIB") or os.path.join(_HERE, "csrc", "libmmpc.so
 
 KIND_WHOLEBODY, KIND_BASE, KIND_WHOLEBODY_POSE = 0, 1, 2
 STATUS_CONVERGED, STATUS_MAXITER, STATUS_NUMERIC = 0, 1, 2
+STATUS_Q8_REFUSED = 8      # host-side only (controllers/_q8.py): converged, but an as-written extra half-space row is violated
 
 
 class MmpcConfig(C.Structure):
@@ -175,9 +176,11 @@ class Engine:
         self._chk(lib().mmpc_set_warm_start(self._h, C.c_void_p(u_guess.data_ptr()) if u_guess is not None else None,
                                             float(mu_init)), "mmpc_set_warm_start")
 
-    def set_schedule_hint(self, on):
-        """mmpc_set_schedule_hint: longest-first launch order from the previous launch's iteration counts (default on)."""
-        self._chk(lib().mmpc_set_schedule_hint(self._h, int(bool(on))), "mmpc_set_schedule_hint")
+    def set_schedule_hint(self, mode):
+        """mmpc_set_schedule_hint: launch order of a batch's workgroups - 0/False batch order, 1/True (default) longest-first
+        by the previous launch's iteration counts when there is one, else by the a-priori difficulty key of the batch's own
+        data, 2 always the a-priori key."""
+        self._chk(lib().mmpc_set_schedule_hint(self._h, int(mode)), "mmpc_set_schedule_hint")
 
     def set_terminal_xy_equality(self, on):
         self._chk(lib().mmpc_set_terminal_xy_equality(self._h, int(bool(on))), "mmpc_set_terminal_xy_equality")

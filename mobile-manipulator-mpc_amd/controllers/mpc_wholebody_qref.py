@@ -2,6 +2,7 @@ import numpy as np
 
 from .. import _capi
 from ._facade import OptiFacade, Sym
+from . import _q8
 
 PI, INF = np.pi, np.inf
 
@@ -39,15 +40,18 @@ class MPCWholeBody:
         self.obstacle_manipulation_list = obstacle_manipulation_list
         self.endpoint_self_collision_radius = 0.05   # mpc_wholebody_qref.py:43
         self.obstacle_expand_dist = 0.03             # :44
-        # half-space ("manipulation") obstacles, mpc_wholebody_qref.py:57-89: one row per (stage, arm sample point),
-        # -max_j n_j.((p_j - 0.03 n_j) - P_i) <= s_k.  For L >= 2 the reference as written emits L rows per point that
-        # read stale / free `constr` entries; that behaviour is NOT reproduced, so the caller has to
-        # acknowledge the divergence with faithful_convex=False.  L = 1 is exact.
+        # half-space ("manipulation") obstacles, mpc_wholebody_qref.py:57-89.  The kernels carry one row per (stage, arm
+        # sample point): -max_j n_j.((p_j - 0.03 n_j) - P_i) <= s_k - for L >= 2 that is the LAST of the L rows the reference
+        # as written emits per point; the other L-1 read stale / free `constr` entries (see _q8.py).
+        # Default (faithful_convex None / True): the NLP as written - after every solve the extra rows are evaluated on the
+        # host; a solution that satisfies them all is a KKT point of the as-written NLP and is returned, one that does not
+        # is refused (RuntimeError; batched calls mark it _capi.STATUS_Q8_REFUSED).  faithful_convex=False: the intended rows only,
+        # no check.  L = 1 has no extra rows.
         hs = [np.concatenate([np.asarray(pt, float).reshape(3), np.asarray(nrm, float).reshape(3)])
               for pt, nrm in obstacle_manipulation_list]
-        if len(hs) >= 2 and faithful_convex is not False:
-            raise NotImplementedError("L >= 2 half-space obstacles: the as-written stale-`constr` coupling (quirk Q8) is "
-                                      "not reproduced; pass faithful_convex=False to use the intended max-over-planes rows")
+        self._hs = np.array(hs, float).reshape(-1, 6)
+        self._q8_check = len(hs) >= 2 and faithful_convex is not False
+        self.q8_margin = None      # largest value of an as-written extra row at the last solve (<= 0: all satisfied)
         if abs(self.base_radius - 0.4) > 0 or abs(self.endpoint_self_collision_radius - 0.05) > 0:
             raise ValueError("the kernels bake base_radius 0.4 / self-collision radius 0.05 (base.py:15, :43)")
         self._M = len(obstacle_list) if n_obstacles is None else int(n_obstacles)
@@ -105,6 +109,12 @@ class MPCWholeBody:
         if r["status"][0] != 0:
             # the reference dies here too (RuntimeError from opti.solve(), then UnboundLocalError, :314-329)
             raise RuntimeError("MPC solve failed: status %d after %d iterations" % (r["status"][0], r["iters"][0]))
+        if self._q8_check:
+            self._apply_q8_check(r)
+            if r["status"][0] != 0:
+                raise RuntimeError("an as-written half-space row (quirk Q8: stale `constr` entry of the previous stage) is violated "
+                                   "by %.3g at the solution of the intended rows; the coupled rows are not implemented - "
+                                   "faithful_convex=False solves the intended NLP" % self.q8_margin)
         print("cost: ", r["cost"][0])                                                                   # :317
         self.x_guess = r["X"][0]
         self.u_latest = r["U"][0]
@@ -119,4 +129,17 @@ class MPCWholeBody:
         B = x_init.shape[0]
         if obs is None:
             obs = self._obs_array(B)
-        return self._engine.solve_batch(x_init, traj_ref, u_ref, obs)
+        r = self._engine.solve_batch(x_init, traj_ref, u_ref, obs)
+        if self._q8_check:
+            self._apply_q8_check(r)
+        return r
+
+    Q8_TOL = 1e-8      # feasibility tolerance of the extra rows (the solver's own: scaled KKT error <= 1e-8)
+
+    def _apply_q8_check(self, r):
+        """Marks converged instances whose solution violates an as-written extra row with _capi.STATUS_Q8_REFUSED."""
+        rows = _q8.as_written_extra_rows(r["X"], r["s"], self._hs)                 # (B, N, 6, L-1)
+        worst = rows.reshape(rows.shape[0], -1).max(axis=1)
+        self.q8_margin = float(worst.max())
+        r["q8_margin"] = worst
+        r["status"] = np.where((r["status"] == 0) & (worst > self.Q8_TOL), _capi.STATUS_Q8_REFUSED, r["status"]).astype(np.int32)

@@ -27,6 +27,7 @@
 // value a field of the lane state holds in lane j (the emulator runs the lanes of a phase one after another: a field that
 // is read across lanes and rewritten in the same phase is double-buffered by the parity of the stage)
 #define MMPC_LANE_GET(field, j) (ls_all[j].field)
+#define MMPC_LANE_XOR16(field) (ls_all[lane ^ 16].field)
 #define MMPC_FW_SLOTS 2
 #define MMPC_FW_SLOT(k) ((k) & 1)
 #define LANES_END_REG }
@@ -34,6 +35,7 @@
 #define MMPC_LS ls_one
 #define MMPC_WR(i) wr_one[i]
 #define MMPC_LANE_GET(field, j) mmpc_readlane_f64(ls_one.field, j)
+#define MMPC_LANE_XOR16(field) mmpc_xor16_f64(ls_one.field, lane)
 #define MMPC_FW_SLOTS 1
 #define MMPC_FW_SLOT(k) 0
 #define LANES_END_REG }      // end of a phase whose results travel in registers only: no LDS ordering to enforce
@@ -233,10 +235,12 @@ MMPC_HD MmpcFastLayout mmpc_fast_layout(int M, int obs_per_stage) {
     MMPC_CARVE(CST, MMPC_C_SIZE) MMPC_CARVE(CV, F::NS * MMPC_NCV) MMPC_CARVE(CD, F::NS * F::NX) MMPC_CARVE(TRG, F::NS * 8)
     MMPC_CARVE(HXX, F::NS * F::NXX) MMPC_CARVE(QXU, F::NS * F::NV) MMPC_CARVE(HUXL, F::NU * F::NX)
     MMPC_CARVE(HUUL, F::NUU) MMPC_CARVE(HUX02, F::NS) MMPC_CARVE(HUUD, F::NS * F::NU) MMPC_CARVE(SN, 16)
-    MMPC_CARVE(KK, N * F::NU * F::NX) MMPC_CARVE(KF, N * F::NU) MMPC_CARVE(KU, N * F::NPU) MMPC_CARVE(DXU, F::NS * F::NV) MMPC_CARVE(DS, F::NS)
+    MMPC_CARVE(KK, N * F::NU * F::NX) MMPC_CARVE(KF, N * F::NU) MMPC_CARVE(DXU, F::NS * F::NV) MMPC_CARVE(DS, F::NS)
     MMPC_CARVE(DLAM, F::NS * F::NX) MMPC_CARVE(RB, F::NS * F::NV) MMPC_CARVE(RDS, F::NS) MMPC_CARVE(Q1V, F::NV + 2) MMPC_CARVE(FILT, 2 * MMPC_FCAP)
-    // scratch of the backward pass lives, where it fits, in an array that is dead while it runs: the dump slots in the
+    // scratch of the backward pass lives, where it fits, in arrays that are dead while it runs: the couplings between the
+    // inputs of a stage in the search direction (written by the forward roll-out afterwards), the dump slots in the
     // multiplier step (D1)
+    if (F::NS * F::NV >= N * F::NPU) L.KU = L.DXU; else { MMPC_CARVE(KU, N * F::NPU) }
     if (F::NS * F::NX >= MMPC_WAVE) L.DUMP = L.DLAM; else { MMPC_CARVE(DUMP, MMPC_WAVE) } MMPC_CARVE(MISC, 8)
 #undef MMPC_CARVE
     L.total = o;
@@ -280,6 +284,15 @@ struct MmpcLaneState {
 MMPC_DEV double mmpc_readlane_f64(double v, int j) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), j), hi = __builtin_amdgcn_readlane(__double2hiint(v), j);
     return __hiloint2double(hi, lo);
+}
+// value of lane (l ^ 16): the 16-lane rows 0 <-> 1 and 2 <-> 3 trade places (v_permlane16_swap_b32 x 2, gfx950; with both
+// operands equal it returns {even rows doubled, odd rows doubled})
+MMPC_DEV double mmpc_xor16_f64(double v, int lane) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    const bool odd = (lane >> 4) & 1;
+    return __hiloint2double(odd ? b[0] : b[1], odd ? a[0] : a[1]);
 }
 MMPC_DEV double mmpc_wave_sum(double v) {
 #pragma unroll
@@ -1046,25 +1059,48 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                     for (int r = 0; r < 4; r++) { const unsigned o = ls.h_o[r]; ls.nhm[r] = lds[(o & 0xffffu) + (k - 1) * (int)(o >> 16)]; }
                 }
                 LANES_END_REG
-                // R3: the inputs are eliminated one at a time ON the tile (block L D L^T = Schur complement): for input a with
-                // pivot row c = M[NX+1+a][.] and pivot d = c[NX+1+a] > 0,  M <- M - c c^T / d  is one rank-one MFMA whose only
-                // non-zero K-slot is supplied by the lane group that already holds the row in its accumulator (row index mod
-                // 4 = lane group = K-slot: no lane movement, no LDS exchange).  What is left in rows / columns (x, 1) after
-                // the last input is [P_k p_k; p_k^T .].  The normalised rows c / d are kept: u_a = -(c/d) . (dx, 1, u_b>a),
-                // from which the gains are formed for all stages at once after the pass.
+                // R3: the inputs are eliminated ON the tile (block L D L^T = Schur complement).  For input a with pivot row
+                // c = M[NX+1+a][.] and pivot d = c[NX+1+a] > 0,  M <- M - c c^T / d  is one rank-one MFMA whose only non-zero
+                // K-slot is supplied by the lane group that already holds the row in its accumulator (row index mod 4 = lane
+                // group = K-slot: no LDS exchange).  Two inputs whose rows sit in neighbouring lane groups of the same
+                // accumulator register go together as a 2x2 block pivot D (one reciprocal, one MFMA: the serial chain
+                // accumulator -> pivot -> reciprocal -> MFMA is what a stage costs): M <- M - [c0 c1] D^-1 [c0 c1]^T, each
+                // group fetching its partner's row entry from lane ^ 16.  What is left in rows / columns (x, 1) after the
+                // last input is [P_k p_k; p_k^T .].  The normalised rows W = D^-1 [c0 c1]^T are kept: u_a = -W_a . (dx, 1,
+                // u_b>a), from which the gains are formed for all stages at once after the pass.
+                constexpr bool PAIRS = ((NX + 1) & 1) == 0;               // first input row even -> rows (2q, 2q+1) share a register
+                constexpr int NLEG = PAIRS ? (NU + 1) / 2 : NU;
 #pragma unroll
-                for (int a = 0; a < NU; a++) {
+                for (int leg = 0; leg < NLEG; leg++) {
                     LANES_BEGIN
                     auto &ls = MMPC_LS;
-                    const int ta = NX + 1 + a, ra = ta >> 2, ga = ta & 3;
-                    const double d = MMPC_LANE_GET(rM[ra], 16 * ga + ta);
-                    if (!(d > 0.0)) ric_bad = 1;   // (NaN fails too) the pass stops at the next stage and is redone one rung down
-                    const double c = ls.rM[ra], w = c * mmpc_rcp3(d);
-                    const bool own = (lane >> 4) == ga;
+                    const int a0 = PAIRS ? 2 * leg : leg;
+                    const bool pair = PAIRS && a0 + 1 < NU;
+                    const int ta = NX + 1 + a0, ra = ta >> 2, ga = ta & 3, g = lane >> 4;
+                    const double c = ls.rM[ra];
+                    double w;
+                    bool own;
+                    unsigned o;
+                    if (pair) {
+                        const double d00 = MMPC_LANE_GET(rM[ra], 16 * ga + ta), d01 = MMPC_LANE_GET(rM[ra], 16 * ga + ta + 1),
+                                     d11 = MMPC_LANE_GET(rM[ra], 16 * (ga + 1) + ta + 1);
+                        const double det = fma(d00, d11, -d01 * d01);
+                        if (!(d00 > 0.0 && det > 0.0)) ric_bad = 1;   // (NaN fails too) the pass stops at the next stage, redone one rung down
+                        const double idet = mmpc_rcp3(det), co = MMPC_LANE_XOR16(rM[ra]);
+                        const bool in1 = g == ga + 1;
+                        own = g == ga || in1;
+                        w = fma((in1 ? d00 : d11) * idet, c, -(d01 * idet) * co);
+                        o = in1 ? ls.kr_o[a0 + 1 < NU ? a0 + 1 : a0] : ls.kr_o[a0];
+                    } else {
+                        const double d = MMPC_LANE_GET(rM[ra], 16 * ga + ta);
+                        if (!(d > 0.0)) ric_bad = 1;
+                        own = g == ga;
+                        w = c * mmpc_rcp3(d);
+                        o = ls.kr_o[a0];
+                    }
                     ls.opa = own ? -w : 0.0;
                     ls.opb = own ? c : 0.0;
-                    const unsigned o = ls.kr_o[a];   // (lanes that hold no entry of the row write to their dump slot: no branch)
-                    lds[(o & 0xffffu) + k * (int)(o >> 16)] = w;
+                    lds[(o & 0xffffu) + k * (int)(o >> 16)] = w;   // (lanes that hold no entry of the row write to their dump slot: no branch)
                     LANES_END_REG
                     MMPC_MFMA(rM, ls.opa, ls.opb)
                 }

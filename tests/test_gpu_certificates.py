@@ -8,7 +8,8 @@ no solve() vectors, so the HIP outputs are checked against
        moving-obstacle, terminal-equality and half-space shapes;
   (ii) committed solutions of an independent active-set SQP (tests/golden/slsqp_solutions.npz): 1e-4 on X, 5e-4 on U,
        1e-6 relative on the cost for the 13 fixtures where SLSQP ends at the same minimiser;
-  (iii) the CPU oracle on ALL 8192 instances of the bench batch, with the tolerance that is actually met.
+  (iii) the CPU oracle on ALL 8192 instances of the bench batch, with the tolerance that is actually met (2e-5; 1e-6 for
+       all but one instance - see the test).
 Everything goes through the C ABI (mmpc_amd._capi)."""
 import numpy as np
 import pytest
@@ -63,12 +64,15 @@ def test_bench_batch_passes_ipopt_termination_test_incl_tail(mm):
 
 
 def test_full_bench_batch_against_cpu_oracle(mm):
-    """All 8192 instances, GPU vs the scalar C oracle (same algorithm, different libm / summation order / MFMA
-    factorisation).  Both stop at the first iterate with scaled KKT error <= 1e-8, and that iterate is not the same point
-    to the last digit: where a row is weakly active (multiplier ~ slack ~ 1e-4.5 at mu = 1e-9) two iterates that both pass
-    the test differ by up to a few 1e-6 in the variables that row touches, at equal cost (1e-9 relative).  The tolerance
-    below is what is met over the whole batch; instances beyond 1e-6 are listed and must be certified KKT points with the
-    oracle's cost."""
+    """All 8192 instances, GPU vs the scalar C oracle (same algorithm; different libm, summation order, and the Riccati
+    factorisation runs on MFMA tiles).  Both stop at the first iterate whose scaled KKT error is <= 1e-8.  That test pins
+    the minimiser only as far as the problem's curvature allows: the yaw-acceleration input carries R = 0.1 and no rate
+    term (mpc_wholebody_qref.py:14-15), and the oracle ITSELF moves by 2.9e-6 (instance 6981) to 2.2e-5 (instance 2) in U
+    when its tolerance is tightened from 1e-8 to 1e-11 (cost unchanged to 1e-10).  Measured on this batch: 8181 of 8192
+    instances take the same number of iterations and agree to ~1e-11; ONE instance (6981: 33 iterations on the CPU, one
+    more or less on the GPU) differs by 1.2e-6 in X / 9.8e-6 in U, one more by > 1e-7.  The assertion states that:
+    <= 2e-5 everywhere, <= 1e-6 for all but at most 4 instances, equal cost (1e-9), and every instance above 1e-6 must
+    pass the certificate of the reference NLP on its GPU output."""
     B, N, M = 8192, 20, 5
     d = synth.make_batch(B)
     par, xi, r = _gpu_batch(mm, d, N, M)
@@ -76,23 +80,18 @@ def test_full_bench_batch_against_cpu_oracle(mm):
     assert (r["status"] == 0).all() and (o["status"] == 0).all()
     dX = np.abs(r["X"] - o["X"]).reshape(B, -1).max(1); dU = np.abs(r["U"] - o["U"]).reshape(B, -1).max(1)
     dev = np.maximum(dX, dU)
-    same_cost = np.abs(r["cost"] / o["cost"] - 1) < 1e-8
-    print("full batch: max |dX| %.3e max |dU| %.3e; > 1e-6: %s; > 1e-7: %d; equal iteration counts %.4f; other minimum: %s"
+    print("full batch: max |dX| %.3e max |dU| %.3e; > 1e-6: %s; > 1e-7: %d; equal iteration counts %.4f; max cost rel %.2e"
           % (dX.max(), dU.max(), np.nonzero(dev > 1e-6)[0].tolist(), int((dev > 1e-7).sum()), (r["iters"] == o["iters"]).mean(),
-             np.nonzero(~same_cost)[0].tolist()))
-    assert (r["iters"] == o["iters"]).mean() > 0.97
-    # instances that ended in another local minimum than the oracle (a pivot test that rounding decides the other way):
-    # rare, and each must be a certified KKT point whose cost is not worse than the oracle's by more than 1 %
-    other = np.nonzero(~same_cost)[0]
-    assert len(other) <= 4
-    assert dev[same_cost].max() < 5e-6
-    loose = np.nonzero((dev > 1e-6) | ~same_cost)[0]
-    assert len(loose) <= 16
+             np.abs(r["cost"] / o["cost"] - 1).max()))
+    assert (r["iters"] == o["iters"]).mean() > 0.99
+    assert np.abs(r["cost"] / o["cost"] - 1).max() < 1e-9          # nobody ends in another local minimum
+    assert dev.max() < 2e-5
+    loose = np.nonzero(dev > 1e-6)[0]
+    assert len(loose) <= 4
     ul = np.zeros((N, 5))
     cs = certify([(nlp.Problem(par, xi[b], d["traj_ref"][b], d["u_ref"][b], ul, d["obs"][b]), r["X"][b], r["U"][b], r["s"][b]) for b in loose])
     for b, c in zip(loose, cs):
         assert c["E0"] <= CERT_TOL, (int(b), c)
-        assert r["cost"][b] <= o["cost"][b] * (1 + (1e-8 if same_cost[b] else 1e-2)), int(b)
 
 
 def test_c2_base_batch_1024(mm):
@@ -267,10 +266,12 @@ def test_failed_instances_keep_their_warm_start(mm):
     successful solve, mpc_wholebody_qref.py:329-330), and a larger batch after a smaller one starts its new rows cold."""
     B, N, M = 32, 15, 3
     d = synth.make_batch(B, N=N, M=M, kind="base", config_id=2)
-    ctrl = mm.MPCBase(mm.Base(0.1), [], N=N, max_batch=B, n_obstacles=M, max_iter=8)    # nobody converges in 8 iterations
+    ctrl = mm.MPCBase(mm.Base(0.1), [], N=N, max_batch=B, n_obstacles=M, max_iter=8)    # about half converge in 8 iterations
     r = ctrl.solve_batch(d["x_init"], d["traj_ref"], d["u_ref"], d["obs"])
-    assert (r["status"] == 1).all()
-    assert np.abs(ctrl._engine.get_u_latest(B)).max() == 0.0
+    conv = r["status"] == 0
+    assert conv.any() and (r["status"][~conv] == 1).all() and (~conv).sum() >= 4
+    ul = ctrl._engine.get_u_latest(B)
+    assert np.abs(ul[~conv]).max() == 0.0 and np.array_equal(ul[conv], r["U"][conv])
     full = mm.MPCBase(mm.Base(0.1), [], N=N, max_batch=B, n_obstacles=M)
     r8 = full.solve_batch(d["x_init"][:8], d["traj_ref"][:8], d["u_ref"][:8], d["obs"][:8])
     assert (r8["status"] == 0).all()
@@ -306,7 +307,8 @@ def test_launches_on_two_streams_are_ordered(mm):
             outs[i & 1] = eng.solve_batch_device(xi, tr, ur, ul, ob, out=outs[i & 1])
     torch.cuda.synchronize()
     assert torch.equal(outs[0]["X"], X0) and torch.equal(outs[1]["X"], X0)
-    eng.set_schedule_hint(False)
-    r = eng.solve_batch_device(xi, tr, ur, ul, ob)
-    torch.cuda.synchronize()
-    assert torch.equal(r["X"], X0)
+    for mode in (0, 2):       # batch order; a-priori difficulty key of the batch's own data
+        eng.set_schedule_hint(mode)
+        r = eng.solve_batch_device(xi, tr, ur, ul, ob)
+        torch.cuda.synchronize()
+        assert torch.equal(r["X"], X0) and torch.equal(r["iters"], ref["iters"])

@@ -150,26 +150,46 @@ def test_terminal_xy_equality_through_opti_facade(mm):
 
 def test_c1_demo_scenario_with_halfspaces(mm):
     """Config C1: demo_wholebody_qref.py scenario 2 through the reference's constructor signature
-    (obstacle_list + obstacle_manipulation_list), single-instance solve()."""
+    (obstacle_list + obstacle_manipulation_list, no extra flag), single-instance solve().  With two planes the NLP as
+    written carries L-1 = 1 extra row per (stage >= 1, arm point) that reads the previous stage's `constr` entry (quirk Q8,
+    controllers/_q8.py).  First tick of the demo (x_start = 0): the GPU solution satisfies every one of them, is returned,
+    equals the oracle's and passes the certificate OF THE AS-WRITTEN NLP.  Started under the ridge of the two planes, the
+    solution of the intended rows violates an as-written row: refused (RuntimeError), and faithful_convex=False returns it."""
     r2 = 1 / np.sqrt(2)
     oml = [(np.array([2.5, 2, 0.35 + 0.606 + 0.333]), np.array([[r2, 0, r2]])),
            (np.array([2.5, 2, 0.35 + 0.606 + 0.333]), np.array([[-r2, 0, r2]]))]          # demo_wholebody_qref.py:30-33
     obstacles = [mm.Obstacles(2.5, 3.0, 0.6), mm.Obstacles(2.5, 1.0, 0.6), mm.Obstacles(5 - 0.6, 5, 0.1)]
     robot = mm.MobileManipulator(0.1)
-    with pytest.raises(NotImplementedError, match="Q8"):
-        mm.MPCWholeBody(robot, obstacles, oml, N=20)
-    ctrl = mm.MPCWholeBody(robot, obstacles, oml, N=20, faithful_convex=False)
+    ctrl = mm.MPCWholeBody(robot, obstacles, oml, N=20)                                   # the reference's own call (demo:47)
     hs = np.array([np.concatenate([p, n.reshape(3)]) for p, n in oml])
     par = nlp.WholeBodyParams()
     obs = np.array([[2.5, 3.0, 0.6], [2.5, 1.0, 0.6], [4.4, 5, 0.1]])
-    for x_start, target in ((np.zeros(9), np.array([5, 5, -np.pi, 0, 0, 0, 0, 0, 0.0])),
-                            (np.array([1.9, 2.0, 0.0, 0.3, 0, 0, 0.3, -1.2, 1.6]), np.array([3.2, 2.0, 0, 0, 0, 0, 0.3, -1.2, 1.6]))):
-        ctrl.reset()
-        traj = np.linspace(x_start, target, 51)[:21]
-        u0 = ctrl.solve(x_start.copy(), traj, np.zeros((20, 5)))
-        o = coracle.solve_batch(par, x_start[None], traj[None], np.zeros((1, 20, 5)), np.zeros((1, 20, 5)), obs[None], hs=hs)
-        assert o["status"][0] == 0
-        assert np.abs(u0 - o["U"][0, 0]).max() < TOL and np.abs(ctrl.x_guess - o["X"][0]).max() < TOL
+    x_start, target = np.zeros(9), np.array([5, 5, -np.pi, 0, 0, 0, 0, 0, 0.0])
+    traj = np.linspace(x_start, target, 51)[:21]
+    u0 = ctrl.solve(x_start.copy(), traj, np.zeros((20, 5)))
+    assert ctrl.q8_margin < 0                                                             # every as-written extra row holds
+    o = coracle.solve_batch(par, x_start[None], traj[None], np.zeros((1, 20, 5)), np.zeros((1, 20, 5)), obs[None], hs=hs)
+    assert o["status"][0] == 0
+    assert np.abs(u0 - o["U"][0, 0]).max() < TOL and np.abs(ctrl.x_guess - o["X"][0]).max() < TOL
+    r = ctrl.solve_batch(x_start[None], traj[None], np.zeros((1, 20, 5)))
+    prob = nlp.Problem(par, x_start, traj, np.zeros((20, 5)), ctrl.u_latest * 0, obs, hs, as_written=True)
+    # (second call: U_last = first optimum)  certificate of the as-written NLP on the first call's output
+    prob1 = nlp.Problem(par, x_start, traj, np.zeros((20, 5)), np.zeros((20, 5)), obs, hs, as_written=True)
+    c = nlp.kkt_certificate_ipopt(prob1, ctrl.x_guess, ctrl.u_latest, o["s"][0])
+    assert c["E0"] <= 3e-8 and c["ineq_violation"] == 0.0, c
+    assert r["status"][0] == 0 and r["q8_margin"][0] < 0
+    # under the "tent": the intended solution crosses the ridge between two stages -> an as-written row is violated
+    x2 = np.array([1.9, 2.0, 0.0, 0.3, 0, 0, 0.3, -1.2, 1.6]); t2 = np.array([3.2, 2.0, 0, 0, 0, 0, 0.3, -1.2, 1.6])
+    traj2 = np.linspace(x2, t2, 51)[:21]
+    ctrl.reset()
+    with pytest.raises(RuntimeError, match="as-written"):
+        ctrl.solve(x2.copy(), traj2, np.zeros((20, 5)))
+    assert ctrl.q8_margin > 1e-3
+    loose = mm.MPCWholeBody(robot, obstacles, oml, N=20, faithful_convex=False)
+    u0 = loose.solve(x2.copy(), traj2, np.zeros((20, 5)))
+    o = coracle.solve_batch(par, x2[None], traj2[None], np.zeros((1, 20, 5)), np.zeros((1, 20, 5)), obs[None], hs=hs)
+    assert o["status"][0] == 0
+    assert np.abs(u0 - o["U"][0, 0]).max() < TOL and np.abs(loose.x_guess - o["X"][0]).max() < TOL
 
 
 def test_full_size_properties(mm):

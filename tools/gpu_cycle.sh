@@ -2,7 +2,7 @@
 # one GPU round: parity tests, bench line (run through gpurun from the repo root).  Steps are chained with && so that
 # nothing is started on the GPU after a step that was killed or timed out.
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests -m gpu -x -q -s > gpurun_out/gpu_tests.log 2>&1; rc=$?
+timeout -k 10 900 python -m pytest tests -m gpu -x -v -s > gpurun_out/gpu_tests.log 2>&1; rc=$?
 tail -5 gpurun_out/gpu_tests.log
 [ $rc -eq 0 ] || { echo "gpu tests rc=$rc"; exit $rc; }
 timeout -k 10 300 python bench.py --steps 20 --warmup 3 > gpurun_out/bench_cycle.json 2> gpurun_out/bench_cycle.err || { tail -5 gpurun_out/bench_cycle.err; exit 1; }

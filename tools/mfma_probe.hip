@@ -35,6 +35,28 @@ __global__ void chain_bop(int n, double a, double *out) {
     out[threadIdx.x] = f[0] + f[1] + f[2] + f[3];
 }
 
+// one input-elimination step of the Riccati stage: pivot from a lane of the accumulator (v_readlane), reciprocal, scaled row
+// as the only non-zero K-slot, rank-one MFMA back onto the accumulator
+__global__ void chain_pivot(int n, double *out) {
+    v4d e = {1.0 + threadIdx.x, 2, 3, 4};
+    const bool own = (threadIdx.x >> 4) == 2;
+    for (int i = 0; i < n; i++) {
+        const double c = e[2];
+        const int lo = __builtin_amdgcn_readlane(__double2loint(c), 42), hi = __builtin_amdgcn_readlane(__double2hiint(c), 42);
+        const double d = __hiloint2double(hi, lo) + 1e3;
+        const double r = __builtin_amdgcn_rcp(d), q = fma(-d, r, 1.0), id = fma(fma(q, q, q), r, r);
+        const double w = c * id;
+        e = __builtin_amdgcn_mfma_f64_16x16x4f64(own ? -w : 0.0, own ? c : 0.0, e, 0, 0, 0);
+    }
+    out[threadIdx.x] = e[0] + e[1] + e[2] + e[3];
+}
+// the small-tile instruction: v_mfma_f64_4x4x4 (four 4x4x4 blocks), dependent accumulate chain
+__global__ void chain_acc4(int n, double a, double b, double *out) {
+    double e = threadIdx.x;
+    for (int i = 0; i < n; i++) e = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, e, 0, 0, 0);
+    out[threadIdx.x] = e;
+}
+
 // dependent fp64 FMA chain and dependent rcp chain (one wave)
 __global__ void chain_fma(int n, double a, double b, double *out) {
     double x = threadIdx.x;
@@ -92,6 +114,12 @@ int main() {
     hipEventRecord(e0); chain_bop<<<1, 64>>>(n / 4, 1e-3, dD); hipEventRecord(e1); hipEventSynchronize(e1);
     hipEventElapsedTime(&ms, e0, e1);
     printf("result-as-B-operand chain: %.2f ns per MFMA (groups of 4)\n", ms * 1e6 / n);
+    hipEventRecord(e0); chain_pivot<<<1, 64>>>(n / 4, dD); hipEventRecord(e1); hipEventSynchronize(e1);
+    hipEventElapsedTime(&ms, e0, e1);
+    printf("pivot step (readlane, rcp3, scale, select, rank-one MFMA): %.2f ns per step\n", ms * 1e6 / (n / 4));
+    hipEventRecord(e0); chain_acc4<<<1, 64>>>(n, 1e-3, 1e-3, dD); hipEventRecord(e1); hipEventSynchronize(e1);
+    hipEventElapsedTime(&ms, e0, e1);
+    printf("dependent 4x4x4 accumulate chain: %.2f ns per MFMA\n", ms * 1e6 / n);
     const int m = 1 << 16;
     chain_fma<<<1, 64>>>(10, 0.5, 1.0, dD); hipDeviceSynchronize();
     hipEventRecord(e0); chain_fma<<<1, 64>>>(m, 0.5, 1.0, dD); hipEventRecord(e1); hipEventSynchronize(e1);

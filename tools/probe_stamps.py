@@ -22,7 +22,7 @@ out = eng.solve_batch_device(xi, tr, ur, ul, ob); torch.cuda.synchronize()
 L.mmpc_debug_read_stamps(buf)
 v = np.array(list(buf), float)
 names = ["line search: move to the trial point", "evaluation, stage lanes", "convergence / barrier update", "A1 stage", "A1 pair",
-         "R0/R1 (P update MFMA, operands)", "R2 (T, M MFMA chain)", "R34 (LDL^T, gains)", "R5", "forward", "D1", "D2 (row steps)",
+         "R0 / P store + operand hand-over", "R1+R2 (T, M MFMA chains)", "R3 (input elimination: 5 rank-one MFMAs)", "gain back-substitution", "forward", "D1", "D2 (row steps)",
          "evaluation, pair lanes + filter test", "exit"]
 tot = v.sum()
 it = out["iters"].float().mean().item()
