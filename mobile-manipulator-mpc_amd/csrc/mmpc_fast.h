@@ -1063,10 +1063,10 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                 // c = M[NX+1+a][.] and pivot d = c[NX+1+a] > 0,  M <- M - c c^T / d  is one rank-one MFMA whose only non-zero
                 // K-slot is supplied by the lane group that already holds the row in its accumulator (row index mod 4 = lane
                 // group = K-slot: no LDS exchange).  Two inputs whose rows sit in neighbouring lane groups of the same
-                // accumulator register go together as a 2x2 block pivot D (one reciprocal, one MFMA: the serial chain
-                // accumulator -> pivot -> reciprocal -> MFMA is what a stage costs): M <- M - [c0 c1] D^-1 [c0 c1]^T, each
-                // group fetching its partner's row entry from lane ^ 16.  What is left in rows / columns (x, 1) after the
-                // last input is [P_k p_k; p_k^T .].  The normalised rows W = D^-1 [c0 c1]^T are kept: u_a = -W_a . (dx, 1,
+                // accumulator register go together (one MFMA with two K-slots: the serial chain accumulator -> pivot ->
+                // reciprocal -> MFMA is what a stage costs): M <- M - c0 c0^T / d0 - c1' c1'^T / d1 with c1' = c1 - (d01/d0) c0,
+                // the second group fetching its partner's row entry from lane ^ 16.  What is left in rows / columns (x, 1) after the
+                // last input is [P_k p_k; p_k^T .].  The normalised rows c / d are kept: u_a = -(c/d) . (dx, 1,
                 // u_b>a), from which the gains are formed for all stages at once after the pass.
                 constexpr bool PAIRS = ((NX + 1) & 1) == 0;               // first input row even -> rows (2q, 2q+1) share a register
                 constexpr int NLEG = PAIRS ? (NU + 1) / 2 : NU;
@@ -1078,18 +1078,21 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                     const bool pair = PAIRS && a0 + 1 < NU;
                     const int ta = NX + 1 + a0, ra = ta >> 2, ga = ta & 3, g = lane >> 4;
                     const double c = ls.rM[ra];
-                    double w;
+                    double w, cb = c;
                     bool own;
                     unsigned o;
                     if (pair) {
                         const double d00 = MMPC_LANE_GET(rM[ra], 16 * ga + ta), d01 = MMPC_LANE_GET(rM[ra], 16 * ga + ta + 1),
                                      d11 = MMPC_LANE_GET(rM[ra], 16 * (ga + 1) + ta + 1);
-                        const double det = fma(d00, d11, -d01 * d01);
-                        if (!(d00 > 0.0 && det > 0.0)) ric_bad = 1;   // (NaN fails too) the pass stops at the next stage, redone one rung down
-                        const double idet = mmpc_rcp3(det), co = MMPC_LANE_XOR16(rM[ra]);
+                        // the two pivots of the pair in sequence (same arithmetic as two rank-one steps: l = d01 / d00, second
+                        // pivot d1 = d11 - l d01, second row c1 - l c0), applied as the two K-slots of ONE MFMA
+                        const double i0 = mmpc_rcp3(d00), l = d01 * i0, d1 = fma(-l, d01, d11);
+                        if (!(d00 > 0.0 && d1 > 0.0)) ric_bad = 1;   // (NaN fails too) the pass stops at the next stage, redone one rung down
+                        const double i1 = mmpc_rcp3(d1), co = MMPC_LANE_XOR16(rM[ra]);
                         const bool in1 = g == ga + 1;
                         own = g == ga || in1;
-                        w = fma((in1 ? d00 : d11) * idet, c, -(d01 * idet) * co);
+                        cb = in1 ? fma(-l, co, c) : c;
+                        w = cb * (in1 ? i1 : i0);
                         o = in1 ? ls.kr_o[a0 + 1 < NU ? a0 + 1 : a0] : ls.kr_o[a0];
                     } else {
                         const double d = MMPC_LANE_GET(rM[ra], 16 * ga + ta);
@@ -1099,7 +1102,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                         o = ls.kr_o[a0];
                     }
                     ls.opa = own ? -w : 0.0;
-                    ls.opb = own ? c : 0.0;
+                    ls.opb = own ? cb : 0.0;
                     lds[(o & 0xffffu) + k * (int)(o >> 16)] = w;   // (lanes that hold no entry of the row write to their dump slot: no branch)
                     LANES_END_REG
                     MMPC_MFMA(rM, ls.opa, ls.opb)
