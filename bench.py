@@ -263,6 +263,25 @@ def main():
                                     "note": "batch_order: mode 0; hinted: same batch re-solved with the longest-first order of its "
                                             "previous solve (exact hint) - not the headline; every instance converges to the same "
                                             "result in every order"}
+            # (1b) iteration budget + continuation (mmpc_set_iteration_budget / mmpc_resume_batch_device): the main launch gives
+            # every instance at most 32 iterations - the results of the ~97 % that converge by then are complete when it ends -,
+            # the continuation launch finishes the suspended ones (bitwise the same results as one uninterrupted launch)
+            eng.set_schedule_hint(2)
+            eng.set_iteration_budget(32)
+            cm, cr = [], []
+            ev2 = torch.cuda.Event(enable_timing=True)
+            for _ in range(4):
+                ev0.record()
+                eng.solve_batch_device(x_init, traj, uref, ulast, obs, out=out)
+                ev1.record()
+                eng.resume_batch_device(x_init, traj, uref, ulast, obs, out=out)
+                ev2.record(); ev2.synchronize()
+                cm.append(ev0.elapsed_time(ev1)); cr.append(ev1.elapsed_time(ev2))
+            res["continuation"] = {"budget": 32, "main_launch_ms": sorted(cm)[1], "continuation_ms": sorted(cr)[1],
+                                   "suspended_after_main": eng.suspended_count(),
+                                   "note": "main launch: every instance gets at most 32 iterations; continuation: the suspended "
+                                           "instances run to convergence; outputs bitwise equal to the single launch"}
+            eng.set_iteration_budget(0)
             # (2) two batches in flight (two handles, two HIP streams, alternating): the drain of one launch - waves still
             # iterating on its slowest instances while CUs idle - is filled by the next launch.  No hint.
             eng.set_schedule_hint(2)

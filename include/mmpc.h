@@ -38,6 +38,8 @@ extern "C" {
 #define MMPC_STATUS_CONVERGED 0 /* scaled KKT error <= tol */
 #define MMPC_STATUS_MAXITER 1
 #define MMPC_STATUS_NUMERIC 2   /* NaN / non-PD even with the Gauss-Newton Hessian */
+#define MMPC_STATUS_SUSPENDED 3 /* iteration budget of the launch used up (mmpc_set_iteration_budget): X, U, s hold the current
+                                   iterate, mmpc_resume_batch_device continues the solve */
 
 /* Build-time structure of the NLP = constructor arguments of MPCWholeBody.__init__
  * (mpc_wholebody_qref.py:7-23: N, ulim, xlim, dulim, robot.dt) / MPCBase.__init__
@@ -132,6 +134,22 @@ int mmpc_set_warm_start(mmpc_handle h, const double *d_u_guess, double mu_init);
  * inflated obstacle disc); mode 2: always the a-priori key (no memory of earlier launches); mode 0: batch order.
  * Results never depend on the order.  No reference counterpart (the reference solves one instance at a time). */
 int mmpc_set_schedule_hint(mmpc_handle h, int mode);
+
+/* Iteration budget and continuation (specialised kernels only; no reference counterpart - IPOPT runs one instance to the
+ * end).  One wave solves one instance, so a launch lasts as long as its slowest instance: a handful of instances that need
+ * several hundred iterations (heavy tail of the interior-point iteration count) would hold the results of thousands of
+ * finished ones.  With budget > 0, mmpc_solve_batch_device gives every instance at most `budget` iterations per launch;
+ * an instance that is not converged by then writes its primal-dual state to the handle (18.7 KB at N=20, M=5) and ends
+ * with status MMPC_STATUS_SUSPENDED, X/U/s holding its current iterate.  mmpc_resume_batch_device - same arguments as the
+ * launch it continues, any stream - runs the suspended instances to the end (no budget) with one workgroup each;
+ * the other instances' outputs are not touched.  A resumed solve executes exactly the iterations the uninterrupted one
+ * would have: results are bitwise identical.  mmpc_suspended_count waits for the handle's launches and returns how many
+ * instances the last budgeted launch left suspended.  budget = 0 (default) switches the feature off. */
+int mmpc_set_iteration_budget(mmpc_handle h, int budget);
+int mmpc_resume_batch_device(mmpc_handle h, int B, const double *d_x_init, const double *d_traj_ref, const double *d_u_ref,
+                             const double *d_u_last, const double *d_x_guess, const double *d_obs, double *d_X, double *d_U,
+                             double *d_s, int *d_status, int *d_iters, double *d_cost, double *d_err, void *stream);
+int mmpc_suspended_count(mmpc_handle h, int *count);
 
 /* Streams and threads: a handle owns device state that its launches read and write (parameter block, schedule hint,
  * warm start).  Calls on one handle must come from one host thread at a time.  Launches may use different streams:

@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MMPC_LIB") or os.path.join(_HERE, "csrc", "libmmpc.so")   # MMPC_LIB: A/B builds of the same HIP library
 
 KIND_WHOLEBODY, KIND_BASE, KIND_WHOLEBODY_POSE = 0, 1, 2
-STATUS_CONVERGED, STATUS_MAXITER, STATUS_NUMERIC = 0, 1, 2
+STATUS_CONVERGED, STATUS_MAXITER, STATUS_NUMERIC, STATUS_SUSPENDED = 0, 1, 2, 3
 STATUS_Q8_REFUSED = 8      # host-side only (controllers/_q8.py): converged, but an as-written extra half-space row is violated
 
 
@@ -23,7 +23,7 @@ class MmpcConfig(C.Structure):
 
 EXPORTS = ["mmpc_create", "mmpc_destroy", "mmpc_set_weights", "mmpc_set_terminal_xy_equality", "mmpc_reset",
            "mmpc_solve_batch", "mmpc_solve_batch_device", "mmpc_get_u_latest", "mmpc_set_u_latest",
-           "mmpc_lds_bytes", "mmpc_problems_per_cu", "mmpc_set_warm_start", "mmpc_set_schedule_hint", "mmpc_last_error", "mmpc_version", "mmpc_ik_batch", "mmpc_ik_batch_device"]
+           "mmpc_lds_bytes", "mmpc_problems_per_cu", "mmpc_set_warm_start", "mmpc_set_schedule_hint", "mmpc_set_iteration_budget", "mmpc_resume_batch_device", "mmpc_suspended_count", "mmpc_last_error", "mmpc_version", "mmpc_ik_batch", "mmpc_ik_batch_device"]
 
 _lib = None
 _dp = C.POINTER(C.c_double)
@@ -59,6 +59,9 @@ def lib():
         L.mmpc_problems_per_cu.argtypes = [C.c_void_p]
         L.mmpc_set_warm_start.argtypes = [C.c_void_p, C.c_void_p, C.c_double]
         L.mmpc_set_schedule_hint.argtypes = [C.c_void_p, C.c_int]
+        L.mmpc_set_iteration_budget.argtypes = [C.c_void_p, C.c_int]
+        L.mmpc_resume_batch_device.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 13 + [C.c_void_p]
+        L.mmpc_suspended_count.argtypes = [C.c_void_p, _ip]
         L.mmpc_last_error.argtypes = [C.c_void_p]
         L.mmpc_last_error.restype = C.c_char_p
         L.mmpc_version.restype = C.c_char_p
@@ -182,6 +185,16 @@ class Engine:
         data, 2 always the a-priori key."""
         self._chk(lib().mmpc_set_schedule_hint(self._h, int(mode)), "mmpc_set_schedule_hint")
 
+    def set_iteration_budget(self, budget):
+        """mmpc_set_iteration_budget: iterations a launch may spend on an instance before it is suspended (0: off)."""
+        self._chk(lib().mmpc_set_iteration_budget(self._h, int(budget)), "mmpc_set_iteration_budget")
+
+    def suspended_count(self):
+        """mmpc_suspended_count: instances the last budgeted launch left suspended (waits for the handle's launches)."""
+        n = C.c_int(0)
+        self._chk(lib().mmpc_suspended_count(self._h, C.byref(n)), "mmpc_suspended_count")
+        return n.value
+
     def set_terminal_xy_equality(self, on):
         self._chk(lib().mmpc_set_terminal_xy_equality(self._h, int(bool(on))), "mmpc_set_terminal_xy_equality")
 
@@ -219,7 +232,7 @@ class Engine:
         u = np.ascontiguousarray(u, float)
         self._chk(lib().mmpc_set_u_latest(self._h, u.shape[0], _d(u)), "mmpc_set_u_latest")
 
-    def solve_batch_device(self, x_init, traj_ref, u_ref, u_last, obs, x_guess=None, out=None, stream=None):
+    def solve_batch_device(self, x_init, traj_ref, u_ref, u_last, obs, x_guess=None, out=None, stream=None, resume=False):
         """torch CUDA float64 tensors in / out, asynchronous on torch's current stream (or `stream`).
         PyTorch is only the owner of the device memory and of the stream here."""
         import torch
@@ -249,8 +262,14 @@ class Engine:
                        err=torch.empty(B, dtype=torch.float64, device=dev))
         st = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
         p = lambda t_: C.c_void_p(t_.data_ptr()) if t_ is not None else None
-        self._chk(lib().mmpc_solve_batch_device(self._h, B, p(x_init), p(traj_ref), p(u_ref), p(u_last), p(x_guess),
-                                                p(obs), p(out["X"]), p(out["U"]), p(out["s"]), p(out["status"]),
-                                                p(out["iters"]), p(out["cost"]), p(out["err"]), C.c_void_p(st)),
-                  "mmpc_solve_batch_device")
+        fn = lib().mmpc_resume_batch_device if resume else lib().mmpc_solve_batch_device
+        self._chk(fn(self._h, B, p(x_init), p(traj_ref), p(u_ref), p(u_last), p(x_guess),
+                     p(obs), p(out["X"]), p(out["U"]), p(out["s"]), p(out["status"]),
+                     p(out["iters"]), p(out["cost"]), p(out["err"]), C.c_void_p(st)),
+                  "mmpc_resume_batch_device" if resume else "mmpc_solve_batch_device")
         return out
+
+    def resume_batch_device(self, x_init, traj_ref, u_ref, u_last, obs, out, x_guess=None, stream=None):
+        """mmpc_resume_batch_device: continues the instances the preceding budgeted solve_batch_device call (same tensors,
+        same `out`) left suspended; the other rows of `out` are not touched."""
+        return self.solve_batch_device(x_init, traj_ref, u_ref, u_last, obs, x_guess=x_guess, out=out, stream=stream, resume=True)

@@ -189,6 +189,11 @@ struct MmpcIO {
     const double *u_guess;                                             // (or null)
     double *X, *U, *s, *cost, *err;
     int *status, *iters;
+    // iteration budget / continuation (specialised kernels): after `budget` iterations of this launch (0: no budget) an
+    // unconverged instance writes its primal-dual state to `state` and ends with status MMPC_STATUS_SUSPENDED; a launch
+    // with resume != 0 starts from that state and runs exactly the iterations the uninterrupted solve would have run next
+    double *state;
+    int budget, resume;
 };
 
 MMPC_DEV double mmpc_min(double a, double b) { return a < b ? a : b; }

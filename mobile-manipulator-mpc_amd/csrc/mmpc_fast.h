@@ -247,6 +247,15 @@ MMPC_HD MmpcFastLayout mmpc_fast_layout(int M, int obs_per_stage) {
     return L;
 }
 
+// doubles of the per-instance save area of a suspended solve: trajectory, slacks, equality multipliers, filter, scalars,
+// and per lane the multipliers of its box rows and the slack / multiplier of its circle and self-collision rows
+#define MMPC_NSCAL 12
+template <int KIND, int N>
+MMPC_HD int mmpc_fast_state_doubles(int MC) {
+    typedef MmpcFastDims<KIND, N> F;
+    return F::NPAIR + F::NS + F::NS * F::NX + 2 * MMPC_FCAP + MMPC_NSCAL + MMPC_WAVE * (2 * F::NPASS + 2 * (MC > 0 ? MC : 1) + 8);
+}
+
 template <int KIND, int N, int MC>
 struct MmpcLaneState {
     typedef MmpcFastDims<KIND, N> F;
@@ -587,12 +596,39 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
 
     int status = 1, it = 0, nfilt = 0, filt_init = 0;
     double E0 = 0.0, th_max = 0.0, th_min = 0.0;
+    // save area of a suspended solve (layout: mmpc_fast_state_doubles)
+    constexpr int MCS = MC > 0 ? MC : 1, NLREG = 2 * NPASS + 2 * MCS + 8;
+    double *const st_xu = io.state, *const st_s = io.state + NPAIR, *const st_lam = io.state + NPAIR + NS,
+           *const st_filt = io.state + NPAIR + NS + NS * NX, *const st_scal = st_filt + 2 * MMPC_FCAP,
+           *const st_lane = st_scal + MMPC_NSCAL;
+    int nsmall_r = 0;
+    double prox_r = 0.0;
+    if (io.resume) {
+        // ---- continue a suspended solve: the state the uninterrupted loop would hold at this point
+        LANES_BEGIN
+        auto &ls = MMPC_LS;
+        for (int i = lane; i < NPAIR; i += MMPC_WAVE) XU[i] = st_xu[i];
+        for (int i = lane; i < NS; i += MMPC_WAVE) S[i] = st_s[i];
+        for (int i = lane; i < NS * NX; i += MMPC_WAVE) LAM[i] = st_lam[i];
+        for (int i = lane; i < 2 * MMPC_FCAP; i += MMPC_WAVE) FILT[i] = st_filt[i];
+        const double *q = st_lane + lane * NLREG;
+#pragma unroll
+        for (int p = 0; p < NPASS; p++) { ls.lo_z[p] = q[p]; ls.hi_z[p] = q[NPASS + p]; }
+#pragma unroll
+        for (int m = 0; m < MCS; m++) { ls.ct[m] = q[2 * NPASS + m]; ls.cz[m] = q[2 * NPASS + MCS + m]; }
+#pragma unroll
+        for (int i = 0; i < 4; i++) { ls.st[i] = q[2 * NPASS + 2 * MCS + i]; ls.sz[i] = q[2 * NPASS + 2 * MCS + 4 + i]; }
+        LANES_END
+        mu = st_scal[0]; th_max = st_scal[1]; th_min = st_scal[2]; prox_r = st_scal[3];
+        it = (int)st_scal[4]; nfilt = (int)st_scal[5]; filt_init = (int)st_scal[6]; nsmall_r = (int)st_scal[7];
+    }
+    const int it_start = it;
     // results of the evaluation of the current point (iterate or line-search trial)
     double err_d = 0.0, err_p = 0.0, tzmax = 0.0, tzmin = 0.0, zsum = 0.0, cost_c = 0.0, th_c = 0.0, sumlog = 0.0;
     // line-search state: the evaluation of a trial point IS the evaluation the next iteration starts from (98.6 % of the
     // first trials are accepted), so the loop below evaluates once per trial and never a second time for the accepted one
-    int in_ls = 0, lspass = 0, lsi = 0, nsmall = 0;
-    double prox = 0.0;   // proximal term for crawling iterations (mmpc_prox_update)
+    int in_ls = 0, lspass = 0, lsi = 0, nsmall = nsmall_r;
+    double prox = prox_r;   // proximal term for crawling iterations (mmpc_prox_update)
     double alpha = 0.0, ap = 1.0, ad = 1.0, dphi = 0.0, phi0 = 0.0, th0 = 0.0;
 
     // ---- move to a trial point: the primal variables, the equality multipliers and the slacks of the nonlinear rows by
@@ -828,6 +864,30 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
             status = 2; break; }
         if (E0 <= tol) { status = 0; break; }
         if (it == P.max_iter) break;
+        if (io.budget > 0 && it - it_start >= io.budget && io.state) {
+            // ---- iteration budget of this launch used up: park the solve (the point has just been evaluated and is not
+            //      converged; a resumed launch re-evaluates it and continues with the barrier update below)
+            LANES_BEGIN
+            auto &ls = MMPC_LS;
+            for (int i = lane; i < NPAIR; i += MMPC_WAVE) st_xu[i] = XU[i];
+            for (int i = lane; i < NS; i += MMPC_WAVE) st_s[i] = S[i];
+            for (int i = lane; i < NS * NX; i += MMPC_WAVE) st_lam[i] = LAM[i];
+            for (int i = lane; i < 2 * MMPC_FCAP; i += MMPC_WAVE) st_filt[i] = i < 2 * nfilt ? FILT[i] : 0.0;
+            double *q = st_lane + lane * NLREG;
+#pragma unroll
+            for (int p = 0; p < NPASS; p++) { q[p] = ls.lo_z[p]; q[NPASS + p] = ls.hi_z[p]; }
+#pragma unroll
+            for (int m = 0; m < MCS; m++) { q[2 * NPASS + m] = ls.ct[m]; q[2 * NPASS + MCS + m] = ls.cz[m]; }
+#pragma unroll
+            for (int i = 0; i < 4; i++) { q[2 * NPASS + 2 * MCS + i] = ls.st[i]; q[2 * NPASS + 2 * MCS + 4 + i] = ls.sz[i]; }
+            if (lane == 0) {
+                st_scal[0] = mu; st_scal[1] = th_max; st_scal[2] = th_min; st_scal[3] = prox;
+                st_scal[4] = (double)it; st_scal[5] = (double)nfilt; st_scal[6] = (double)filt_init; st_scal[7] = (double)nsmall;
+            }
+            LANES_END
+            status = 3;   // MMPC_STATUS_SUSPENDED
+            break;
+        }
         {
             bool changed = false;
             for (;;) {

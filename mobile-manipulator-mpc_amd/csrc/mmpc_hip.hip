@@ -43,6 +43,7 @@ __global__ __launch_bounds__(MMPC_WAVE) void mmpc_solve_kernel(
     io.iters = iters + b;
     io.cost = cost + b;
     io.err = err + b;
+    io.state = nullptr; io.budget = 0; io.resume = 0;   // (iteration budgets are a feature of the specialised kernels)
     mmpc_solve_one<KIND>(P, io, lds);
 }
 
@@ -53,11 +54,13 @@ __global__ __launch_bounds__(MMPC_WAVE, WPE) void mmpc_fast_kernel(
     const double *__restrict__ u_ref, const double *__restrict__ u_last, const double *__restrict__ x_guess,
     const double *__restrict__ obs, double *__restrict__ X, double *__restrict__ U, double *__restrict__ s,
     int *__restrict__ status, int *__restrict__ iters, double *__restrict__ cost, double *__restrict__ err,
-    const int *__restrict__ order) {
+    const int *__restrict__ order, int budget, double *__restrict__ state, int state_stride, const int *__restrict__ resume_count) {
     extern __shared__ double lds[];
     typedef MmpcDims<KIND> D;
     if ((int)blockIdx.x >= B) return;
-    // longest-first schedule hint: workgroup i solves instance order[i] (a permutation; results do not depend on it)
+    // a continuation launch: `order` is the compacted list of the suspended instances, *resume_count its length
+    if (resume_count && (int)blockIdx.x >= *resume_count) return;
+    // launch order: workgroup i solves instance order[i] (a permutation / a list; results do not depend on it)
     const int b = order ? order[blockIdx.x] : (int)blockIdx.x;
     const MmpcParams &P = *Pp;
     const int M = MC;
@@ -77,6 +80,9 @@ __global__ __launch_bounds__(MMPC_WAVE, WPE) void mmpc_fast_kernel(
     io.iters = iters + b;
     io.cost = cost + b;
     io.err = err + b;
+    io.state = state ? state + (size_t)b * state_stride : nullptr;
+    io.budget = budget;
+    io.resume = resume_count ? 1 : 0;
     mmpc_solve_fast<KIND, N, MC>(P, io, lds);
 }
 
@@ -98,6 +104,13 @@ __global__ __launch_bounds__(1024) void mmpc_lpt_order(int B, const int *__restr
     if (t == 0) { int acc = 0; for (int v = 255; v >= 0; v--) { start[v] = acc; acc += hist[v]; } }
     __syncthreads();
     for (int i = t; i < B; i += 1024) { int v = iters[i]; v = v < 0 ? 0 : (v > 255 ? 255 : v); order[atomicAdd(&start[v], 1)] = i; }
+}
+
+// list of the instances a budgeted launch left suspended (any order), and their number
+__global__ __launch_bounds__(256) void mmpc_collect_suspended(int B, const int *__restrict__ status, int *__restrict__ list,
+                                                             int *__restrict__ count) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b < B && status[b] == MMPC_STATUS_SUSPENDED) list[atomicAdd(count, 1)] = b;
 }
 
 // A-priori difficulty of an instance, from its data alone: how close the reference path comes to (or how deep it cuts
@@ -176,6 +189,11 @@ struct mmpc_handle_s {
     int ev_valid;
     int hint_on;            // mmpc_set_schedule_hint: 0 batch order, 1 history when there is one / data-derived otherwise, 2 data-derived
     int *d_key;             // a-priori difficulty keys of the launch being prepared
+    // iteration budget / continuation (mmpc_set_iteration_budget, mmpc_resume_batch_device)
+    int budget;             // iterations a launch may spend on an instance before it is suspended (0: no budget)
+    int state_doubles;      // save area per instance
+    double *d_state;        // [max_batch][state_doubles], allocated when a budget is first set
+    int *d_list, *d_count;  // compacted list of the suspended instances of the last launch
     int no_lpt_env, force_generic_env;   // MMPC_NO_LPT / MMPC_FORCE_GENERIC, read once at create (diagnostics)
     int *d_warm;            // per instance: 1 once a CONVERGED solve has filled its u_latest / x_guess rows
     // device-side state and staging (capacity max_batch)
@@ -305,6 +323,7 @@ extern "C" int mmpc_create(const mmpc_config *cfg, mmpc_handle *out) {
 #define MMPC_X(K, NN, MM, WW)                                                                                        \
         if (cfg->kind == K && cfg->N == NN && cfg->M == MM && cfg->L == 0) {                                                                       \
             h->fast = 1;                                                                                               \
+            h->state_doubles = mmpc_fast_state_doubles<K, NN>(MM);                                                     \
             h->fast_lds_bytes = mmpc_fast_layout<K, NN>(MM, p.obs_per_stage).total * (int)sizeof(double);         \
             HIPCHK(h, hipFuncSetAttribute((const void *)mmpc_fast_kernel<K, NN, MM, WW>, hipFuncAttributeMaxDynamicSharedMemorySize, h->fast_lds_bytes)); \
             HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&h->fast_per_cu, mmpc_fast_kernel<K, NN, MM, WW>, MMPC_WAVE, h->fast_lds_bytes)); \
@@ -350,7 +369,8 @@ extern "C" int mmpc_create(const mmpc_config *cfg, mmpc_handle *out) {
 extern "C" int mmpc_destroy(mmpc_handle h) {
     if (!h) return MMPC_E_ARG;
     void *ptrs[] = {h->dp, h->d_x_init, h->d_traj, h->d_uref, h->d_obs, h->d_ulatest, h->d_xguess, h->d_X, h->d_U,
-                    h->d_s, h->d_cost, h->d_err, h->d_u0, h->d_status, h->d_iters, h->d_order, h->d_warm, h->d_key};
+                    h->d_s, h->d_cost, h->d_err, h->d_u0, h->d_status, h->d_iters, h->d_order, h->d_warm, h->d_key, h->d_state,
+                    h->d_list, h->d_count};
     (void)hipSetDevice(h->cfg.device);
     if (h->ev_valid) (void)hipEventSynchronize(h->ev);
     if (h->ev) (void)hipEventDestroy(h->ev);
@@ -396,14 +416,15 @@ extern "C" int mmpc_reset(mmpc_handle h) {
 
 static int launch(mmpc_handle h, int B, const double *x_init, const double *traj, const double *uref, const double *ulast,
                   const double *xguess, const double *obs, double *X, double *U, double *s, int *status, int *iters,
-                  double *cost, double *err, hipStream_t st) {
+                  double *cost, double *err, hipStream_t st, bool resume = false) {
     // (the X guess is a launch argument: null = tile(x_init); nothing in the device parameter block changes per launch)
     // a launch on another stream than the previous one waits for it: both touch the handle's schedule hint
     if (h->ev_valid && st != h->last_stream) HIPCHK(h, hipStreamWaitEvent(st, h->ev, 0));
     const bool use_fast = h->fast && h->diag && !h->hp.terminal_xy_eq && !h->force_generic_env;
+    if (resume && !(use_fast && h->d_state)) return fail(h, MMPC_E_UNSUPPORTED, "%s%s", "nothing to resume: no budgeted launch of a specialised kernel precedes");
     // launch order of the workgroups (results do not depend on it): the iteration counts of the handle's previous launch of
     // this batch size when there are any and the mode allows them, else the a-priori difficulty key of THIS batch's data
-    const bool lpt = h->hint_on && !h->no_lpt_env && B <= h->cfg.max_batch && B > 256;
+    const bool lpt = !resume && h->hint_on && !h->no_lpt_env && B <= h->cfg.max_batch && B > 256;
     const bool history = lpt && h->hint_on == 1 && h->order_B == B;
     if (lpt && !history && h->cfg.M > 0) {
         hipLaunchKernelGGL(mmpc_difficulty_key, dim3((B + 63) / 64), dim3(64), 0, st, B, h->cfg.N, h->cfg.M, h->nref,
@@ -415,7 +436,8 @@ static int launch(mmpc_handle h, int B, const double *x_init, const double *traj
 #define MMPC_X(K, NN, MM, WW)                                                                                          \
         if (h->cfg.kind == K && h->cfg.N == NN && h->cfg.M == MM)                                                                          \
             hipLaunchKernelGGL((mmpc_fast_kernel<K, NN, MM, WW>), dim3(B), dim3(MMPC_WAVE), h->fast_lds_bytes, st, h->dp, B, x_init, traj, \
-                               uref, ulast, xguess, obs, X, U, s, status, iters, cost, err, order);
+                               uref, ulast, xguess, obs, X, U, s, status, iters, cost, err, resume ? h->d_list : order,          \
+                               resume ? 0 : h->budget, h->d_state, h->state_doubles, resume ? h->d_count : (const int *)nullptr);
         MMPC_FAST_LIST(MMPC_X)
 #undef MMPC_X
     } else if (h->cfg.kind == MMPC_KIND_WHOLEBODY)
@@ -428,12 +450,56 @@ static int launch(mmpc_handle h, int B, const double *x_init, const double *traj
         hipLaunchKernelGGL(mmpc_solve_kernel<2>, dim3(B), dim3(MMPC_WAVE), h->lds_bytes, st, h->dp, B, x_init, traj, uref,
                            ulast, xguess, obs, X, U, s, status, iters, cost, err, order);
     HIPCHK(h, hipGetLastError());
+    if (use_fast && h->budget > 0 && !resume) {
+        // who is suspended: compacted list for mmpc_resume_batch_device
+        HIPCHK(h, hipMemsetAsync(h->d_count, 0, 4, st));
+        hipLaunchKernelGGL(mmpc_collect_suspended, dim3((B + 255) / 256), dim3(256), 0, st, B, status, h->d_list, h->d_count);
+    }
     if (lpt && h->hint_on == 1) {
         hipLaunchKernelGGL(mmpc_lpt_order, dim3(1), dim3(1024), 0, st, B, iters, h->d_order);
         h->order_B = B;
     }
     HIPCHK(h, hipEventRecord(h->ev, st));
     h->ev_valid = 1; h->last_stream = st;
+    return MMPC_OK;
+}
+
+extern "C" int mmpc_set_iteration_budget(mmpc_handle h, int budget) {
+    if (!h || budget < 0) return fail(h, MMPC_E_ARG, "mmpc_set_iteration_budget: %s%s", "budget must be >= 0");
+    if (budget > 0 && !h->fast) return fail(h, MMPC_E_UNSUPPORTED, "mmpc_set_iteration_budget: %s%s", "this (kind, N, M) runs the generic kernel, which has no continuation");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (budget > 0 && !h->d_state) {
+        const size_t B = (size_t)h->cfg.max_batch;
+        if (h->cfg.max_batch > (1 << 20)) return fail(h, MMPC_E_ARG, "%s%s", "iteration budgets need max_batch <= 2^20");
+        HIPCHK(h, hipMalloc(&h->d_state, B * (size_t)h->state_doubles * 8));
+        HIPCHK(h, hipMalloc(&h->d_list, B * 4));
+        HIPCHK(h, hipMalloc(&h->d_count, 4));
+        HIPCHK(h, hipMemset(h->d_count, 0, 4));
+    }
+    if (h->ev_valid) HIPCHK(h, hipEventSynchronize(h->ev));
+    h->budget = budget;
+    return MMPC_OK;
+}
+
+extern "C" int mmpc_resume_batch_device(mmpc_handle h, int B, const double *d_x_init, const double *d_traj_ref,
+                                        const double *d_u_ref, const double *d_u_last, const double *d_x_guess,
+                                        const double *d_obs, double *d_X, double *d_U, double *d_s, int *d_status,
+                                        int *d_iters, double *d_cost, double *d_err, void *stream) {
+    if (!h || B < 1 || B > h->cfg.max_batch || !d_x_init || !d_traj_ref || !d_u_ref || !d_u_last || !d_X || !d_U || !d_s ||
+        !d_status || !d_iters || !d_cost || !d_err || (h->cfg.M > 0 && !d_obs))
+        return fail(h, MMPC_E_ARG, "mmpc_resume_batch_device: %s%s", "bad argument");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    return launch(h, B, d_x_init, d_traj_ref, d_u_ref, d_u_last, d_x_guess, d_obs ? d_obs : h->d_obs, d_X, d_U, d_s,
+                  d_status, d_iters, d_cost, d_err, (hipStream_t)stream, true);
+}
+
+extern "C" int mmpc_suspended_count(mmpc_handle h, int *count) {
+    if (!h || !count) return MMPC_E_ARG;
+    *count = 0;
+    if (!h->d_count) return MMPC_OK;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (h->ev_valid) HIPCHK(h, hipEventSynchronize(h->ev));
+    HIPCHK(h, hipMemcpy(count, h->d_count, 4, hipMemcpyDeviceToHost));
     return MMPC_OK;
 }
 
@@ -490,6 +556,11 @@ extern "C" int mmpc_solve_batch(mmpc_handle h, int B, const double *x_init, cons
     int rc = launch(h, B, h->d_x_init, h->d_traj, h->d_uref, h->d_ulatest, xg, h->d_obs, h->d_X, h->d_U, h->d_s,
                     h->d_status, h->d_iters, h->d_cost, h->d_err, st);
     if (rc) return rc;
+    if (h->budget > 0 && h->fast && h->d_state) {   // the host-pointer call returns finished solves: continue the suspended ones at once
+        rc = launch(h, B, h->d_x_init, h->d_traj, h->d_uref, h->d_ulatest, xg, h->d_obs, h->d_X, h->d_U, h->d_s,
+                    h->d_status, h->d_iters, h->d_cost, h->d_err, st, true);
+        if (rc && rc != MMPC_E_UNSUPPORTED) return rc;
+    }
     // u_latest <- U*, x_guess <- X*  (:329-330), for the instances that converged
     hipLaunchKernelGGL(mmpc_keep_converged, dim3(B), dim3(64), 0, st, B, (int)(N * nu), (int)((N + 1) * nx), h->d_status, h->d_U,
                        h->d_X, h->d_ulatest, h->d_xguess, h->d_warm);

@@ -34,6 +34,7 @@ static void run(const MmpcParams *P, int B, const double *x_init, const double *
         io.U = U + (size_t)b * N * D::NU;
         io.s = s + (size_t)b * (N + 1);
         io.status = status + b; io.iters = iters + b; io.cost = cost + b; io.err = err + b;
+        io.state = nullptr; io.budget = 0; io.resume = 0;
         MmpcEmu emu = reverse ? MmpcEmu{63, -1, -1} : MmpcEmu{0, 64, 1};
         mmpc_solve_one<KIND>(*P, io, lds, emu);
         free(lds);
@@ -43,7 +44,8 @@ static void run(const MmpcParams *P, int B, const double *x_init, const double *
 template <int KIND, int N, int MC>
 static void run_fast(const MmpcParams *P, int B, const double *x_init, const double *traj_ref, const double *u_ref,
                      const double *u_last, const double *x_guess, const double *obs, double *X, double *U, double *s,
-                     int *status, int *iters, double *cost, double *err, int reverse) {
+                     int *status, int *iters, double *cost, double *err, int reverse, int budget = 0, double *state = nullptr,
+                     int resume = 0) {
     typedef MmpcDims<KIND> D;
     const int M = MC;
     MmpcFastLayout L = mmpc_fast_layout<KIND, N>(M, P->obs_per_stage);
@@ -63,6 +65,9 @@ static void run_fast(const MmpcParams *P, int B, const double *x_init, const dou
         io.U = U + (size_t)b * N * D::NU;
         io.s = s + (size_t)b * (N + 1);
         io.status = status + b; io.iters = iters + b; io.cost = cost + b; io.err = err + b;
+        const int sd = mmpc_fast_state_doubles<KIND, N>(MC);
+        io.state = state ? state + (size_t)b * sd : nullptr; io.budget = budget; io.resume = resume;
+        if (resume && status[b] != 3) { free(lds); continue; }   // a continuation launch only runs the suspended instances
         MmpcEmu emu = reverse ? MmpcEmu{63, -1, -1} : MmpcEmu{0, 64, 1};
         mmpc_solve_fast<KIND, N, MC>(*P, io, lds, emu);
         free(lds);
@@ -77,6 +82,22 @@ extern "C" int mmpc_emu_solve_fast(int kind, const MmpcParams *P, int B, const d
 #define MMPC_FAST_CASE(K, NN, MM) if (kind == K && P->N == NN && P->M == MM) { run_fast<K, NN, MM>(P, B, x_init, traj_ref, u_ref, u_last, x_guess, obs, X, U, s, status, iters, cost, err, reverse); return 0; }
     MMPC_FAST_CASE(0, 20, 5) MMPC_FAST_CASE(0, 20, 3) MMPC_FAST_CASE(0, 30, 8) MMPC_FAST_CASE(0, 20, 0) MMPC_FAST_CASE(1, 15, 3)
 #undef MMPC_FAST_CASE
+    return -1;
+}
+// same with an iteration budget: state = [B][mmpc_emu_fast_state_doubles] save area; resume != 0 continues the instances whose
+// status[] is 3 (MMPC_STATUS_SUSPENDED) and leaves the others alone
+extern "C" int mmpc_emu_solve_fast_budget(int kind, const MmpcParams *P, int B, const double *x_init, const double *traj_ref,
+                                          const double *u_ref, const double *u_last, const double *x_guess, const double *obs,
+                                          double *X, double *U, double *s, int *status, int *iters, double *cost, double *err,
+                                          int budget, double *state, int resume) {
+#define MMPC_FAST_CASE(K, NN, MM) if (kind == K && P->N == NN && P->M == MM) { run_fast<K, NN, MM>(P, B, x_init, traj_ref, u_ref, u_last, x_guess, obs, X, U, s, status, iters, cost, err, 0, budget, state, resume); return 0; }
+    MMPC_FAST_CASE(0, 20, 5) MMPC_FAST_CASE(1, 15, 3)
+#undef MMPC_FAST_CASE
+    return -1;
+}
+extern "C" int mmpc_emu_fast_state_doubles(int kind, int N, int M) {
+    if (kind == 0 && N == 20) return mmpc_fast_state_doubles<0, 20>(M);
+    if (kind == 1 && N == 15) return mmpc_fast_state_doubles<1, 15>(M);
     return -1;
 }
 extern "C" int mmpc_emu_fast_lds_doubles(int kind, int N, int M, int obs_per_stage) {

@@ -100,3 +100,32 @@ def ik_batch(q0, target_xz, asan=False):
     q = np.zeros((B, 3)); st = np.zeros(B, np.int32); it = np.zeros(B, np.int32)
     lib.mmpc_emu_ik(B, _p(q0), _p(t), _p(q), st.ctypes.data_as(C.POINTER(C.c_int)), it.ctypes.data_as(C.POINTER(C.c_int)))
     return dict(q=q, status=st, iters=it)
+
+
+def solve_fast_budgeted(par, x_init, traj_ref, u_ref, u_last, obs, budget, max_rounds=200, **kw):
+    """The specialised kernel (host build) with an iteration budget per launch: first launch, then continuation launches
+    (each again with the budget) until nobody is suspended.  Returns the outputs and the number of launches."""
+    lib = C.CDLL(build(False))
+    x_init = np.ascontiguousarray(x_init, float); traj_ref = np.ascontiguousarray(traj_ref, float)
+    u_ref = np.ascontiguousarray(u_ref, float); u_last = np.ascontiguousarray(u_last, float); obs = np.ascontiguousarray(obs, float)
+    B = x_init.shape[0]
+    N, nx, nu = par.N, par.nx, par.nu
+    M = obs.shape[-2]
+    prm = make_params(par, M, obs.ndim == 4, False, **kw)
+    kind = 0 if par.kind == "wholebody" else 1
+    sd = lib.mmpc_emu_fast_state_doubles(kind, N, M)
+    assert sd > 0
+    state = np.full((B, sd), np.nan)
+    X = np.zeros((B, N + 1, nx)); U = np.zeros((B, N, nu)); s = np.zeros((B, N + 1))
+    status = np.zeros(B, np.int32); iters = np.zeros(B, np.int32); cost = np.zeros(B); err = np.zeros(B)
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+    launches = 0
+    for rnd in range(max_rounds):
+        rc = lib.mmpc_emu_solve_fast_budget(kind, C.byref(prm), B, _p(x_init), _p(traj_ref), _p(u_ref), _p(u_last), None, _p(obs),
+                                            _p(X), _p(U), _p(s), ip(status), ip(iters), _p(cost), _p(err), int(budget), _p(state),
+                                            int(rnd > 0))
+        assert rc == 0
+        launches += 1
+        if not (status == 3).any():
+            break
+    return dict(X=X, U=U, s=s, status=status, iters=iters, cost=cost, err=err), launches

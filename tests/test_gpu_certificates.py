@@ -312,3 +312,42 @@ def test_launches_on_two_streams_are_ordered(mm):
         r = eng.solve_batch_device(xi, tr, ur, ul, ob)
         torch.cuda.synchronize()
         assert torch.equal(r["X"], X0) and torch.equal(r["iters"], ref["iters"])
+
+
+def test_iteration_budget_and_continuation(mm):
+    """mmpc_set_iteration_budget / mmpc_resume_batch_device: a launch with a budget of 24 iterations leaves the instances
+    that need more suspended (status 3, iterate so far in X/U/s); the continuation finishes exactly those, and every
+    output - iteration counts included - is bitwise the output of the uninterrupted solve.  Also through the host-pointer
+    entry point, which resumes by itself."""
+    import torch
+    B, N, M = 4096, 20, 5
+    d = synth.make_batch(B)
+    par = nlp.WholeBodyParams()
+    ctrl = _wb(mm, N, M, B)
+    eng = ctrl._engine
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    xi, tr, ur, ob = t(np.clip(d["x_init"], par.xlim[0], par.xlim[1])), t(d["traj_ref"]), t(d["u_ref"]), t(d["obs"])
+    ul = torch.zeros((B, N, 5), dtype=torch.float64, device=dev)
+    ref = eng.solve_batch_device(xi, tr, ur, ul, ob)
+    torch.cuda.synchronize()
+    ref = {k: v.clone() for k, v in ref.items()}
+    long = ref["iters"] > 24
+    assert 0 < int(long.sum()) < B // 4
+    eng.set_iteration_budget(24)
+    out = eng.solve_batch_device(xi, tr, ur, ul, ob)
+    torch.cuda.synchronize()
+    assert eng.suspended_count() == int(long.sum())
+    assert bool((out["status"][long] == 3).all()) and bool((out["status"][~long] == 0).all())
+    assert bool((out["iters"][long] == 24).all())
+    assert torch.equal(out["X"][~long], ref["X"][~long]) and torch.equal(out["iters"][~long], ref["iters"][~long])
+    eng.resume_batch_device(xi, tr, ur, ul, ob, out=out)
+    torch.cuda.synchronize()
+    for k in ("X", "U", "s", "status", "iters", "cost", "err"):
+        assert torch.equal(out[k], ref[k]), k
+    # host-pointer entry point: budgeted main launch + continuation inside the call
+    r = ctrl.solve_batch(d["x_init"], d["traj_ref"], d["u_ref"], d["obs"])
+    assert (r["status"] == 0).all() and np.array_equal(r["X"], ref["X"].cpu().numpy())
+    eng.set_iteration_budget(0)
+    with pytest.raises(RuntimeError):
+        mm.MPCWholeBody(mm.MobileManipulator(0.1), [], [], N=12, max_batch=4, n_obstacles=2)._engine.set_iteration_budget(8)   # generic kernel
