@@ -350,7 +350,9 @@ struct MmpcLogAcc {
     MMPC_DEV double value() const { int e = ex; const double l = mmpc_log_mant(mant, &e); return l + (double)e * 0.69314718055994530942; }
 };
 
-template <int KIND, int N, int MC>
+// CONT: built with the iteration budget / continuation code (a separate instantiation: the extra live values cost the
+// default kernel registers it does not have)
+template <int KIND, int N, int MC, bool CONT = false>
 MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds MMPC_EMU_ARG) {
     typedef MmpcFastDims<KIND, N> F;
     typedef MmpcTab<KIND> TB;
@@ -598,13 +600,15 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
     double E0 = 0.0, th_max = 0.0, th_min = 0.0;
     // save area of a suspended solve (layout: mmpc_fast_state_doubles)
     constexpr int MCS = MC > 0 ? MC : 1, NLREG = 2 * NPASS + 2 * MCS + 8;
-    double *const st_xu = io.state, *const st_s = io.state + NPAIR, *const st_lam = io.state + NPAIR + NS,
-           *const st_filt = io.state + NPAIR + NS + NS * NX, *const st_scal = st_filt + 2 * MMPC_FCAP,
-           *const st_lane = st_scal + MMPC_NSCAL;
+    // (offsets into io.state; the pointers are formed where they are used so that nothing of this stays live in the loop)
+    constexpr int ST_S = NPAIR, ST_LAM = NPAIR + NS, ST_FILT = NPAIR + NS + NS * NX, ST_SCAL = ST_FILT + 2 * MMPC_FCAP,
+                  ST_LANE = ST_SCAL + MMPC_NSCAL;
     int nsmall_r = 0;
     double prox_r = 0.0;
-    if (io.resume) {
+    if (CONT && io.resume) {
         // ---- continue a suspended solve: the state the uninterrupted loop would hold at this point
+        const double *const st_xu = io.state, *const st_s = io.state + ST_S, *const st_lam = io.state + ST_LAM,
+                     *const st_filt = io.state + ST_FILT, *const st_scal = io.state + ST_SCAL, *const st_lane = io.state + ST_LANE;
         LANES_BEGIN
         auto &ls = MMPC_LS;
         for (int i = lane; i < NPAIR; i += MMPC_WAVE) XU[i] = st_xu[i];
@@ -622,7 +626,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
         mu = st_scal[0]; th_max = st_scal[1]; th_min = st_scal[2]; prox_r = st_scal[3];
         it = (int)st_scal[4]; nfilt = (int)st_scal[5]; filt_init = (int)st_scal[6]; nsmall_r = (int)st_scal[7];
     }
-    const int it_start = it;
+    const int it_start = CONT ? it : 0;
     // results of the evaluation of the current point (iterate or line-search trial)
     double err_d = 0.0, err_p = 0.0, tzmax = 0.0, tzmin = 0.0, zsum = 0.0, cost_c = 0.0, th_c = 0.0, sumlog = 0.0;
     // line-search state: the evaluation of a trial point IS the evaluation the next iteration starts from (98.6 % of the
@@ -864,9 +868,11 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
             status = 2; break; }
         if (E0 <= tol) { status = 0; break; }
         if (it == P.max_iter) break;
-        if (io.budget > 0 && it - it_start >= io.budget && io.state) {
+        if (CONT && io.budget > 0 && it - it_start >= io.budget && io.state) {
             // ---- iteration budget of this launch used up: park the solve (the point has just been evaluated and is not
             //      converged; a resumed launch re-evaluates it and continues with the barrier update below)
+            double *const st_xu = io.state, *const st_s = io.state + ST_S, *const st_lam = io.state + ST_LAM,
+                   *const st_filt = io.state + ST_FILT, *const st_scal = io.state + ST_SCAL, *const st_lane = io.state + ST_LANE;
             LANES_BEGIN
             auto &ls = MMPC_LS;
             for (int i = lane; i < NPAIR; i += MMPC_WAVE) st_xu[i] = XU[i];

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(MMPC_WAVE) void mmpc_solve_kernel(
 }
 
 // WPE = waves per SIMD the register allocation is sized for (2: <= 256 registers, only pays when LDS allows >4 problems/CU)
-template <int KIND, int N, int MC, int WPE>
+template <int KIND, int N, int MC, int WPE, bool CONT>
 __global__ __launch_bounds__(MMPC_WAVE, WPE) void mmpc_fast_kernel(
     const MmpcParams *__restrict__ Pp, int B, const double *__restrict__ x_init, const double *__restrict__ traj_ref,
     const double *__restrict__ u_ref, const double *__restrict__ u_last, const double *__restrict__ x_guess,
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(MMPC_WAVE, WPE) void mmpc_fast_kernel(
     io.state = state ? state + (size_t)b * state_stride : nullptr;
     io.budget = budget;
     io.resume = resume_count ? 1 : 0;
-    mmpc_solve_fast<KIND, N, MC>(P, io, lds);
+    mmpc_solve_fast<KIND, N, MC, CONT>(P, io, lds);
 }
 
 // (kind, N, M) triples with a specialised kernel; everything else runs the generic kernel.
@@ -325,8 +325,9 @@ extern "C" int mmpc_create(const mmpc_config *cfg, mmpc_handle *out) {
             h->fast = 1;                                                                                               \
             h->state_doubles = mmpc_fast_state_doubles<K, NN>(MM);                                                     \
             h->fast_lds_bytes = mmpc_fast_layout<K, NN>(MM, p.obs_per_stage).total * (int)sizeof(double);         \
-            HIPCHK(h, hipFuncSetAttribute((const void *)mmpc_fast_kernel<K, NN, MM, WW>, hipFuncAttributeMaxDynamicSharedMemorySize, h->fast_lds_bytes)); \
-            HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&h->fast_per_cu, mmpc_fast_kernel<K, NN, MM, WW>, MMPC_WAVE, h->fast_lds_bytes)); \
+            HIPCHK(h, hipFuncSetAttribute((const void *)mmpc_fast_kernel<K, NN, MM, WW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, h->fast_lds_bytes)); \
+            HIPCHK(h, hipFuncSetAttribute((const void *)mmpc_fast_kernel<K, NN, MM, WW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, h->fast_lds_bytes)); \
+            HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&h->fast_per_cu, mmpc_fast_kernel<K, NN, MM, WW, false>, MMPC_WAVE, h->fast_lds_bytes)); \
         }
         MMPC_FAST_LIST(MMPC_X)
 #undef MMPC_X
@@ -434,10 +435,16 @@ static int launch(mmpc_handle h, int B, const double *x_init, const double *traj
     const int *order = (history || (lpt && h->cfg.M > 0)) ? h->d_order : nullptr;
     if (use_fast) {
 #define MMPC_X(K, NN, MM, WW)                                                                                          \
-        if (h->cfg.kind == K && h->cfg.N == NN && h->cfg.M == MM)                                                                          \
-            hipLaunchKernelGGL((mmpc_fast_kernel<K, NN, MM, WW>), dim3(B), dim3(MMPC_WAVE), h->fast_lds_bytes, st, h->dp, B, x_init, traj, \
-                               uref, ulast, xguess, obs, X, U, s, status, iters, cost, err, resume ? h->d_list : order,          \
-                               resume ? 0 : h->budget, h->d_state, h->state_doubles, resume ? h->d_count : (const int *)nullptr);
+        if (h->cfg.kind == K && h->cfg.N == NN && h->cfg.M == MM) {                                                                        \
+            if (resume || h->budget > 0)                                                                                               \
+                hipLaunchKernelGGL((mmpc_fast_kernel<K, NN, MM, WW, true>), dim3(B), dim3(MMPC_WAVE), h->fast_lds_bytes, st, h->dp, B,     \
+                                   x_init, traj, uref, ulast, xguess, obs, X, U, s, status, iters, cost, err, resume ? h->d_list : order, \
+                                   resume ? 0 : h->budget, h->d_state, h->state_doubles, resume ? h->d_count : (const int *)nullptr);   \
+            else                                                                                                                       \
+                hipLaunchKernelGGL((mmpc_fast_kernel<K, NN, MM, WW, false>), dim3(B), dim3(MMPC_WAVE), h->fast_lds_bytes, st, h->dp, B,    \
+                                   x_init, traj, uref, ulast, xguess, obs, X, U, s, status, iters, cost, err, order, 0,                  \
+                                   (double *)nullptr, 0, (const int *)nullptr);                                                         \
+        }
         MMPC_FAST_LIST(MMPC_X)
 #undef MMPC_X
     } else if (h->cfg.kind == MMPC_KIND_WHOLEBODY)

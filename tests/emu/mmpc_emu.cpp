@@ -69,7 +69,7 @@ static void run_fast(const MmpcParams *P, int B, const double *x_init, const dou
         io.state = state ? state + (size_t)b * sd : nullptr; io.budget = budget; io.resume = resume;
         if (resume && status[b] != 3) { free(lds); continue; }   // a continuation launch only runs the suspended instances
         MmpcEmu emu = reverse ? MmpcEmu{63, -1, -1} : MmpcEmu{0, 64, 1};
-        mmpc_solve_fast<KIND, N, MC>(*P, io, lds, emu);
+        if (budget > 0 || resume) mmpc_solve_fast<KIND, N, MC, true>(*P, io, lds, emu); else mmpc_solve_fast<KIND, N, MC, false>(*P, io, lds, emu);
         free(lds);
     }
 }
