@@ -35,10 +35,11 @@ def test_wholebody_other_shapes(mm, N, M):
     d = synth.make_batch(B, N=N, M=M, config_id=40 + M)
     ctrl = _wb(mm, N, M, B)
     r = ctrl.solve_batch(d["x_init"], d["traj_ref"], d["u_ref"], d["obs"])
-    o = coracle.solve_batch(nlp.WholeBodyParams(N=N), d["x_init"], d["traj_ref"], d["u_ref"], np.zeros((B, N, 5)), d["obs"], nthreads=8)
+    o = coracle.solve_batch(nlp.WholeBodyParams(N=N), d["x_init"], d["traj_ref"], d["u_ref"], np.zeros((B, N, 5)), d["obs"], nthreads=8,
+                            max_iter=2000)
     assert (r["status"] == 0).all() and (o["status"] == 0).all()
     same = np.abs(r["cost"] / o["cost"] - 1) < 1e-6
-    assert same.mean() >= 0.98
+    assert same.mean() >= 0.98 and (r["cost"][~same] <= 1.05 * o["cost"][~same]).all()      # at most 1 of 96 in another minimum, not a worse one
     assert np.abs(r["X"][same] - o["X"][same]).max() < TOL and np.abs(r["U"][same] - o["U"][same]).max() < TOL
 
 
@@ -90,13 +91,15 @@ def test_wholebody_c5_moving_obstacles(mm):
     # three resident problems per CU (include/mmpc.h: mmpc_problems_per_cu, mmpc_lds_bytes)
     assert ctrl._engine.lds_bytes <= 160 * 1024 // 3 and ctrl._engine.problems_per_cu == 3
     r = ctrl.solve_batch(d["x_init"], d["traj_ref"], d["u_ref"], obs)
-    o = coracle.solve_batch(nlp.WholeBodyParams(N=30), d["x_init"], d["traj_ref"], d["u_ref"], np.zeros((B, 30, 5)), obs, nthreads=8)
-    ok = (r["status"] == 0) & (o["status"] == 0)
-    assert ok.mean() > 0.95
+    o = coracle.solve_batch(nlp.WholeBodyParams(N=30), d["x_init"], d["traj_ref"], d["u_ref"], np.zeros((B, 30, 5)), obs, nthreads=8,
+                            max_iter=2000)
+    assert (r["status"] == 0).all() and (o["status"] == 0).all()
     # moving obstacles make some instances two-sided (pass in front of / behind an obstacle): implementations that differ in
-    # the last bit can settle in different local minima there.  Those are recognised by their cost and must be rare.
-    same = ok & (np.abs(r["cost"] / o["cost"] - 1) < 1e-6)
-    assert same.mean() > 0.9
+    # the last bit can settle in different local minima there.  Those are recognised by their cost, must be rare, and the
+    # GPU's minimum must not be the worse one by more than 5 % (tests/test_gpu_certificates.py certifies every instance of
+    # the larger batch)
+    same = np.abs(r["cost"] / o["cost"] - 1) < 1e-6
+    assert same.mean() >= 0.97 and (r["cost"][~same] <= 1.05 * o["cost"][~same]).all()
     assert np.abs(r["X"][same] - o["X"][same]).max() < 1e-5 and np.abs(r["U"][same] - o["U"][same]).max() < 1e-5
 
 
@@ -253,10 +256,10 @@ def test_closed_loop_moving_obstacles_c5(mm):
     for tick in range(4):
         obs_now = loop.obstacles_now()
         loc, lu = iw.calc_local_ref_traj(x, loop.traj_ref, loop.u_ref, N)
-        o = coracle.solve_batch(par, x, loc, lu, ul, obs_now, nthreads=8)
+        o = coracle.solve_batch(par, x, loc, lu, ul, obs_now, nthreads=8, max_iter=2000)
         r = loop.step()
         ok = o["status"] == 0
-        assert ok.mean() > 0.9
+        assert ok.all() and (r["status"] == 0).all()
         assert np.abs(r["U"][ok] - o["U"][ok]).max() < 1e-5
         ul = o["U"]
         x = np.array([coracle.f("wholebody", 0.1, np.clip(x[b], par.xlim[0], par.xlim[1]), o["U"][b, 0]) for b in range(B)])
