@@ -282,6 +282,24 @@ def main():
                                    "note": "main launch: every instance gets at most 32 iterations; continuation: the suspended "
                                            "instances run to convergence; outputs bitwise equal to the single launch"}
             eng.set_iteration_budget(0)
+            # (1c) the generic kernel (any N, M, dense weights, half-space rows, terminal equality - what C1 and the closed-loop
+            # demo's 'approach' / 'manipulate' phases run on) on the same batch, for scale
+            os.environ["MMPC_FORCE_GENERIC"] = "1"
+            try:
+                ctrlg = mm.MPCWholeBody(robot, [], [], N=N, max_batch=Bl, device=local_dev, n_obstacles=M)
+            finally:
+                del os.environ["MMPC_FORCE_GENERIC"]
+            ctrlg._engine.set_schedule_hint(2)
+            outg = ctrlg._engine.solve_batch_device(x_init, traj, uref, ulast, obs)
+            ev0.record()
+            outg = ctrlg._engine.solve_batch_device(x_init, traj, uref, ulast, obs, out=outg)
+            ev1.record(); ev1.synchronize()
+            g_ms = ev0.elapsed_time(ev1)
+            res["generic_kernel"] = {"ms": g_ms, "value": Bl / (g_ms * 1e-3), "unit": "solves/s",
+                                     "lds_bytes_per_problem": ctrlg._engine.lds_bytes, "problems_per_cu": ctrlg._engine.problems_per_cu,
+                                     "max_abs_dX_vs_specialised": float((outg["X"] - out["X"]).abs().max()),
+                                     "note": "mmpc_solve_kernel<0> (all state in LDS, scalar Riccati) on the same batch"}
+            del ctrlg, outg
             # (2) two batches in flight (two handles, two HIP streams, alternating): the drain of one launch - waves still
             # iterating on its slowest instances while CUs idle - is filled by the next launch.  No hint.
             eng.set_schedule_hint(2)

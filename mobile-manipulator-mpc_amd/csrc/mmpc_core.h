@@ -145,11 +145,22 @@ struct MmpcDims {
     static constexpr int NUU = NU * (NU + 1) / 2;
 };
 
+// per-launch constants kept in LDS (WTS block): the weights and the limits.  Read through the parameter block they are
+// scalar loads that LLVM hoists out of every loop - several hundred live SGPRs, most of them spilled
+#define MMPC_W_Q2 0      // [81]
+#define MMPC_W_P2 81     // [81]
+#define MMPC_W_RW2 162   // [25]
+#define MMPC_W_R2 187    // [25]
+#define MMPC_W_W2 212    // [25]
+#define MMPC_W_XLIM 237  // [2][9]
+#define MMPC_W_ULIM 255  // [2][5]
+#define MMPC_W_DULIM 265 // [2][5]
+#define MMPC_W_SIZE 276
 // LDS slab layout (offsets in doubles).  Shared by host (size query) and device.
 struct MmpcLayout {
     int X, U, S, LAM, XREF, UREF, ULAST, OBS, T, Z, HR, DTR, GC, HC, GSF, CV, CD, GX, GU, HXX, QX, HUXL, HUUL,
         HUX02, HUUD, QU, HSS, GSS, VX, VXN, KK, KF, DX, DU, DS, DLAM, PF, TT, PC, MF, MG, MH, MGX, MGU, RED, FILT,
-        MISC, PNU, PNUS, KFV, GNU, FWV, NUEQ, GHS, total;
+        MISC, PNU, PNUS, KFV, GNU, FWV, NUEQ, GHS, WTS, total;
     int R, NR;
 };
 
@@ -178,7 +189,7 @@ MMPC_HD MmpcLayout mmpc_layout(int N, int M, int obs_per_stage, int nhs = 0) {
     MMPC_CARVE(RED, 8 * MMPC_WAVE) MMPC_CARVE(FILT, 2 * MMPC_FCAP) MMPC_CARVE(MISC, 8)
     // terminal xy equality (interface_wholebody_qref.py:166-167): multiplier sensitivities
     MMPC_CARVE(PNU, D::NX * 2) MMPC_CARVE(PNUS, NS * D::NX * 2) MMPC_CARVE(KFV, N * D::NU * 2) MMPC_CARVE(GNU, D::NV * 2)
-    MMPC_CARVE(FWV, 2 * 3 * D::NX) MMPC_CARVE(NUEQ, 4) MMPC_CARVE(GHS, NS * nhs * 6)
+    MMPC_CARVE(FWV, 2 * 3 * D::NX) MMPC_CARVE(NUEQ, 4) MMPC_CARVE(GHS, NS * nhs * 6) MMPC_CARVE(WTS, MMPC_W_SIZE)
 #undef MMPC_CARVE
     L.total = o;
     return L;
@@ -338,11 +349,11 @@ struct MmpcTab<1> {
 //   KIND 2: e = endpoint pose (x + R cos psi, y + R sin psi, Z, psi) - ref (controllers/mpc_wholebody.py:79-80,104-106 with
 //           mobile_manipulator.py:36-53), W2 is 4x4 (leading dimension 4); Hessian = J^T W2 J + sum_c (W2 e)_c d2E_c.
 template <int KIND>
-MMPC_DEV double mmpc_state_cost(const MmpcParams &P, bool terminal, const double *xk, const double *ref, double *grad,
+MMPC_DEV double mmpc_state_cost(const double *WTS, bool terminal, const double *xk, const double *ref, double *grad,
                                 double *hxx, bool exact) {
     typedef MmpcDims<KIND> D;
     constexpr int NX = D::NX;
-    const double *W2 = terminal ? P.P2 : P.Q2;
+    const double *W2 = WTS + (terminal ? MMPC_W_P2 : MMPC_W_Q2);
     if constexpr (KIND != 2) {
         double e[NX], q = 0.0;
         for (int j = 0; j < NX; j++) e[j] = xk[j] - ref[j];
@@ -399,15 +410,19 @@ MMPC_DEV double mmpc_state_cost(const MmpcParams &P, bool terminal, const double
 // ------------------------------------------------------------------------------------------
 // The solver.  `lds` points at this problem's slab of mmpc_layout<KIND>(N,M,..).total doubles.
 // ------------------------------------------------------------------------------------------
-template <int KIND>
+// NC, MC, OPSC, LC: horizon, circle obstacles, per-stage obstacle table and number of half-space planes as compile-time
+// constants (0 / -1: taken from P at run time).  With run-time sizes the 54 LDS offsets of the layout are live scalars for
+// the whole solve - they spill to vector lanes, and those to scratch; instantiated for a shape they are constants.
+template <int KIND, int NC = 0, int MC = -1, int OPSC = -1, int LC = -1>
 MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds MMPC_EMU_ARG) {
     typedef MmpcDims<KIND> D;
     typedef MmpcTab<KIND> TB;
     constexpr int NX = D::NX, NU = D::NU, NSELF = D::NSELF, NV = D::NV, NXX = D::NXX, NUU = D::NUU;
-    const int N = P.N, M = P.M, NS = N + 1;
-    const int NHS = (KIND == 0 && P.L > 0) ? 6 : 0;
+    const int N = NC ? NC : P.N, M = MC >= 0 ? MC : P.M, NS = N + 1;
+    const int OPS = OPSC >= 0 ? OPSC : P.obs_per_stage, PL = LC >= 0 ? LC : P.L;
+    const int NHS = (KIND == 0 && PL > 0) ? 6 : 0;
     constexpr int NREF = D::NREF;
-    const MmpcLayout L = mmpc_layout<KIND>(N, M, P.obs_per_stage, NHS);
+    const MmpcLayout L = mmpc_layout<KIND>(N, M, OPS, NHS);
     const int R = L.R, NR = L.NR;
     double *X = lds + L.X, *U = lds + L.U, *S = lds + L.S, *LAM = lds + L.LAM, *XREF = lds + L.XREF,
            *UREF = lds + L.UREF, *ULAST = lds + L.ULAST, *OBS = lds + L.OBS, *T = lds + L.T, *Z = lds + L.Z,
@@ -420,6 +435,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
            *MF = lds + L.MF, *MG = lds + L.MG, *MH = lds + L.MH, *MGX = lds + L.MGX, *MGU = lds + L.MGU,
            *RED = lds + L.RED, *FILT = lds + L.FILT, *MISC = lds + L.MISC, *PNU = lds + L.PNU, *PNUS = lds + L.PNUS,
            *KFV = lds + L.KFV, *GNU = lds + L.GNU, *FWV = lds + L.FWV, *NUEQ = lds + L.NUEQ, *GHS = lds + L.GHS;
+    double *const WTS = lds + L.WTS;
     const bool teq = P.terminal_xy_eq != 0;
     const int SL_UHI = NU, SL_XLO = 2 * NU, SL_XHI = 2 * NU + NX, SL_C = 2 * NU + 2 * NX, SL_S = SL_C + M, SL_H = SL_S + NSELF;
     const double dt = P.dt, Sw = P.S, tol = P.tol;
@@ -430,26 +446,41 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
             if (k >= N) return false;
             const int j = r < NU ? r : r - NU;
             const double ul = ULAST[k * NU + j];
-            if (r < NU) b = mmpc_max(P.ulim[0][j], ul + P.dulim[0][j]);
-            else b = mmpc_min(P.ulim[1][j], ul + P.dulim[1][j]);
+            if (r < NU) b = mmpc_max(WTS[MMPC_W_ULIM + j], ul + WTS[MMPC_W_DULIM + j]);
+            else b = mmpc_min(WTS[MMPC_W_ULIM + 5 + j], ul + WTS[MMPC_W_DULIM + 5 + j]);
         } else {
             if (k < 1) return false;
             const int q = r - SL_XLO;
-            b = q < NX ? P.xlim[0][q] : P.xlim[1][q - NX];
+            b = q < NX ? WTS[MMPC_W_XLIM + q] : WTS[MMPC_W_XLIM + 9 + q - NX];
         }
         return mmpc_finite(b);
     };
     auto obs_ptr = [&](int k, int m) -> const double * {
-        return OBS + ((P.obs_per_stage ? k * M : 0) + m) * 3;
+        return OBS + ((OPS ? k * M : 0) + m) * 3;
     };
     auto slack_idx = [&](int k) -> int { return k < N - 1 ? k : N - 1; };  // :265 quirk (Q1)
 
+    // ---------------------------------------------------------------- per-launch constants -> LDS
+    LANES_BEGIN
+    for (int i = lane; i < MMPC_W_SIZE; i += MMPC_WAVE) {
+        double v;
+        if (i < MMPC_W_P2) v = P.Q2[i];
+        else if (i < MMPC_W_RW2) v = P.P2[i - MMPC_W_P2];
+        else if (i < MMPC_W_R2) v = P.RW2[i - MMPC_W_RW2];
+        else if (i < MMPC_W_W2) v = P.R2[i - MMPC_W_R2];
+        else if (i < MMPC_W_XLIM) v = P.W2[i - MMPC_W_W2];
+        else if (i < MMPC_W_ULIM) v = P.xlim[(i - MMPC_W_XLIM) / 9][(i - MMPC_W_XLIM) % 9];
+        else if (i < MMPC_W_DULIM) v = P.ulim[(i - MMPC_W_ULIM) / 5][(i - MMPC_W_ULIM) % 5];
+        else v = P.dulim[(i - MMPC_W_DULIM) / 5][(i - MMPC_W_DULIM) % 5];
+        WTS[i] = v;
+    }
+    LANES_END
     // ---------------------------------------------------------------- load + initial point
     LANES_BEGIN
     for (int i = lane; i < NS * NX; i += MMPC_WAVE) {
         const int j = i % NX;
         double x0 = io.x_init[j];
-        if (KIND != 1) x0 = mmpc_max(mmpc_min(x0, P.xlim[1][j]), P.xlim[0][j]);  // :290-291
+        if (KIND != 1) x0 = mmpc_max(mmpc_min(x0, WTS[MMPC_W_XLIM + 9 + j]), WTS[MMPC_W_XLIM + j]);  // :290-291
         if (i < NS * NREF) XREF[i] = io.traj_ref[i];
         X[i] = (io.x_guess && i >= NX) ? io.x_guess[i] : x0;  // :302 / mpc_base.py:200
         LAM[i] = 0.0;
@@ -461,7 +492,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
     }
     for (int i = lane; i < NS; i += MMPC_WAVE) S[i] = 0.0;  // :304
     if (lane < 4) NUEQ[lane] = 0.0;
-    for (int i = lane; i < (P.obs_per_stage ? NS : 1) * M * 3; i += MMPC_WAVE) OBS[i] = io.obs[i];
+    for (int i = lane; i < (OPS ? NS : 1) * M * 3; i += MMPC_WAVE) OBS[i] = io.obs[i];
     LANES_END
     // bound push of the initial point (needs U_last of the previous phase for the merged input box)
     LANES_BEGIN
@@ -546,7 +577,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
             // cost gradient (mpc_wholebody_qref.py:192-201,240-242; mpc_base.py:146-153)
             {
                 double g[NX];
-                mmpc_state_cost<KIND>(P, k == N, xk, XREF + k * NREF, g, nullptr, false);
+                mmpc_state_cost<KIND>(WTS, k == N, xk, XREF + k * NREF, g, nullptr, false);
                 for (int i = 0; i < NX; i++) { GX[k * NX + i] = g[i]; rdx[i] = g[i] + (k >= 1 ? LAM[k * NX + i] : 0.0); }
             }
             double *cv = CV + k * MMPC_NCV;
@@ -571,7 +602,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                 for (int a = 0; a < NU; a++) {
                     double v = 0.0;
                     for (int b = 0; b < NU; b++)
-                        v += P.R2[a * NU + b] * (uk[b] - UREF[k * NU + b]) + P.W2[a * NU + b] * (uk[b] - ULAST[k * NU + b]);
+                        v += WTS[MMPC_W_R2 + a * NU + b] * (uk[b] - UREF[k * NU + b]) + WTS[MMPC_W_W2 + a * NU + b] * (uk[b] - ULAST[k * NU + b]);
                     GU[k * NU + a] = v;
                     rdu[a] = v;
                 }
@@ -702,7 +733,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
             LANES_BEGIN
             for (int k = lane; k < NS; k += MMPC_WAVE) {
                 double *hxx = HXX + k * NXX, *qx = QX + k * NX;
-                mmpc_state_cost<KIND>(P, k == N, X + k * NX, XREF + k * NREF, nullptr, hxx, exact);
+                mmpc_state_cost<KIND>(WTS, k == N, X + k * NX, XREF + k * NREF, nullptr, hxx, exact);
                 for (int j = 0; j < NX; j++) hxx[j * (j + 1) / 2 + j] += reg;
                 for (int j = 0; j < NX; j++) qx[j] = GX[k * NX + j];
                 if (k < N) {
@@ -881,7 +912,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                         MG[e2] = v;
                     } else if (e < NXX + NU * NX + NUU) {
                         const int e2 = e - NXX - NU * NX, a = kTriI[e2], b = kTriJ[e2], col = NX + a;
-                        double v = P.RW2[a * NU + b] + (a == b ? HUUD[k * NU + a] : 0.0) + (k == N - 1 ? HUUL[e2] : 0.0);
+                        double v = WTS[MMPC_W_RW2 + a * NU + b] + (a == b ? HUUD[k * NU + a] : 0.0) + (k == N - 1 ? HUUL[e2] : 0.0);
                         for (int q = 0; q < 4; q++) v += cv[TB::ccv(col, q)] * TT[TB::crow(col, q) * NV + NX + b];
                         MH[e2] = v;
                     } else {
@@ -1082,15 +1113,15 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
             const int ks = slack_idx(k);
             const double sks = S[ks] + alpha * DS[ks];
             double f = Sw * sk * sk, th = 0.0;
-            f += 0.5 * mmpc_state_cost<KIND>(P, k == N, xk, XREF + k * NREF, nullptr, nullptr, false);
+            f += 0.5 * mmpc_state_cost<KIND>(WTS, k == N, xk, XREF + k * NREF, nullptr, nullptr, false);
             double sn, cs;
             sincos(xk[2], &sn, &cs);
             if (k < N) {
                 for (int a = 0; a < NU; a++) uk[a] = U[k * NU + a] + alpha * DU[k * NU + a];
                 double q = 0.0;
                 for (int a = 0; a < NU; a++) for (int b = 0; b < NU; b++)
-                    q += (uk[a] - UREF[k * NU + a]) * P.R2[a * NU + b] * (uk[b] - UREF[k * NU + b])
-                       + (uk[a] - ULAST[k * NU + a]) * P.W2[a * NU + b] * (uk[b] - ULAST[k * NU + b]);
+                    q += (uk[a] - UREF[k * NU + a]) * WTS[MMPC_W_R2 + a * NU + b] * (uk[b] - UREF[k * NU + b])
+                       + (uk[a] - ULAST[k * NU + a]) * WTS[MMPC_W_W2 + a * NU + b] * (uk[b] - ULAST[k * NU + b]);
                 f += 0.5 * q;
                 double xn[NX];
                 xn[0] = xk[0] + dt * xk[3]; xn[1] = xk[1] + dt * xk[4]; xn[2] = xk[2] + dt * xk[5];
@@ -1269,12 +1300,12 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
     double f = 0.0;
     for (int k = lane; k < NS; k += MMPC_WAVE) {
         const double *xk = X + k * NX;
-        double q = mmpc_state_cost<KIND>(P, k == N, xk, XREF + k * NREF, nullptr, nullptr, false);
+        double q = mmpc_state_cost<KIND>(WTS, k == N, xk, XREF + k * NREF, nullptr, nullptr, false);
         if (k < N) {
             const double *uk = U + k * NU;
             for (int a = 0; a < NU; a++) for (int b = 0; b < NU; b++)
-                q += (uk[a] - UREF[k * NU + a]) * P.R2[a * NU + b] * (uk[b] - UREF[k * NU + b])
-                   + (uk[a] - ULAST[k * NU + a]) * P.W2[a * NU + b] * (uk[b] - ULAST[k * NU + b]);
+                q += (uk[a] - UREF[k * NU + a]) * WTS[MMPC_W_R2 + a * NU + b] * (uk[b] - UREF[k * NU + b])
+                   + (uk[a] - ULAST[k * NU + a]) * WTS[MMPC_W_W2 + a * NU + b] * (uk[b] - ULAST[k * NU + b]);
         }
         f += 0.5 * q + Sw * S[k] * S[k];
     }

@@ -13,7 +13,7 @@
 #include "mmpc_fast.h"
 #include "mmpc_ik.h"
 
-template <int KIND>
+template <int KIND, int NC = 0, int MC = -1, int OPSC = -1, int LC = -1>
 __global__ __launch_bounds__(MMPC_WAVE) void mmpc_solve_kernel(
     const MmpcParams *__restrict__ Pp, int B, const double *__restrict__ x_init, const double *__restrict__ traj_ref,
     const double *__restrict__ u_ref, const double *__restrict__ u_last, const double *__restrict__ x_guess,
@@ -26,8 +26,8 @@ __global__ __launch_bounds__(MMPC_WAVE) void mmpc_solve_kernel(
     // longest-first schedule hint: workgroup i solves instance order[i] (a permutation; results do not depend on it)
     const int b = order ? order[blockIdx.x] : (int)blockIdx.x;
     const MmpcParams &P = *Pp;
-    const int N = P.N, M = P.M;
-    const size_t so = (size_t)(P.obs_per_stage ? N + 1 : 1) * M * 3;
+    const int N = NC ? NC : P.N, M = MC >= 0 ? MC : P.M;
+    const size_t so = (size_t)((OPSC >= 0 ? OPSC : P.obs_per_stage) ? N + 1 : 1) * M * 3;
     MmpcIO io;
     io.x_init = x_init + (size_t)b * D::NX;
     io.traj_ref = traj_ref + (size_t)b * (N + 1) * D::NREF;
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(MMPC_WAVE) void mmpc_solve_kernel(
     io.cost = cost + b;
     io.err = err + b;
     io.state = nullptr; io.budget = 0; io.resume = 0;   // (iteration budgets are a feature of the specialised kernels)
-    mmpc_solve_one<KIND>(P, io, lds);
+    mmpc_solve_one<KIND, NC, MC, OPSC, LC>(P, io, lds);
 }
 
 // WPE = waves per SIMD the register allocation is sized for (2: <= 256 registers, only pays when LDS allows >4 problems/CU)
@@ -267,8 +267,9 @@ extern "C" int mmpc_debug_read_stamps(unsigned long long *out16) {
 extern "C" const char *mmpc_version(void) { return "mmpc 0.1 (gfx950)"; }
 static thread_local char g_err[512] = "";   // errors of the handle-less entry points (mmpc_ik_*)
 extern "C" const char *mmpc_last_error(mmpc_handle h) { return h ? h->err : g_err; }
-extern "C" int mmpc_problems_per_cu(mmpc_handle h) { return h ? ((h->fast && h->diag && !h->hp.terminal_xy_eq) ? h->fast_per_cu : h->per_cu) : MMPC_E_ARG; }
-extern "C" int mmpc_lds_bytes(mmpc_handle h) { return h ? ((h->fast && h->diag && !h->hp.terminal_xy_eq) ? h->fast_lds_bytes : h->lds_bytes) : MMPC_E_ARG; }
+static bool runs_fast(mmpc_handle h) { return h->fast && h->diag && !h->hp.terminal_xy_eq && !h->force_generic_env; }
+extern "C" int mmpc_problems_per_cu(mmpc_handle h) { return h ? (runs_fast(h) ? h->fast_per_cu : h->per_cu) : MMPC_E_ARG; }
+extern "C" int mmpc_lds_bytes(mmpc_handle h) { return h ? (runs_fast(h) ? h->fast_lds_bytes : h->lds_bytes) : MMPC_E_ARG; }
 
 extern "C" int mmpc_create(const mmpc_config *cfg, mmpc_handle *out) {
     if (!cfg || !out) return MMPC_E_ARG;
