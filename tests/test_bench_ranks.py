@@ -19,6 +19,21 @@ def _free_port():
 
 
 @pytest.mark.gpu
+def test_two_rank_strong_scaling_u0_gather():
+    """--scaling strong (global batch fixed, contiguous slices of one seeded batch) with the u0-only all-gather."""
+    env = dict(os.environ, MMPC_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "2048", "--scaling", "strong", "--gather", "u0"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["batch_per_gpu"] == 1024 and d["config"]["seeds"] == [3]
+    assert "all-gather(u0)" in d["config"]["parallelism"] and [p_["batch"] for p_ in d["per_rank"]] == [1024, 1024]
+    assert d["solver"]["converged_frac"] == 1.0 and abs(d["value"] - 2048 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+
+
+@pytest.mark.gpu
 def test_two_rank_bench_line():
     env = dict(os.environ, MMPC_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
