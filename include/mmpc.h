@@ -61,8 +61,12 @@ typedef struct mmpc_config {
     int L;             /* half-space ("manipulation") obstacles, 0..8: len(obstacle_manipulation_list)
                           (mpc_wholebody_qref.py:10,39; demo_wholebody_qref.py:21-33); whole-body kind only */
     double halfspace[8][6]; /* per obstacle: point (3), outward normal (3).  One row per (stage, arm sample point):
-                          -max_j n_j.((p_j - 0.03 n_j) - P_i) <= s_k, the INTENDED form of obsAvoidConvex (:57-89);
-                          the stale/free `constr` entries of the as-written L>=2 code path are not reproduced */
+                          -max_j n_j.((p_j - 0.03 n_j) - P_i) <= s_k, the INTENDED form of obsAvoidConvex (:57-89) */
+    int as_written;    /* L >= 2: the NLP AS WRITTEN - obsAvoidConvex calls subject_to inside its plane loop and keeps one `constr`
+                          matrix for all stages (:77-89,156), so besides the intended row it emits, per (stage k >= 1, point i,
+                          j < L-1):  -max(c_{k,i,0..j}, c_{k-1,i,j+1..L-1}) <= s_k  (the entries j' > j still hold the PREVIOUS
+                          stage's expressions; at k = 0 they hold free variables that can always satisfy the row).  These rows
+                          tie x_k to x_{k-1}; the generic kernel carries them.  0: intended rows only */
 } mmpc_config;
 
 typedef struct mmpc_handle_s *mmpc_handle;

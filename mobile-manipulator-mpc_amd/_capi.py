@@ -18,7 +18,7 @@ class MmpcConfig(C.Structure):
                 ("max_batch", C.c_int), ("device", C.c_int), ("max_iter", C.c_int),
                 ("dt", C.c_double), ("tol", C.c_double), ("mu_init", C.c_double),
                 ("ulim", (C.c_double * 5) * 2), ("xlim", (C.c_double * 9) * 2), ("dulim", (C.c_double * 5) * 2),
-                ("L", C.c_int), ("halfspace", (C.c_double * 6) * 8)]
+                ("L", C.c_int), ("halfspace", (C.c_double * 6) * 8), ("as_written", C.c_int)]
 
 
 EXPORTS = ["mmpc_create", "mmpc_destroy", "mmpc_set_weights", "mmpc_set_terminal_xy_equality", "mmpc_reset",
@@ -98,7 +98,7 @@ class Engine:
     """Owns one mmpc_handle (one controller's NLP structure on one GPU)."""
 
     def __init__(self, kind, N, M, dt, ulim, xlim, dulim, max_batch=1, device=0, obs_per_stage=False,
-                 tol=1e-8, mu_init=1.0, max_iter=2000, halfspaces=None):
+                 tol=1e-8, mu_init=1.0, max_iter=2000, halfspaces=None, as_written=False):
         self.kind, self.N, self.M = kind, int(N), int(M)
         self.nx, self.nu = (6, 2) if kind == KIND_BASE else (9, 5)
         self.nref = 4 if kind == KIND_WHOLEBODY_POSE else self.nx      # reference row: endpoint pose (x,y,z,psi) or the state
@@ -115,6 +115,7 @@ class Engine:
             for j in range(9):
                 cfg.xlim[r][j] = xlim[r, j] if j < self.nx else 0.0
         cfg.L = 0
+        cfg.as_written = int(bool(as_written))
         if halfspaces is not None and len(halfspaces):
             hs = np.asarray(halfspaces, float).reshape(-1, 6)
             if hs.shape[0] > 8:

@@ -7,11 +7,11 @@ matrix `constr` for all stages (:156), so for L >= 2 planes it emits L rows per 
 
 where a stale entry is the free decision variable `constr[i, j']` at k = 0 (such a row can always be met by that variable and
 never restricts (X, U, s)) and the PREVIOUS stage's expression c_{k-1,i,j'} for k >= 1.  Row j = L-1 is the intended row
--max_j c_{k,i,j} <= s_k, which the kernels carry.  The rows j < L-1 of the stages k >= 1 couple x_k with x_{k-1}; they are not
-in the kernels.  What this module provides is their evaluation: a solution of the intended NLP that satisfies every one of
-them is a KKT point of the NLP as written (the extra rows take zero multipliers, the free entries any large value), and
-the controller returns it; one that violates any of them is refused (RuntimeError) rather than passed off as the
-reference's answer.
+-max_j c_{k,i,j} <= s_k.  The rows j < L-1 of the stages k >= 1 couple x_k with x_{k-1}; the generic kernel carries them
+(mmpc_config.as_written: a row whose previous-stage entry attains the max acts on x_{k-1}, and a slack s_k that reaches back
+is eliminated one stage earlier through the linearised dynamics, csrc/mmpc_core.h).  This module is their plain evaluation
+on the host: the controller re-checks every returned solution against it (post-condition), the tests use it to show how the
+intended and the as-written NLP differ.
 """
 import numpy as np
 

@@ -40,13 +40,12 @@ class MPCWholeBody:
         self.obstacle_manipulation_list = obstacle_manipulation_list
         self.endpoint_self_collision_radius = 0.05   # mpc_wholebody_qref.py:43
         self.obstacle_expand_dist = 0.03             # :44
-        # half-space ("manipulation") obstacles, mpc_wholebody_qref.py:57-89.  The kernels carry one row per (stage, arm
-        # sample point): -max_j n_j.((p_j - 0.03 n_j) - P_i) <= s_k - for L >= 2 that is the LAST of the L rows the reference
-        # as written emits per point; the other L-1 read stale / free `constr` entries (see _q8.py).
-        # Default (faithful_convex None / True): the NLP as written - after every solve the extra rows are evaluated on the
-        # host; a solution that satisfies them all is a KKT point of the as-written NLP and is returned, one that does not
-        # is refused (RuntimeError; batched calls mark it _capi.STATUS_Q8_REFUSED).  faithful_convex=False: the intended rows only,
-        # no check.  L = 1 has no extra rows.
+        # half-space ("manipulation") obstacles, mpc_wholebody_qref.py:57-89.  For L >= 2 planes the reference AS WRITTEN emits L
+        # rows per (stage, arm sample point): the last is the intended -max_j n_j.((p_j - 0.03 n_j) - P_i) <= s_k, the other L-1
+        # read the previous stage's `constr` entries (see _q8.py) and tie x_k to x_{k-1}.
+        # Default (faithful_convex None / True): the NLP as written - the generic kernel carries the coupled rows
+        # (mmpc_config.as_written); after every solve the extra rows are re-evaluated on the host as a post-condition.
+        # faithful_convex=False: the intended rows only.  L = 1 has no extra rows.
         hs = [np.concatenate([np.asarray(pt, float).reshape(3), np.asarray(nrm, float).reshape(3)])
               for pt, nrm in obstacle_manipulation_list]
         self._hs = np.array(hs, float).reshape(-1, 6)
@@ -57,7 +56,7 @@ class MPCWholeBody:
         self._M = len(obstacle_list) if n_obstacles is None else int(n_obstacles)
         self._engine = _capi.Engine(_capi.KIND_WHOLEBODY, N, self._M, self.dt, self.ulim, self.xlim, self.dulim,
                                     max_batch=max_batch, device=device, obs_per_stage=obs_per_stage, tol=tol,
-                                    max_iter=max_iter, halfspaces=hs)
+                                    max_iter=max_iter, halfspaces=hs, as_written=self._q8_check)
         self.max_batch = max_batch
         self.X, self.X_ref = Sym("X"), Sym("X_ref")
         self.reset()
@@ -112,9 +111,8 @@ class MPCWholeBody:
         if self._q8_check:
             self._apply_q8_check(r)
             if r["status"][0] != 0:
-                raise RuntimeError("an as-written half-space row (quirk Q8: stale `constr` entry of the previous stage) is violated "
-                                   "by %.3g at the solution of the intended rows; the coupled rows are not implemented - "
-                                   "faithful_convex=False solves the intended NLP" % self.q8_margin)
+                raise RuntimeError("post-condition failed: an as-written half-space row (quirk Q8) is violated by %.3g at a "
+                                   "solution the engine reported as converged" % self.q8_margin)
         print("cost: ", r["cost"][0])                                                                   # :317
         self.x_guess = r["X"][0]
         self.u_latest = r["U"][0]
@@ -134,7 +132,7 @@ class MPCWholeBody:
             self._apply_q8_check(r)
         return r
 
-    Q8_TOL = 1e-8      # feasibility tolerance of the extra rows (the solver's own: scaled KKT error <= 1e-8)
+    Q8_TOL = 1e-7      # post-condition on the extra rows (the solver stops at a scaled KKT error of 1e-8)
 
     def _apply_q8_check(self, r):
         """Marks converged instances whose solution violates an as-written extra row with _capi.STATUS_Q8_REFUSED."""

@@ -67,6 +67,9 @@ struct MmpcParams {
     // opt-in (mmpc_set_warm_start): initial guess of U as [B][N][nu], separate from the U_last parameter of the cost and of
     // the rate bounds; null = the reference's protocol (U starts at U_last, mpc_wholebody_qref.py:303,310)
     const double *u_guess;
+    // L >= 2 planes: also the L-1 extra rows per (stage >= 1, arm point) that obsAvoidConvex emits AS WRITTEN (quirk Q8,
+    // mpc_wholebody_qref.py:77-89,156): -max(c_{k,i,0..j}, c_{k-1,i,j+1..L-1}) <= s_k  (generic kernel only)
+    int as_written;
 };
 
 // robot_models/manipulator_3DoF.py:18-22, mobile_manipulator.py:14-15, base.py:15,
@@ -160,18 +163,19 @@ struct MmpcDims {
 struct MmpcLayout {
     int X, U, S, LAM, XREF, UREF, ULAST, OBS, T, Z, HR, DTR, GC, HC, GSF, CV, CD, GX, GU, HXX, QX, HUXL, HUUL,
         HUX02, HUUD, QU, HSS, GSS, VX, VXN, KK, KF, DX, DU, DS, DLAM, PF, TT, PC, MF, MG, MH, MGX, MGU, RED, FILT,
-        MISC, PNU, PNUS, KFV, GNU, FWV, NUEQ, GHS, WTS, total;
+        MISC, PNU, PNUS, KFV, GNU, FWV, NUEQ, GHS, WTS, GQ8, BQ8, VQ, RQ, HQX, QQX, HUXS, HUUS, RDX, total;
     int R, NR;
 };
 
 template <int KIND>
-MMPC_HD MmpcLayout mmpc_layout(int N, int M, int obs_per_stage, int nhs = 0) {
+MMPC_HD MmpcLayout mmpc_layout(int N, int M, int obs_per_stage, int nhs = 0, int nq = 0) {
     typedef MmpcDims<KIND> D;
     MmpcLayout L;
     int o = 0;
     const int NS = N + 1;
-    L.R = 2 * D::NU + 2 * D::NX + M + D::NSELF + nhs;   // nhs = 6 half-space rows per stage when L > 0
-    L.NR = M + D::NSELF + nhs;
+    // nhs = 6 half-space rows per stage when L > 0; nq = 6 (L-1) rows of the NLP as written (quirk Q8; none at stage 0)
+    L.R = 2 * D::NU + 2 * D::NX + M + D::NSELF + nhs + nq;
+    L.NR = M + D::NSELF + nhs + nq;
 #define MMPC_CARVE(name, n) L.name = o; o += (n); o = (o + 1) & ~1;
     MMPC_CARVE(X, NS * D::NX) MMPC_CARVE(U, N * D::NU) MMPC_CARVE(S, NS) MMPC_CARVE(LAM, NS * D::NX)
     MMPC_CARVE(XREF, NS * D::NX) MMPC_CARVE(UREF, N * D::NU) MMPC_CARVE(ULAST, N * D::NU)
@@ -190,6 +194,11 @@ MMPC_HD MmpcLayout mmpc_layout(int N, int M, int obs_per_stage, int nhs = 0) {
     // terminal xy equality (interface_wholebody_qref.py:166-167): multiplier sensitivities
     MMPC_CARVE(PNU, D::NX * 2) MMPC_CARVE(PNUS, NS * D::NX * 2) MMPC_CARVE(KFV, N * D::NU * 2) MMPC_CARVE(GNU, D::NV * 2)
     MMPC_CARVE(FWV, 2 * 3 * D::NX) MMPC_CARVE(NUEQ, 4) MMPC_CARVE(GHS, NS * nhs * 6) MMPC_CARVE(WTS, MMPC_W_SIZE)
+    // as-written rows: gradient / branch per row; per stage: coupling of s_k to x_{k-1}, what stage k's rows add to stage k-1
+    // (residual, Hessian y-block, gradient), dense blocks of a slack eliminated one stage earlier, x-stationarity residual
+    MMPC_CARVE(GQ8, NS * nq * 6) MMPC_CARVE(BQ8, NS * nq) MMPC_CARVE(VQ, nq ? NS * 6 : 0) MMPC_CARVE(RQ, nq ? (NS + 1) * 6 : 0)
+    MMPC_CARVE(HQX, nq ? (NS + 1) * 21 : 0) MMPC_CARVE(QQX, nq ? (NS + 1) * 6 : 0) MMPC_CARVE(HUXS, nq ? NS * D::NU * D::NX : 0)
+    MMPC_CARVE(HUUS, nq ? NS * D::NUU : 0) MMPC_CARVE(RDX, nq ? NS * D::NX : 0)
 #undef MMPC_CARVE
     L.total = o;
     return L;
@@ -275,8 +284,15 @@ MMPC_DEV double mmpc_self_row(int i, double px, double py, double c, double s, c
 // (mpc_wholebody_qref.py:57-89, 216-217):  h = -max_j n_j.((pi_j - 0.03 n_j) - P_i(x)).
 // One row per (stage, point): the intended formulation; the reference's L>=2 code path emits L rows that read
 // stale / free `constr` entries (quirk Q8) - not reproduced.  g6 = dh/d(x,y,psi,q1,q2,q3) or null.
+MMPC_DEV double mmpc_hs_row_range(const MmpcParams &P, int i, int j0, int j1, double px, double py, double c, double s,
+                                  const double dr[3], const double dz[3], double *g6, double *h10);
 MMPC_DEV double mmpc_hs_row(const MmpcParams &P, int i, double px, double py, double c, double s, const double dr[3],
                             const double dz[3], double *g6, double *h10 = nullptr) {
+    return mmpc_hs_row_range(P, i, 0, P.L, px, py, c, s, dr, dz, g6, h10);
+}
+// the same over the planes j0 <= j < j1 only: -max_j n_j.((pi_j - 0.03 n_j) - P_i(x))
+MMPC_DEV double mmpc_hs_row_range(const MmpcParams &P, int i, int j0, int j1, double px, double py, double c, double s,
+                                  const double dr[3], const double dz[3], double *g6, double *h10) {
     const double al = (i == 0 || i == 2) ? 0.5 : (i == 1 ? 1.0 : 0.0);
     const double be = (i == 2 || i == 4) ? 0.5 : (i == 3 ? 1.0 : 0.0);
     const double ga = i == 4 ? 0.5 : (i == 5 ? 1.0 : 0.0);
@@ -286,7 +302,7 @@ MMPC_DEV double mmpc_hs_row(const MmpcParams &P, int i, double px, double py, do
     const double Pw0 = sig * px + R * c, Pw1 = sig * py + R * s, Pw2 = Z;
     double best = 0.0;
     int jb = -1;
-    for (int j = 0; j < P.L; j++) {
+    for (int j = j0; j < j1; j++) {
         const double *h = P.hs[j];
         const double v = h[3] * ((h[0] - 0.03 * h[3]) - Pw0) + h[4] * ((h[1] - 0.03 * h[4]) - Pw1) + h[5] * ((h[2] - 0.03 * h[5]) - Pw2);
         if (jb < 0 || v > best) { best = v; jb = j; }
@@ -421,8 +437,10 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
     const int N = NC ? NC : P.N, M = MC >= 0 ? MC : P.M, NS = N + 1;
     const int OPS = OPSC >= 0 ? OPSC : P.obs_per_stage, PL = LC >= 0 ? LC : P.L;
     const int NHS = (KIND == 0 && PL > 0) ? 6 : 0;
+    const int NQ = (KIND == 0 && P.as_written && PL >= 2) ? 6 * (PL - 1) : 0;   // rows of the NLP as written (quirk Q8), stages >= 1
     constexpr int NREF = D::NREF;
-    const MmpcLayout L = mmpc_layout<KIND>(N, M, OPS, NHS);
+    constexpr int HRMAX = KIND == 0 ? 16 + 4 + 6 + 42 : 16 + 4 + 6;
+    const MmpcLayout L = mmpc_layout<KIND>(N, M, OPS, NHS, NQ);
     const int R = L.R, NR = L.NR;
     double *X = lds + L.X, *U = lds + L.U, *S = lds + L.S, *LAM = lds + L.LAM, *XREF = lds + L.XREF,
            *UREF = lds + L.UREF, *ULAST = lds + L.ULAST, *OBS = lds + L.OBS, *T = lds + L.T, *Z = lds + L.Z,
@@ -436,8 +454,10 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
            *RED = lds + L.RED, *FILT = lds + L.FILT, *MISC = lds + L.MISC, *PNU = lds + L.PNU, *PNUS = lds + L.PNUS,
            *KFV = lds + L.KFV, *GNU = lds + L.GNU, *FWV = lds + L.FWV, *NUEQ = lds + L.NUEQ, *GHS = lds + L.GHS;
     double *const WTS = lds + L.WTS;
+    double *const GQ8 = lds + L.GQ8, *const BQ8 = lds + L.BQ8, *const VQ = lds + L.VQ, *const RQ = lds + L.RQ, *const HQX = lds + L.HQX,
+           *const QQX = lds + L.QQX, *const HUXS = lds + L.HUXS, *const HUUS = lds + L.HUUS, *const RDX = lds + L.RDX;
     const bool teq = P.terminal_xy_eq != 0;
-    const int SL_UHI = NU, SL_XLO = 2 * NU, SL_XHI = 2 * NU + NX, SL_C = 2 * NU + 2 * NX, SL_S = SL_C + M, SL_H = SL_S + NSELF;
+    const int SL_UHI = NU, SL_XLO = 2 * NU, SL_XHI = 2 * NU + NX, SL_C = 2 * NU + 2 * NX, SL_S = SL_C + M, SL_H = SL_S + NSELF, SL_Q = SL_H + NHS;
     const double dt = P.dt, Sw = P.S, tol = P.tol;
 
     // bound of a box slot r at stage k; returns false when the row does not exist
@@ -459,6 +479,20 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
         return OBS + ((OPS ? k * M : 0) + m) * 3;
     };
     auto slack_idx = [&](int k) -> int { return k < N - 1 ? k : N - 1; };  // :265 quirk (Q1)
+    // row e = i (L-1) + j of the NLP as written at stage k >= 1: min(-max_{j' <= j} c_{k,i,j'}, -max_{j' > j} c_{k-1,i,j'}) (without
+    // the - s_k); br = 1 when the previous stage's planes attain it - value, gradient and curvature then belong to x_{k-1}
+    auto q8_row = [&](int e, const double *xk, double cs, double sn, const double *dr, const double *dz, const double *xp, double csp,
+                      double snp, const double *drp, const double *dzp, int &br, double *g6, double *h10) -> double {
+        const int i = e / (PL - 1), j = e % (PL - 1);
+        const double vc = mmpc_hs_row_range(P, i, 0, j + 1, xk[0], xk[1], cs, sn, dr, dz, nullptr, nullptr);
+        const double vp = mmpc_hs_row_range(P, i, j + 1, PL, xp[0], xp[1], csp, snp, drp, dzp, nullptr, nullptr);
+        br = vp < vc ? 1 : 0;
+        if (g6) {
+            if (br) mmpc_hs_row_range(P, i, j + 1, PL, xp[0], xp[1], csp, snp, drp, dzp, g6, h10);
+            else mmpc_hs_row_range(P, i, 0, j + 1, xk[0], xk[1], cs, sn, dr, dz, g6, h10);
+        }
+        return br ? vp : vc;
+    };
 
     // ---------------------------------------------------------------- per-launch constants -> LDS
     LANES_BEGIN
@@ -526,6 +560,13 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
             mmpc_arm_segments(xk[NX - 3], xk[NX - 2], xk[NX - 1], dr, dz);
             for (int i = 0; i < NSELF; i++) hr[M + i] = mmpc_self_row(i, xk[0], xk[1], cs, sn, dr, dz, nullptr) - sks;
             for (int i = 0; i < NHS; i++) hr[M + NSELF + i] = mmpc_hs_row(P, i, xk[0], xk[1], cs, sn, dr, dz, nullptr) - sk;
+            if (NQ && k >= 1) {
+                const double *xp = X + (k - 1) * NX;
+                double drp[3], dzp[3], snp, csp;
+                sincos(xp[2], &snp, &csp);
+                mmpc_arm_segments(xp[NX - 3], xp[NX - 2], xp[NX - 1], drp, dzp);
+                for (int e = 0; e < NQ; e++) { int br; hr[M + NSELF + NHS + e] = q8_row(e, xk, cs, sn, dr, dz, xp, csp, snp, drp, dzp, br, nullptr, nullptr) - sk; }
+            }
         }
     };
 
@@ -533,12 +574,13 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
     // ---------------------------------------------------------------- slack / multiplier init
     LANES_BEGIN
     for (int k = lane; k < NS; k += MMPC_WAVE) {
-        double hr[16 + 4 + 6];
+        double hr[HRMAX];
         nl_rows(k, X + k * NX, S[k], S[slack_idx(k)], hr);
         for (int r = 0; r < R; r++) {
             double h = 0.0, b;
             bool act = true;
-            if (r < SL_C) {
+            if (r >= SL_Q && k == 0) act = false;   // (at k = 0 the stale entries are free variables: no row)
+            else if (r < SL_C) {
                 act = box_bound(k, r, b);
                 if (act) {
                     if (r < NU) h = b - U[k * NU + r];
@@ -563,7 +605,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
         // ulim infinite, still finite); count exactly:
         for (int k = 0; k < NS; k++) { double b; if (box_bound(k, r, b)) nrows_act++; }
     }
-    nrows_act += NS * NR;
+    nrows_act += NS * NR - NQ;
 
     for (it = 0; it <= P.max_iter; it++) {
         // ============================================================ E1: evaluation + KKT partials
@@ -667,6 +709,32 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                     e_p = mmpc_max(e_p, fabs(h + t));
                     tzmax = mmpc_max(tzmax, t * z); tzmin = mmpc_min(tzmin, t * z); zsum += z;
                 }
+                if (NQ) {   // rows of the NLP as written (quirk Q8): planes 0..j at x_k, planes j+1.. at x_{k-1}
+                    double rq[6] = {0, 0, 0, 0, 0, 0};
+                    if (k >= 1) {
+                        const double *xp = X + (k - 1) * NX;
+                        double drp[3], dzp[3], snp, csp;
+                        sincos(xp[2], &snp, &csp);
+                        mmpc_arm_segments(xp[NX - 3], xp[NX - 2], xp[NX - 1], drp, dzp);
+                        for (int e = 0; e < NQ; e++) {
+                            double g6[6];
+                            int br;
+                            const double h = q8_row(e, xk, cs, sn, dr, dz, xp, csp, snp, drp, dzp, br, g6, nullptr) - S[k];
+                            HR[k * NR + M + NSELF + NHS + e] = h;
+                            BQ8[k * NQ + e] = (double)br;
+                            const double t = T[k * R + SL_Q + e], z = Z[k * R + SL_Q + e];
+                            for (int a = 0; a < 6; a++) {
+                                GQ8[(k * NQ + e) * 6 + a] = g6[a];
+                                if (br) rq[a] += g6[a] * z; else rdx[kY[a]] += g6[a] * z;
+                            }
+                            rds -= z;
+                            e_p = mmpc_max(e_p, fabs(h + t));
+                            tzmax = mmpc_max(tzmax, t * z); tzmin = mmpc_min(tzmin, t * z); zsum += z;
+                        }
+                    }
+                    for (int a = 0; a < 6; a++) RQ[k * 6 + a] = rq[a];   // what this stage's rows add to the stationarity of x_{k-1}
+                    if (k == N) for (int a = 0; a < 6; a++) RQ[(N + 1) * 6 + a] = 0.0;
+                }
             }
             if (k < N) rds -= selfz; else MISC[1] = selfz;
             DS[k] = rds;  // stage-local part of the s-stationarity residual (finished in E1b)
@@ -677,7 +745,8 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                     zsum += fabs(NUEQ[j]);
                 }
             }
-            if (k >= 1) for (int i = 0; i < NX; i++) e_d = mmpc_max(e_d, fabs(rdx[i]));
+            if (NQ) { for (int i = 0; i < NX; i++) RDX[k * NX + i] = rdx[i]; }   // finished in E1b (the next stage's rows add to it)
+            else if (k >= 1) for (int i = 0; i < NX; i++) e_d = mmpc_max(e_d, fabs(rdx[i]));
             if (k < N) for (int a = 0; a < NU; a++) e_d = mmpc_max(e_d, fabs(rdu[a]));
         }
         RED[0 * MMPC_WAVE + lane] = e_d; RED[1 * MMPC_WAVE + lane] = e_p; RED[2 * MMPC_WAVE + lane] = tzmax;
@@ -689,6 +758,14 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
         LANES_BEGIN
         double e_s = 0.0;
         for (int k = lane; k < NS; k += MMPC_WAVE) e_s = mmpc_max(e_s, fabs(DS[k] - (k == N - 1 ? MISC[1] : 0.0)));
+        if (NQ)
+            for (int k = lane; k < NS; k += MMPC_WAVE) {
+                if (k < 1) continue;
+                double r9[NX];
+                for (int i = 0; i < NX; i++) r9[i] = RDX[k * NX + i];
+                for (int a = 0; a < 6; a++) r9[kY[a]] += RQ[(k + 1) * 6 + a];
+                for (int i = 0; i < NX; i++) e_s = mmpc_max(e_s, fabs(r9[i]));
+            }
         RED[5 * MMPC_WAVE + lane] = e_s;
         LANES_END
         double err_d = 0.0, err_p = 0.0, tzmax = 0.0, tzmin = 1e300, zsum = 0.0;
@@ -816,7 +893,48 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                     }
                     hss += w; gss -= zh;
                 }
+                if (NQ) {
+                    // rows of the NLP as written: a row whose previous-stage entry attains the max acts on x_{k-1}; its blocks are
+                    // handed to stage k-1 (HQX, QQX: added in A2), its tie between s_k and x_{k-1} is VQ
+                    double hq[21], qq[6] = {0, 0, 0, 0, 0, 0}, vq[6] = {0, 0, 0, 0, 0, 0};
+                    for (int e2 = 0; e2 < 21; e2++) hq[e2] = 0.0;
+                    if (k >= 1) {
+                        const double *xk = X + k * NX, *xp = X + (k - 1) * NX;
+                        double sn, cs, dr[3], dz[3], snp, csp, drp[3], dzp[3];
+                        if (exact) {
+                            sincos(xk[2], &sn, &cs); mmpc_arm_segments(xk[NX - 3], xk[NX - 2], xk[NX - 1], dr, dz);
+                            sincos(xp[2], &snp, &csp); mmpc_arm_segments(xp[NX - 3], xp[NX - 2], xp[NX - 1], drp, dzp);
+                        }
+                        for (int e = 0; e < NQ; e++) {
+                            const double t = T[k * R + SL_Q + e], z = Z[k * R + SL_Q + e], w = z / t;
+                            const double zh = mu / t + w * (HR[k * NR + M + NSELF + NHS + e] + t);
+                            const double *g6 = GQ8 + (k * NQ + e) * 6;
+                            const bool br = BQ8[k * NQ + e] != 0.0;
+                            double h10[10];
+                            if (exact) { double gt[6]; int b2; q8_row(e, xk, cs, sn, dr, dz, xp, csp, snp, drp, dzp, b2, gt, h10); }
+                            if (br) {
+                                for (int a = 0; a < 6; a++) {
+                                    for (int b = 0; b <= a; b++) hq[a * (a + 1) / 2 + b] += w * g6[a] * g6[b];
+                                    qq[a] += g6[a] * zh; vq[a] += w * g6[a];
+                                }
+                                if (exact) for (int a = 0; a < 4; a++) for (int b = 0; b <= a; b++) hq[(2 + a) * (3 + a) / 2 + 2 + b] += z * h10[a * (a + 1) / 2 + b];
+                            } else {
+                                for (int a = 0; a < 6; a++) {
+                                    const int ia = kY[a];
+                                    for (int b = 0; b <= a; b++) hxx[ia * (ia + 1) / 2 + kY[b]] += w * g6[a] * g6[b];
+                                    qx[ia] += g6[a] * zh; vx[a] += w * g6[a];
+                                }
+                                if (exact) for (int a = 0; a < 4; a++) { const int ia = kY[2 + a]; for (int b = 0; b <= a; b++) hxx[ia * (ia + 1) / 2 + kY[2 + b]] += z * h10[a * (a + 1) / 2 + b]; }
+                            }
+                            hss += w; gss -= zh;
+                        }
+                    }
+                    for (int e2 = 0; e2 < 21; e2++) HQX[k * 21 + e2] = hq[e2];
+                    for (int a = 0; a < 6; a++) { QQX[k * 6 + a] = qq[a]; VQ[k * 6 + a] = vq[a]; }
+                    if (k == N) { for (int e2 = 0; e2 < 21; e2++) HQX[(N + 1) * 21 + e2] = 0.0; for (int a = 0; a < 6; a++) QQX[(N + 1) * 6 + a] = 0.0; }
+                }
                 HSS[k] = hss; GSS[k] = gss;
+                if (NQ && k == N - 1) { MISC[4] = hss; MISC[5] = gss; }   // (copies for the lane of stage N-2, see A2)
                 for (int a = 0; a < 6; a++) VX[k * 6 + a] = vx[a];
                 if (k == N) { MISC[2] = hssN; MISC[3] = gssN; for (int a = 0; a < 6; a++) VXN[a] = vN[a]; }
             }
@@ -826,7 +944,57 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
             LANES_BEGIN
             for (int k = lane; k < NS; k += MMPC_WAVE) {
                 double *hxx = HXX + k * NXX, *qx = QX + k * NX;
-                if (k == N - 1 && NSELF) {
+                bool back_self = false;   // s_k reaches back to x_{k-1}: eliminated at stage k-1, not here
+                if (NQ) {
+                    // blocks the rows of stage k+1 contribute to this stage
+                    for (int a = 0; a < 6; a++) {
+                        const int ia = kY[a];
+                        for (int b = 0; b <= a; b++) hxx[ia * (ia + 1) / 2 + kY[b]] += HQX[(k + 1) * 21 + a * (a + 1) / 2 + b];
+                        qx[ia] += QQX[(k + 1) * 6 + a];
+                    }
+                    if (k >= 1 && k != N - 1) for (int a = 0; a < 6; a++) back_self = back_self || VQ[k * 6 + a] != 0.0;
+                    bool back_next = false;
+                    if (k + 1 <= N && k + 1 != N - 1) for (int a = 0; a < 6; a++) back_next = back_next || VQ[(k + 1) * 6 + a] != 0.0;
+                    if (k < N) {
+                        for (int c = 0; c < NU * NX; c++) HUXS[k * NU * NX + c] = 0.0;
+                        for (int c = 0; c < NUU; c++) HUUS[k * NUU + c] = 0.0;
+                    }
+                    if (back_next) {
+                        // Schur complement of s_{k+1} in the variables of this stage: dx_{k+1} = A dx + B du + c, so
+                        // a = vq + A^T v, b = B^T v, gamma = g_s - v.c  (the pattern of the terminal self rows, Q1)
+                        const double ih = 1.0 / HSS[k + 1];
+                        double gam = GSS[k + 1], vfull[NX], a[NX], b[NU > 0 ? NU : 1];
+                        for (int j = 0; j < NX; j++) { vfull[j] = 0.0; a[j] = 0.0; }
+                        for (int q = 0; q < 6; q++) { vfull[kY[q]] = VX[(k + 1) * 6 + q]; a[kY[q]] = VQ[(k + 1) * 6 + q]; }
+                        const double *cv = CV + k * MMPC_NCV;
+                        for (int j = 0; j < NV; j++) {
+                            double v = 0.0;
+                            for (int q = 0; q < 4; q++) v += cv[TB::ccv(j, q)] * vfull[TB::crow(j, q)];
+                            if (j < NX) a[j] += v; else b[j - NX] = v;
+                        }
+                        for (int j = 0; j < NX; j++) gam -= vfull[j] * CD[k * NX + j];
+                        for (int e = 0; e < NXX; e++) hxx[e] -= a[kTriI[e]] * a[kTriJ[e]] * ih;
+                        for (int j = 0; j < NX; j++) qx[j] += a[j] * gam * ih;
+                        for (int c = 0; c < NU; c++) {
+                            for (int j = 0; j < NX; j++) HUXS[(k * NU + c) * NX + j] = -b[c] * a[j] * ih;
+                            for (int d = 0; d <= c; d++) HUUS[k * NUU + c * (c + 1) / 2 + d] = -b[c] * b[d] * ih;
+                            QU[k * NU + c] += b[c] * gam * ih;
+                        }
+                    }
+                    if (k == N - 2 && N >= 2) {
+                        // s_{N-1} touches x_{N-2}, x_{N-1} and (quirk Q1) x_N: its reach-back part keeps the diagonal block and the
+                        // gradient on x_{N-2} only - an inexact Newton matrix in that corner, the residuals stay exact
+                        const double ih = 1.0 / (MISC[4] + (NSELF ? MISC[2] : 0.0)), g1 = MISC[5] + (NSELF ? MISC[3] : 0.0);
+                        for (int a = 0; a < 6; a++) {
+                            const int ia = kY[a];
+                            for (int b = 0; b <= a; b++) hxx[ia * (ia + 1) / 2 + kY[b]] -= VQ[(N - 1) * 6 + a] * VQ[(N - 1) * 6 + b] * ih;
+                            qx[ia] += VQ[(N - 1) * 6 + a] * g1 * ih;
+                        }
+                    }
+                }
+                if (back_self) {
+                    // (nothing: the slack of this stage has been eliminated by the lane of stage k-1 above)
+                } else if (k == N - 1 && NSELF) {
                     const double hss = HSS[k] + MISC[2];
                     double gam = GSS[k] + MISC[3];
                     HSS[k] = hss; GSS[k] = gam;
@@ -907,12 +1075,12 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                         MF[e] = v;
                     } else if (e < NXX + NU * NX) {
                         const int e2 = e - NXX, a = e2 / NX, j = e2 % NX, col = NX + a;
-                        double v = (k == N - 1 ? HUXL[e2] : 0.0) + ((a == 0 && j == 2) ? HUX02[k] : 0.0);
+                        double v = (k == N - 1 ? HUXL[e2] : (NQ ? HUXS[k * NU * NX + e2] : 0.0)) + ((a == 0 && j == 2) ? HUX02[k] : 0.0);
                         for (int q = 0; q < 4; q++) v += cv[TB::ccv(col, q)] * TT[TB::crow(col, q) * NV + j];
                         MG[e2] = v;
                     } else if (e < NXX + NU * NX + NUU) {
                         const int e2 = e - NXX - NU * NX, a = kTriI[e2], b = kTriJ[e2], col = NX + a;
-                        double v = WTS[MMPC_W_RW2 + a * NU + b] + (a == b ? HUUD[k * NU + a] : 0.0) + (k == N - 1 ? HUUL[e2] : 0.0);
+                        double v = WTS[MMPC_W_RW2 + a * NU + b] + (a == b ? HUUD[k * NU + a] : 0.0) + (k == N - 1 ? HUUL[e2] : (NQ ? HUUS[k * NUU + e2] : 0.0));
                         for (int q = 0; q < 4; q++) v += cv[TB::ccv(col, q)] * TT[TB::crow(col, q) * NV + NX + b];
                         MH[e2] = v;
                     } else {
@@ -1089,6 +1257,17 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
         LANES_BEGIN
         for (int k = lane; k < NS; k += MMPC_WAVE) {
             const double *dx = DX + k * NX;
+            double vdx = 0.0;
+            const int ny = NSELF ? 6 : 2;
+            for (int a = 0; a < ny; a++) vdx += VX[k * 6 + a] * dx[kY[a]];
+            if (k == N - 1 && NSELF) for (int a = 0; a < 6; a++) vdx += VXN[a] * DX[N * NX + kY[a]];
+            bool back_self = false;
+            if (NQ && k >= 1) {
+                for (int a = 0; a < 6; a++) vdx += VQ[k * 6 + a] * DX[(k - 1) * NX + kY[a]];
+                if (k != N - 1) for (int a = 0; a < 6; a++) back_self = back_self || VQ[k * 6 + a] != 0.0;
+            }
+            const double dsk = -(GSS[k] - vdx) / HSS[k];
+            DS[k] = dsk;
             for (int i = 0; i < NX; i++) {
                 double v = QX[k * NX + i];
                 for (int j = 0; j < NX; j++)
@@ -1096,11 +1275,9 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                 if (teq) v += PNUS[(k * NX + i) * 2] * NUEQ[2] + PNUS[(k * NX + i) * 2 + 1] * NUEQ[3];
                 DLAM[k * NX + i] = -v - LAM[k * NX + i];
             }
-            double vdx = 0.0;
-            const int ny = NSELF ? 6 : 2;
-            for (int a = 0; a < ny; a++) vdx += VX[k * 6 + a] * dx[kY[a]];
-            if (k == N - 1 && NSELF) for (int a = 0; a < 6; a++) vdx += VXN[a] * DX[N * NX + kY[a]];
-            DS[k] = -(GSS[k] - vdx) / HSS[k];
+            // a slack eliminated one stage earlier is not part of this stage's cost-to-go: its pull on x_k enters the multiplier of
+            // the dynamics directly,  lam_k+ = -(P_k dx_k + p_k) + v_k ds_k
+            if (back_self) for (int a = 0; a < 6; a++) DLAM[k * NX + kY[a]] += VX[k * 6 + a] * dsk;
         }
         LANES_END
         // ---- D2: row steps, fraction-to-boundary, directional derivative, merit at alpha = 0
@@ -1149,7 +1326,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                 th += fabs(h + tv);
                 acc(tv);
             }
-            double hr[16 + 4 + 6];
+            double hr[HRMAX];
             {
                 for (int m = 0; m < M; m++) {
                     const double *o = obs_ptr(k, m);
@@ -1161,9 +1338,17 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                     mmpc_arm_segments(xk[NX - 3], xk[NX - 2], xk[NX - 1], dr, dz);
                     for (int i = 0; i < NSELF; i++) hr[M + i] = mmpc_self_row(i, xk[0], xk[1], cs, sn, dr, dz, nullptr) - sks;
                     for (int i = 0; i < NHS; i++) hr[M + NSELF + i] = mmpc_hs_row(P, i, xk[0], xk[1], cs, sn, dr, dz, nullptr) - sk;
+                    if (NQ && k >= 1) {
+                        double xp[NX], drp[3], dzp[3], snp, csp;
+                        for (int j = 0; j < NX; j++) xp[j] = X[(k - 1) * NX + j] + alpha * DX[(k - 1) * NX + j];
+                        sincos(xp[2], &snp, &csp);
+                        mmpc_arm_segments(xp[NX - 3], xp[NX - 2], xp[NX - 1], drp, dzp);
+                        for (int e = 0; e < NQ; e++) { int br; hr[M + NSELF + NHS + e] = q8_row(e, xk, cs, sn, dr, dz, xp, csp, snp, drp, dzp, br, nullptr, nullptr) - sk; }
+                    }
                 }
             }
             for (int m = 0; m < NR; m++) {
+                if (k == 0 && m >= NR - NQ) continue;   // (no rows of the as-written set at stage 0)
                 const double tv = T[k * R + SL_C + m] + alpha * DTR[k * NR + m];
                 th += fabs(hr[m] + tv);
                 acc(tv);
@@ -1193,11 +1378,18 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                     h = HR[k * NR + M + i];
                     jd = -DS[slack_idx(k)];
                     for (int a = 0; a < 6; a++) jd += GSF[(k * NSELF + i) * 6 + a] * dx[kY[a]];
-                } else {
+                } else if (r < SL_Q) {
                     const int i = r - SL_H;
                     h = HR[k * NR + M + NSELF + i];
                     jd = -DS[k];
                     for (int a = 0; a < 6; a++) jd += GHS[(k * 6 + i) * 6 + a] * dx[kY[a]];
+                } else {
+                    if (k == 0) { DTR[k * NR + r - SL_C] = 0.0; continue; }
+                    const int e = r - SL_Q;
+                    const double *dq = DX + (BQ8[k * NQ + e] != 0.0 ? k - 1 : k) * NX;
+                    h = HR[k * NR + M + NSELF + NHS + e];
+                    jd = -DS[k];
+                    for (int a = 0; a < 6; a++) jd += GQ8[(k * NQ + e) * 6 + a] * dq[kY[a]];
                 }
                 const double t = T[k * R + r], z = Z[k * R + r];
                 const double dtv = -(h + t) - jd, dzv = mu / t - z - (z / t) * dtv;
@@ -1277,7 +1469,8 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                     else if (r < SL_XHI) { h = b - X[k * NX + r - SL_XLO]; jd = -DX[k * NX + r - SL_XLO]; }
                     else { h = X[k * NX + r - SL_XHI] - b; jd = DX[k * NX + r - SL_XHI]; }
                     dtv = -(h + T[k * R + r]) - jd;
-                } else dtv = DTR[k * NR + r - SL_C];
+                } else if (r >= SL_Q && k == 0) continue;
+                else dtv = DTR[k * NR + r - SL_C];
                 const double t = T[k * R + r], z = Z[k * R + r];
                 const double dzv = mu / t - z - (z / t) * dtv;
                 const double tn = t + alpha * dtv;

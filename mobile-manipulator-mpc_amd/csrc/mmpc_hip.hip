@@ -300,8 +300,10 @@ extern "C" int mmpc_create(const mmpc_config *cfg, mmpc_handle *out) {
     p.L = cfg->L;
     for (int j = 0; j < 8; j++) for (int a = 0; a < 6; a++) p.hs[j][a] = j < cfg->L ? cfg->halfspace[j][a] : 0.0;
     const int nhs = (cfg->kind == MMPC_KIND_WHOLEBODY && cfg->L > 0) ? 6 : 0;
+    p.as_written = (cfg->kind == MMPC_KIND_WHOLEBODY && cfg->L >= 2 && cfg->as_written) ? 1 : 0;
+    const int nq8 = p.as_written ? 6 * (cfg->L - 1) : 0;
     default_weights(h);
-    const MmpcLayout L = cfg->kind == MMPC_KIND_WHOLEBODY ? mmpc_layout<0>(cfg->N, cfg->M, p.obs_per_stage, nhs)
+    const MmpcLayout L = cfg->kind == MMPC_KIND_WHOLEBODY ? mmpc_layout<0>(cfg->N, cfg->M, p.obs_per_stage, nhs, nq8)
                        : cfg->kind == MMPC_KIND_BASE    ? mmpc_layout<1>(cfg->N, cfg->M, p.obs_per_stage, 0)
                                                         : mmpc_layout<2>(cfg->N, cfg->M, p.obs_per_stage, 0);
     h->lds_bytes = L.total * (int)sizeof(double);

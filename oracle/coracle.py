@@ -15,7 +15,7 @@ class OracleCfg(C.Structure):
                 ("S", C.c_double),
                 ("ulim", (C.c_double * 5) * 2), ("xlim", (C.c_double * 9) * 2), ("dulim", (C.c_double * 5) * 2),
                 ("tol", C.c_double), ("mu_init", C.c_double), ("max_iter", C.c_int),
-                ("L", C.c_int), ("hs", (C.c_double * 6) * 8), ("pose_ref", C.c_int)]
+                ("L", C.c_int), ("hs", (C.c_double * 6) * 8), ("pose_ref", C.c_int), ("as_written", C.c_int)]
 
 
 def build(force=False):
@@ -36,12 +36,13 @@ def lib():
     return _lib
 
 
-def make_cfg(par, M, obs_per_stage=False, tol=1e-8, mu_init=1.0, max_iter=200, hs=None):
+def make_cfg(par, M, obs_per_stage=False, tol=1e-8, mu_init=1.0, max_iter=200, hs=None, as_written=False):
     c = OracleCfg()
     c.kind = 0 if par.kind == "wholebody" else 1
     c.N, c.M, c.obs_per_stage = par.N, M, int(obs_per_stage)
     c.terminal_xy_eq = int(par.terminal_xy_equality)
     c.pose_ref = int(getattr(par, "pose_ref", False))
+    c.as_written = int(bool(as_written))
     c.dt = par.dt
     nx, nu = par.nx, par.nu
 

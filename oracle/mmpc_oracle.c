@@ -25,6 +25,7 @@
  * certified by KKT residuals (oracle/nlp.py:kkt_certificate) and scipy SLSQP (oracle/xcheck.py).
  */
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -33,7 +34,8 @@
 #define NSM 65          /* max stages (N+1) */
 #define MMX 16          /* max circle obstacles */
 #define LMX 8           /* max half-space obstacles */
-#define RMX (2 * NUM + 2 * NXM + MMX + 4 + 6)
+#define NQ8M (6 * (LMX - 1))   /* extra half-space rows per stage of the NLP as written (quirk Q8) */
+#define RMX (2 * NUM + 2 * NXM + MMX + 4 + 6 + NQ8M)
 #define FCAP 16
 #define PROX0 100.0
 #define PROX_LO 0.05
@@ -55,6 +57,8 @@ typedef struct {
     double hs[LMX][6];   /* point (3), normal (3) */
     int pose_ref;        /* controllers/mpc_wholebody.py: the state cost tracks the endpoint pose (x,y,z,psi); Q, P are 4x4
                             (leading dimension 4), traj_ref is [N+1][4]; no self-collision / half-space rows */
+    int as_written;      /* L >= 2: also the L-1 extra rows per (stage >= 1, arm point) that obsAvoidConvex emits as written
+                            (quirk Q8, mpc_wholebody_qref.py:77-89,156): -max(c_{k,i,0..j}, c_{k-1,i,j+1..L-1}) <= s_k */
 } oracle_cfg;
 
 /* robot_models/manipulator_3DoF.py:18-22, mobile_manipulator.py:14-15, base.py:15,
@@ -148,7 +152,12 @@ static double self_row(const double *x, int i, double *g6) {
 /* half-space row for sample point i of [j2/2, j2, (j2+j3)/2, j3, (j3+e)/2, e] (mpc_wholebody_qref.py:57-89,216-217):
  *   h = -max_j n_j.((pi_j - 0.03 n_j) - P_i(x));   one row per (k,i) - the intended formulation, see oracle/nlp.py */
 static const double HS_PTS[6][3] = {{0.5, 0, 0}, {1, 0, 0}, {0.5, 0.5, 0}, {0, 1, 0}, {0, 0.5, 0.5}, {0, 0, 1}};
+/* the same for ONE plane range [j0, j1): -max_{j0 <= j < j1} c_{i,j}(x), derivatives of the plane that attains it */
+static double hs_row_range(const oracle_cfg *cfg, const double *x, int i, int j0, int j1, double *g6, double *h10);
 static double hs_row(const oracle_cfg *cfg, const double *x, int i, double *g6, double *h10) {
+    return hs_row_range(cfg, x, i, 0, cfg->L, g6, h10);
+}
+static double hs_row_range(const oracle_cfg *cfg, const double *x, int i, int j0, int j1, double *g6, double *h10) {
     double al = HS_PTS[i][0], be = HS_PTS[i][1], ga = HS_PTS[i][2], sig = al + be + ga;
     double cm[3] = {sig, be + ga, ga}, dr[3], dz[3];
     arm_segments(x + 6, dr, dz);
@@ -157,7 +166,7 @@ static double hs_row(const oracle_cfg *cfg, const double *x, int i, double *g6, 
     double c = cos(x[2]), s = sin(x[2]);
     double P[3] = {sig * x[0] + R * c, sig * x[1] + R * s, Z};
     double best = 0; int jb = -1;
-    for (int j = 0; j < cfg->L; j++) {
+    for (int j = j0; j < j1; j++) {
         const double *pi = cfg->hs[j], *n = cfg->hs[j] + 3;
         double v = 0; for (int a = 0; a < 3; a++) v += n[a] * ((pi[a] - 0.03 * n[a]) - P[a]);
         if (jb < 0 || v > best) { best = v; jb = j; }
@@ -216,6 +225,10 @@ typedef struct {
     double h[NSM][RMX];
     double gcirc[NSM][MMX][2], hcirc[NSM][MMX][3], gself[NSM][4][6], ghs[NSM][6][6], hhs[NSM][6][10];
     int nhs;
+    /* rows of the NLP as written (quirk Q8): row e = i (L-1) + j of stage k >= 1 reads planes 0..j at x_k and planes j+1..L-1 at
+     * x_{k-1}; q8br = 1 when the previous stage's entry attains the max (the row's gradient then acts on x_{k-1}) */
+    int nq8, q8br[NSM][NQ8M];
+    double gq8[NSM][NQ8M][6], hq8[NSM][NQ8M][10], vq[NSM][NXM];
     double A[NSM][NXM][NXM], B[NSM][NXM][NUM], c[NSM][NXM];
     double gX[NSM][NXM], gU[NSM][NUM], gs[NSM];
     /* QP */
@@ -239,6 +252,7 @@ static const double *obs_at(const work *w, int k, int m) {
 #define SL_CIRC(w, m) (2 * (w)->nu + 2 * (w)->nx + (m))
 #define SL_SELF(w, i) (2 * (w)->nu + 2 * (w)->nx + (w)->M + (i))
 #define SL_HS(w, i) (2 * (w)->nu + 2 * (w)->nx + (w)->M + 4 + (i))
+#define SL_Q8(w, e) (2 * (w)->nu + 2 * (w)->nx + (w)->M + 4 + (w)->nhs + (e))
 
 static int slack_idx(const work *w, int k) { return k < w->N - 1 ? k : w->N - 1; } /* :265 quirk */
 
@@ -271,6 +285,7 @@ static void setup_rows(work *w) {
         for (int m = 0; m < w->M; m++) w->act[k][SL_CIRC(w, m)] = 1;
         if (c->kind == 0 && !c->pose_ref) for (int i = 0; i < 4; i++) w->act[k][SL_SELF(w, i)] = 1;
         for (int i = 0; i < w->nhs; i++) w->act[k][SL_HS(w, i)] = 1;
+        if (k >= 1) for (int e = 0; e < w->nq8; e++) w->act[k][SL_Q8(w, e)] = 1;   /* (at k = 0 the stale entries are free variables: no row) */
     }
 }
 
@@ -293,6 +308,22 @@ static void eval_rows(work *w, double X[NSM][NXM], double U[NSM][NUM], const dou
             for (int i = 0; i < 4; i++)
                 h[k][SL_SELF(w, i)] = self_row(X[k], i, with_deriv ? w->gself[k][i] : 0) - s[slack_idx(w, k)];
         for (int i = 0; i < w->nhs; i++) h[k][SL_HS(w, i)] = hs_row(w->cfg, X[k], i, with_deriv ? w->ghs[k][i] : 0, with_deriv ? w->hhs[k][i] : 0) - s[k];
+        if (k >= 1 && w->nq8) {
+            const int L = w->cfg->L;
+            for (int i = 0; i < 6; i++) for (int j = 0; j < L - 1; j++) {
+                const int e = i * (L - 1) + j;
+                double gc[6], hc[10], gp[6], hp[10];
+                const double vc = hs_row_range(w->cfg, X[k], i, 0, j + 1, with_deriv ? gc : 0, with_deriv ? hc : 0);         /* -max_{j' <= j} c_k */
+                const double vp = hs_row_range(w->cfg, X[k - 1], i, j + 1, L, with_deriv ? gp : 0, with_deriv ? hp : 0);   /* -max_{j' > j} c_{k-1} */
+                const int br = vp < vc;   /* -max(a, b) = min(-a, -b) */
+                h[k][SL_Q8(w, e)] = (br ? vp : vc) - s[k];
+                if (with_deriv) {
+                    w->q8br[k][e] = br;
+                    memcpy(w->gq8[k][e], br ? gp : gc, sizeof(gc));
+                    memcpy(w->hq8[k][e], br ? hp : hc, sizeof(hc));
+                }
+            }
+        }
     }
 }
 
@@ -422,8 +453,9 @@ static void chol_solve(double L[NUM][NUM], int n, double *b) {
 static int factor(work *w, double mu, int use_exact, double prox) {
     const oracle_cfg *c = w->cfg;
     int nx = w->nx, nu = w->nu, N = w->N;
-    for (int k = 0; k <= N; k++) { w->hss[k] = 2 * c->S; w->gss[k] = w->gs[k]; memset(w->vx[k], 0, sizeof(w->vx[k])); }
+    for (int k = 0; k <= N; k++) { w->hss[k] = 2 * c->S; w->gss[k] = w->gs[k]; memset(w->vx[k], 0, sizeof(w->vx[k])); memset(w->vq[k], 0, sizeof(w->vq[k])); }
     memset(w->vxN, 0, sizeof(w->vxN));
+    /* (two sweeps over the stages: a row of stage k whose previous-stage entry attains the max adds to stage k-1's blocks) */
     for (int k = 0; k <= N; k++) {
         {
             double Hcv[NXM][NXM];
@@ -462,6 +494,8 @@ static int factor(work *w, double mu, int use_exact, double prox) {
                 } else if (r < 2 * nu + 2 * nx + w->M + 4 || c->kind != 0) {
                     int i = r - 2 * nu - 2 * nx - w->M; ks = slack_idx(w, k);
                     for (int j = 0; j < 6; j++) jx[YIDX[j]] = w->gself[k][i][j];
+                } else if (r >= SL_Q8(w, 0)) {
+                    continue;   /* rows of the NLP as written: second sweep below */
                 } else {
                     int i = r - 2 * nu - 2 * nx - w->M - 4; ks = k;     /* half-space rows: s[k] (s[N] at the end, :268) */
                     for (int j = 0; j < 6; j++) jx[YIDX[j]] = w->ghs[k][i][j];
@@ -478,15 +512,55 @@ static int factor(work *w, double mu, int use_exact, double prox) {
             }
         }
     }
-    /* Schur complement of s_k (H_xs = -v) */
+    for (int k = 1; k <= N && w->nq8; k++)
+        for (int e = 0; e < w->nq8; e++) {
+            const int r = SL_Q8(w, e), br = w->q8br[k][e], kk = k - br;
+            double tt = w->t[k][r], zz = w->z[k][r], wt = zz / tt, rh = w->h[k][r] + tt, zh = mu / tt + wt * rh;
+            double jx[NXM]; memset(jx, 0, sizeof(jx));
+            for (int j = 0; j < 6; j++) jx[YIDX[j]] = w->gq8[k][e][j];
+            if (use_exact)
+                for (int a = 0; a < 4; a++) for (int b = 0; b < 4; b++) {
+                    int hi = a >= b ? a : b, lo = a >= b ? b : a;
+                    w->Hxx[kk][YIDX[2 + a]][YIDX[2 + b]] += zz * w->hq8[k][e][hi * (hi + 1) / 2 + lo];
+                }
+            for (int i = 0; i < nx; i++) { for (int j = 0; j < nx; j++) w->Hxx[kk][i][j] += wt * jx[i] * jx[j]; w->qx[kk][i] += jx[i] * zh; }
+            w->hss[k] += wt; w->gss[k] -= zh;
+            if (br) for (int i = 0; i < nx; i++) w->vq[k][i] += wt * jx[i];      /* couples s_k with x_{k-1} */
+            else for (int i = 0; i < nx; i++) w->vx[k][i] += wt * jx[i];
+        }
+    /* Schur complement of s_k (H_xs = -v).  s_k is tied to x_k by its own rows (v), for k = N-1 also to x_N by the terminal
+     * self rows (vN, quirk Q1), and in the NLP as written to x_{k-1} by the rows whose previous-stage entry attains the max
+     * (vq).  A slack that reaches back is eliminated one stage earlier, everything expressed in (x_{k-1}, u_{k-1}) through
+     * dx_k = A dx_{k-1} + B du_{k-1} + c:  a = vq + A^T v, b = B^T v, gamma = g_s - v.c.  (s_{N-1} would then touch three
+     * stages; its reach-back part keeps only the diagonal block of x_{N-2} - an inexact Newton matrix in that corner,
+     * the residuals stay exact.) */
     for (int k = 0; k <= N; k++) {
-        double a[NXM], b[NUM], gam = w->gss[k], ih = 1.0 / w->hss[k];
+        int back = 0;
+        if (w->nq8 && k >= 1 && k != N - 1) for (int i = 0; i < nx; i++) if (w->vq[k][i] != 0.0) back = 1;
+        double ih = 1.0 / w->hss[k];
+        if (back) {
+            const int km = k - 1;
+            double a[NXM], b[NUM], gam = w->gss[k];
+            for (int i = 0; i < nx; i++) { a[i] = w->vq[k][i]; for (int j = 0; j < nx; j++) a[i] += w->A[km][j][i] * w->vx[k][j]; }
+            for (int i = 0; i < nu; i++) { b[i] = 0; for (int j = 0; j < nx; j++) b[i] += w->B[km][j][i] * w->vx[k][j]; }
+            for (int j = 0; j < nx; j++) gam -= w->vx[k][j] * w->c[km][j];
+            for (int i = 0; i < nx; i++) { for (int j = 0; j < nx; j++) w->Hxx[km][i][j] -= a[i] * a[j] * ih; w->qx[km][i] += a[i] * gam * ih; }
+            for (int i = 0; i < nu; i++) {
+                for (int j = 0; j < nx; j++) w->Hux[km][i][j] -= b[i] * a[j] * ih;
+                for (int j = 0; j < nu; j++) w->Huu[km][i][j] -= b[i] * b[j] * ih;
+                w->qu[km][i] += b[i] * gam * ih;
+            }
+            continue;
+        }
+        double a[NXM], b[NUM], gam = w->gss[k];
         for (int i = 0; i < nx; i++) a[i] = w->vx[k][i];
         for (int i = 0; i < nu; i++) b[i] = 0;
         if (k == N - 1) {
             for (int i = 0; i < nx; i++) for (int j = 0; j < nx; j++) a[i] += w->A[k][j][i] * w->vxN[j];
             for (int i = 0; i < nu; i++) for (int j = 0; j < nx; j++) b[i] += w->B[k][j][i] * w->vxN[j];
             for (int j = 0; j < nx; j++) gam -= w->vxN[j] * w->c[k][j];
+            if (w->nq8 && k >= 1)   /* reach-back part of s_{N-1}: diagonal block and gradient on x_{N-2} only */
+                for (int i = 0; i < nx; i++) { for (int j = 0; j < nx; j++) w->Hxx[k - 1][i][j] -= w->vq[k][i] * w->vq[k][j] * ih; w->qx[k - 1][i] += w->vq[k][i] * w->gss[k] * ih; }
         }
         for (int i = 0; i < nx; i++) { for (int j = 0; j < nx; j++) w->Hxx[k][i][j] -= a[i] * a[j] * ih; w->qx[k][i] += a[i] * gam * ih; }
         if (k == N - 1)
@@ -571,7 +645,8 @@ int mmpc_oracle_solve(const oracle_cfg *cfg, const double *x_init, const double 
     w->nx = cfg->kind == 0 ? 9 : 6; w->nu = cfg->kind == 0 ? 5 : 2;
     int nx = w->nx, nu = w->nu, N = w->N;
     w->nhs = (cfg->kind == 0 && !cfg->pose_ref && cfg->L > 0) ? 6 : 0;
-    w->nrow = 2 * nu + 2 * nx + w->M + ((cfg->kind == 0 && !cfg->pose_ref) ? 4 : 0) + w->nhs;
+    w->nq8 = (w->nhs && cfg->as_written && cfg->L >= 2) ? 6 * (cfg->L - 1) : 0;
+    w->nrow = 2 * nu + 2 * nx + w->M + ((cfg->kind == 0 && !cfg->pose_ref) ? 4 : 0) + w->nhs + w->nq8;
     w->xinit = x_init; w->xref = traj_ref; w->uref = u_ref; w->ulast = u_last; w->obs = obs;
     for (int i = 0; i < nx; i++) for (int j = 0; j < nx; j++) {
         w->Q2[i][j] = cfg->Q[i * nx + j] + cfg->Q[j * nx + i]; w->P2[i][j] = cfg->P[i * nx + j] + cfg->P[j * nx + i]; }
@@ -643,7 +718,8 @@ int mmpc_oracle_solve(const oracle_cfg *cfg, const double *x_init, const double 
                 else if (r < 2 * nu + 2 * nx) { int q = r - 2 * nu; int j = q < nx ? q : q - nx; rdx[k][j] += (q < nx ? -zz : zz); }
                 else if (r < 2 * nu + 2 * nx + w->M) { int m = r - 2 * nu - 2 * nx; rdx[k][0] += w->gcirc[k][m][0] * zz; rdx[k][1] += w->gcirc[k][m][1] * zz; rds[k] -= zz; }
                 else if (r < 2 * nu + 2 * nx + w->M + 4) { int i = r - 2 * nu - 2 * nx - w->M; for (int j = 0; j < 6; j++) rdx[k][YIDX[j]] += w->gself[k][i][j] * zz; rds[slack_idx(w, k)] -= zz; }
-                else { int i = r - 2 * nu - 2 * nx - w->M - 4; for (int j = 0; j < 6; j++) rdx[k][YIDX[j]] += w->ghs[k][i][j] * zz; rds[k] -= zz; }
+                else if (r < 2 * nu + 2 * nx + w->M + 4 + w->nhs) { int i = r - 2 * nu - 2 * nx - w->M - 4; for (int j = 0; j < 6; j++) rdx[k][YIDX[j]] += w->ghs[k][i][j] * zz; rds[k] -= zz; }
+                else { int e = r - SL_Q8(w, 0), kk = k - w->q8br[k][e]; for (int j = 0; j < 6; j++) rdx[kk][YIDX[j]] += w->gq8[k][e][j] * zz; rds[k] -= zz; }
             }
             for (int k = 0; k < N; k++) {
                 for (int i = 0; i < nx; i++) {
@@ -660,9 +736,9 @@ int mmpc_oracle_solve(const oracle_cfg *cfg, const double *x_init, const double 
                     zsum += fabs(w->nu_eq[j]);
                 }
             for (int k = 0; k <= N; k++) {
-                if (k > 0) for (int i = 0; i < nx; i++) if (fabs(rdx[k][i]) > err_d) err_d = fabs(rdx[k][i]);
-                if (k < N) for (int i = 0; i < nu; i++) if (fabs(rdu[k][i]) > err_d) err_d = fabs(rdu[k][i]);
-                if (fabs(rds[k]) > err_d) err_d = fabs(rds[k]);
+                if (k > 0) for (int i = 0; i < nx; i++) if (fabs(rdx[k][i]) > err_d) { err_d = fabs(rdx[k][i]); if (getenv("MMPC_ORACLE_DEBUG2")) fprintf(stderr, "  rdx[%d][%d] %.3e\n", k, i, rdx[k][i]); }
+                if (k < N) for (int i = 0; i < nu; i++) if (fabs(rdu[k][i]) > err_d) { err_d = fabs(rdu[k][i]); if (getenv("MMPC_ORACLE_DEBUG2")) fprintf(stderr, "  rdu[%d][%d] %.3e\n", k, i, rdu[k][i]); }
+                if (fabs(rds[k]) > err_d) { err_d = fabs(rds[k]); if (getenv("MMPC_ORACLE_DEBUG2")) fprintf(stderr, "  rds[%d] %.3e\n", k, rds[k]); }
             }
         }
         double sd = zsum / (nrows_act + (N + 1) * nx); sd = (sd > 100.0 ? sd : 100.0) / 100.0;
@@ -734,8 +810,16 @@ int mmpc_oracle_solve(const oracle_cfg *cfg, const double *x_init, const double 
         for (int k = 0; k <= N; k++) {
             double vdx = 0; for (int j = 0; j < nx; j++) vdx += w->vx[k][j] * w->dX[k][j];
             if (k == N - 1) for (int j = 0; j < nx; j++) vdx += w->vxN[j] * w->dX[N][j];
+            if (w->nq8 && k >= 1) for (int j = 0; j < nx; j++) vdx += w->vq[k][j] * w->dX[k - 1][j];
             w->ds[k] = -(w->gss[k] - vdx) / w->hss[k];
         }
+        if (w->nq8)   /* a slack eliminated one stage earlier is not part of its own stage's cost-to-go: its pull on x_k enters the
+                       * multiplier of the dynamics directly,  lam_k+ = -(P_k dx_k + p_k) + v_k ds_k */
+            for (int k = 1; k <= N; k++) {
+                int back = 0;
+                if (k != N - 1) for (int i = 0; i < nx; i++) if (w->vq[k][i] != 0.0) back = 1;
+                if (back) for (int i = 0; i < nx; i++) w->lamn[k][i] += w->vx[k][i] * w->ds[k];
+            }
         double tau = fmax(0.99, 1 - mu), ap = 1, ad = 1, dphi = 0;
         for (int k = 0; k <= N; k++) {
             for (int r = 0; r < w->nrow; r++) {
@@ -745,7 +829,8 @@ int mmpc_oracle_solve(const oracle_cfg *cfg, const double *x_init, const double 
                 else if (r < 2 * nu + 2 * nx) { int q = r - 2 * nu; int j = q < nx ? q : q - nx; jd = (q < nx ? -1.0 : 1.0) * w->dX[k][j]; }
                 else if (r < 2 * nu + 2 * nx + w->M) { int m = r - 2 * nu - 2 * nx; jd = w->gcirc[k][m][0] * w->dX[k][0] + w->gcirc[k][m][1] * w->dX[k][1] - w->ds[k]; }
                 else if (r < 2 * nu + 2 * nx + w->M + 4) { int i = r - 2 * nu - 2 * nx - w->M; jd = -w->ds[slack_idx(w, k)]; for (int j = 0; j < 6; j++) jd += w->gself[k][i][j] * w->dX[k][YIDX[j]]; }
-                else { int i = r - 2 * nu - 2 * nx - w->M - 4; jd = -w->ds[k]; for (int j = 0; j < 6; j++) jd += w->ghs[k][i][j] * w->dX[k][YIDX[j]]; }
+                else if (r < SL_Q8(w, 0)) { int i = r - 2 * nu - 2 * nx - w->M - 4; jd = -w->ds[k]; for (int j = 0; j < 6; j++) jd += w->ghs[k][i][j] * w->dX[k][YIDX[j]]; }
+                else { int e = r - SL_Q8(w, 0), kk = k - w->q8br[k][e]; jd = -w->ds[k]; for (int j = 0; j < 6; j++) jd += w->gq8[k][e][j] * w->dX[kk][YIDX[j]]; }
                 double tt = w->t[k][r], zz = w->z[k][r];
                 double dtv = -(w->h[k][r] + tt) - jd, dzv = mu / tt - zz - (zz / tt) * dtv;
                 w->dt_[k][r] = dtv; w->dz[k][r] = dzv;
@@ -793,6 +878,7 @@ int mmpc_oracle_solve(const oracle_cfg *cfg, const double *x_init, const double 
             nfilt = 0; /* filter reset heuristic: the filter blocked every trial step */
         }
         nf += !accepted;
+        if (getenv("MMPC_ORACLE_DEBUG")) fprintf(stderr, "it %d mu %.2e E0 %.3e err_d %.3e err_p %.3e comp %.3e alpha %.3e ap %.3e ad %.3e acc %d prox %.1e dphi %.3e\n", it, mu, E0, err_d, err_p, comp0, alpha, ap, ad, accepted, prox, dphi);
         /* proximal term for crawling iterations (oracle/ipm_numpy.py: Options.prox*) */
         nsmall = alpha < PROX_LO ? nsmall + 1 : 0;
         if (cfg->terminal_xy_eq) prox = 0.0;   /* the forced correction E dx_N = e makes nu grow like prox */

@@ -16,7 +16,8 @@ static void run(const MmpcParams *P, int B, const double *x_init, const double *
                 int *status, int *iters, double *cost, double *err, int reverse) {
     typedef MmpcDims<KIND> D;
     const int N = P->N, M = P->M;
-    MmpcLayout L = mmpc_layout<KIND>(N, M, P->obs_per_stage, (KIND == 0 && P->L > 0) ? 6 : 0);
+    MmpcLayout L = mmpc_layout<KIND>(N, M, P->obs_per_stage, (KIND == 0 && P->L > 0) ? 6 : 0,
+                                     (KIND == 0 && P->L >= 2 && P->as_written) ? 6 * (P->L - 1) : 0);
     const size_t so = (size_t)(P->obs_per_stage ? N + 1 : 1) * M * 3;
     for (int b = 0; b < B; b++) {
         // exact-size heap slab so that ASAN sees any out-of-slab access

@@ -19,7 +19,7 @@ class MmpcParams(C.Structure):
                 ("Q2", C.c_double * 81), ("P2", C.c_double * 81), ("RW2", C.c_double * 25),
                 ("R2", C.c_double * 25), ("W2", C.c_double * 25),
                 ("ulim", (C.c_double * 5) * 2), ("xlim", (C.c_double * 9) * 2), ("dulim", (C.c_double * 5) * 2),
-                ("L", C.c_int), ("hs", (C.c_double * 6) * 8), ("u_guess", C.c_void_p)]
+                ("L", C.c_int), ("hs", (C.c_double * 6) * 8), ("u_guess", C.c_void_p), ("as_written", C.c_int)]
 
 
 def build(asan=False):
@@ -32,7 +32,7 @@ def build(asan=False):
     return out
 
 
-def make_params(par, M, obs_per_stage=False, use_xguess=False, tol=1e-8, mu_init=1.0, max_iter=200, hs=None):
+def make_params(par, M, obs_per_stage=False, use_xguess=False, tol=1e-8, mu_init=1.0, max_iter=200, hs=None, as_written=False):
     """MmpcParams as the C ABI would build it from mmpc_config + weights (terminal_xy_eq from par)."""
     p = MmpcParams()
     nx, nu = par.nx, par.nu
@@ -51,6 +51,7 @@ def make_params(par, M, obs_per_stage=False, use_xguess=False, tol=1e-8, mu_init
         for j in range(nx):
             p.xlim[r][j] = par.xlim[r, j]
     p.L = 0
+    p.as_written = int(bool(as_written))
     if hs is not None and len(hs):
         hs = np.asarray(hs, float).reshape(-1, 6)
         p.L = hs.shape[0]

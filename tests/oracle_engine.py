@@ -9,13 +9,14 @@ from tests import emu_helper
 
 class OracleEngine:
     def __init__(self, kind, N, M, dt, ulim, xlim, dulim, max_batch=1, device=0, obs_per_stage=False, tol=1e-8,
-                 mu_init=1.0, max_iter=200, halfspaces=None):
+                 mu_init=1.0, max_iter=200, halfspaces=None, as_written=False):
         self.kind, self.N, self.M = kind, N, M
         self.par = nlp.WholeBodyParams(N=N, dt=dt) if kind == 0 else nlp.BaseParams(N=N, dt=dt)
         self.par.ulim, self.par.xlim, self.par.dulim = np.asarray(ulim, float), np.asarray(xlim, float), np.asarray(dulim, float)
         self.nx, self.nu = self.par.nx, self.par.nu
         self.hs = halfspaces if halfspaces is not None and len(halfspaces) else None
         self.tol, self.max_iter = tol, max_iter
+        self.as_written = bool(as_written) and self.hs is not None and len(self.hs) >= 2
         self.u_latest = None
         self.x_guess = None
 
@@ -39,7 +40,7 @@ class OracleEngine:
         ul = np.zeros((B, self.N, self.nu)) if self.u_latest is None else self.u_latest[:B]
         X0 = self.x_guess[:B] if (self.kind == 1 and self.x_guess is not None) else None
         r = coracle.solve_batch(self.par, x_init, traj_ref, u_ref, ul, obs, X0=X0, hs=self.hs, tol=self.tol,
-                                max_iter=self.max_iter)
+                                max_iter=self.max_iter, as_written=self.as_written)
         self.u_latest = r["U"].copy()
         self.x_guess = r["X"].copy()
         r["u0"] = r["U"][:, 0, :].copy()

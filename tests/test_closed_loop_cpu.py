@@ -10,7 +10,13 @@ import numpy as np
 from tests import oracle_engine
 
 
-def test_demo_scenario_2_state_machine_on_oracle(mm, monkeypatch):
+import pytest
+
+
+@pytest.mark.parametrize("as_written", [True, False], ids=["nlp_as_written", "intended_rows"])
+def test_demo_scenario_2_state_machine_on_oracle(mm, monkeypatch, as_written):
+    """as_written: the reference's own constructor call (two half-space planes -> quirk Q8 rows in the NLP); every tick's
+    solution is re-checked against the extra rows by the controller.  intended_rows: faithful_convex=False."""
     oracle_engine.patch(monkeypatch, mm)
     dt, N = 0.1, 20
     obstacles = [mm.Obstacles(2.5, 3.0, 0.6), mm.Obstacles(2.5, 1.0, 0.6), mm.Obstacles(5 - 0.6, 5, 0.1)]   # demo_wholebody_qref.py:35-39
@@ -18,7 +24,8 @@ def test_demo_scenario_2_state_machine_on_oracle(mm, monkeypatch):
     manip = [(np.array([2.5, 2, 0.35 + 0.606 + 0.333]), np.array([[r2, 0, r2]])),                          # :30-33
              (np.array([2.5, 2, 0.35 + 0.606 + 0.333]), np.array([[-r2, 0, r2]]))]
     target = np.array([5 - 0.6, 5, 0.606 + 0.333 + 0.5, -np.pi])                                          # :29
-    ctrl = mm.MPCWholeBody(mm.MobileManipulator(dt), obstacles, manip, N=N, faithful_convex=False)
+    ctrl = mm.MPCWholeBody(mm.MobileManipulator(dt), obstacles, manip, N=N, max_iter=2000) if as_written else \
+        mm.MPCWholeBody(mm.MobileManipulator(dt), obstacles, manip, N=N, faithful_convex=False)
     world = mm.Interface(dt, 5, 2, np.zeros(9), target, ctrl, physical_sim=False)
     assert np.allclose(world.x_target, [5.0, 5.0, -np.pi, 0, 0, 0, 0, 0, 0])
     with contextlib.redirect_stdout(io.StringIO()):
@@ -34,6 +41,8 @@ def test_demo_scenario_2_state_machine_on_oracle(mm, monkeypatch):
     assert abs(ctrl.angleDiff(X[-1, 2], -np.pi)) < 0.5 * np.pi / 180 + 1e-3
     # weights were switched by the state machine (interface_wholebody_qref.py:211-215)
     assert np.allclose(np.diag(ctrl.Q_value), [500, 500, 500, 0, 0, 1, 1, 1, 1])
+    if as_written:
+        assert ctrl.q8_margin is not None and ctrl.q8_margin <= ctrl.Q8_TOL
 
 
 def test_interface_rejects_simulator_branch(mm, monkeypatch):

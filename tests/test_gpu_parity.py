@@ -153,46 +153,51 @@ def test_terminal_xy_equality_through_opti_facade(mm):
 
 def test_c1_demo_scenario_with_halfspaces(mm):
     """Config C1: demo_wholebody_qref.py scenario 2 through the reference's constructor signature
-    (obstacle_list + obstacle_manipulation_list, no extra flag), single-instance solve().  With two planes the NLP as
-    written carries L-1 = 1 extra row per (stage >= 1, arm point) that reads the previous stage's `constr` entry (quirk Q8,
-    controllers/_q8.py).  First tick of the demo (x_start = 0): the GPU solution satisfies every one of them, is returned,
-    equals the oracle's and passes the certificate OF THE AS-WRITTEN NLP.  Started under the ridge of the two planes, the
-    solution of the intended rows violates an as-written row: refused (RuntimeError), and faithful_convex=False returns it."""
+    (obstacle_list + obstacle_manipulation_list, no extra flag), single-instance solve().  With two planes the NLP AS WRITTEN
+    carries one extra row per (stage >= 1, arm point) that reads the previous stage's `constr` entry (quirk Q8): the generic
+    kernel solves that NLP.  First tick of the demo (x_start = 0): the extra rows are inactive, the solution equals the one of
+    the intended rows.  Started under the ridge of the two planes the two NLPs differ - the as-written optimum brakes at the
+    input limit (u0[0] = -2) where the intended one coasts (-0.14): GPU = C oracle, and the output passes the certificate OF
+    THE AS-WRITTEN NLP.  faithful_convex=False gives the intended rows."""
     r2 = 1 / np.sqrt(2)
     oml = [(np.array([2.5, 2, 0.35 + 0.606 + 0.333]), np.array([[r2, 0, r2]])),
            (np.array([2.5, 2, 0.35 + 0.606 + 0.333]), np.array([[-r2, 0, r2]]))]          # demo_wholebody_qref.py:30-33
     obstacles = [mm.Obstacles(2.5, 3.0, 0.6), mm.Obstacles(2.5, 1.0, 0.6), mm.Obstacles(5 - 0.6, 5, 0.1)]
     robot = mm.MobileManipulator(0.1)
     ctrl = mm.MPCWholeBody(robot, obstacles, oml, N=20)                                   # the reference's own call (demo:47)
+    loose = mm.MPCWholeBody(robot, obstacles, oml, N=20, faithful_convex=False)
     hs = np.array([np.concatenate([p, n.reshape(3)]) for p, n in oml])
     par = nlp.WholeBodyParams()
     obs = np.array([[2.5, 3.0, 0.6], [2.5, 1.0, 0.6], [4.4, 5, 0.1]])
-    x_start, target = np.zeros(9), np.array([5, 5, -np.pi, 0, 0, 0, 0, 0, 0.0])
-    traj = np.linspace(x_start, target, 51)[:21]
-    u0 = ctrl.solve(x_start.copy(), traj, np.zeros((20, 5)))
-    assert ctrl.q8_margin < 0                                                             # every as-written extra row holds
-    o = coracle.solve_batch(par, x_start[None], traj[None], np.zeros((1, 20, 5)), np.zeros((1, 20, 5)), obs[None], hs=hs)
-    assert o["status"][0] == 0
-    assert np.abs(u0 - o["U"][0, 0]).max() < TOL and np.abs(ctrl.x_guess - o["X"][0]).max() < TOL
-    r = ctrl.solve_batch(x_start[None], traj[None], np.zeros((1, 20, 5)))
-    prob = nlp.Problem(par, x_start, traj, np.zeros((20, 5)), ctrl.u_latest * 0, obs, hs, as_written=True)
-    # (second call: U_last = first optimum)  certificate of the as-written NLP on the first call's output
-    prob1 = nlp.Problem(par, x_start, traj, np.zeros((20, 5)), np.zeros((20, 5)), obs, hs, as_written=True)
-    c = nlp.kkt_certificate_ipopt(prob1, ctrl.x_guess, ctrl.u_latest, o["s"][0])
-    assert c["E0"] <= 3e-8 and c["ineq_violation"] == 0.0, c
-    assert r["status"][0] == 0 and r["q8_margin"][0] < 0
-    # under the "tent": the intended solution crosses the ridge between two stages -> an as-written row is violated
-    x2 = np.array([1.9, 2.0, 0.0, 0.3, 0, 0, 0.3, -1.2, 1.6]); t2 = np.array([3.2, 2.0, 0, 0, 0, 0, 0.3, -1.2, 1.6])
-    traj2 = np.linspace(x2, t2, 51)[:21]
-    ctrl.reset()
-    with pytest.raises(RuntimeError, match="as-written"):
-        ctrl.solve(x2.copy(), traj2, np.zeros((20, 5)))
-    assert ctrl.q8_margin > 1e-3
-    loose = mm.MPCWholeBody(robot, obstacles, oml, N=20, faithful_convex=False)
-    u0 = loose.solve(x2.copy(), traj2, np.zeros((20, 5)))
-    o = coracle.solve_batch(par, x2[None], traj2[None], np.zeros((1, 20, 5)), np.zeros((1, 20, 5)), obs[None], hs=hs)
-    assert o["status"][0] == 0
-    assert np.abs(u0 - o["U"][0, 0]).max() < TOL and np.abs(loose.x_guess - o["X"][0]).max() < TOL
+    z = np.zeros((1, 20, 5))
+    starts = ((np.zeros(9), np.array([5, 5, -np.pi, 0, 0, 0, 0, 0, 0.0])),
+              (np.array([1.9, 2.0, 0.0, 0.3, 0, 0, 0.3, -1.2, 1.6]), np.array([3.2, 2.0, 0, 0, 0, 0, 0.3, -1.2, 1.6])))
+    for case, (x_start, target) in enumerate(starts):
+        traj = np.linspace(x_start, target, 51)[:21]
+        ctrl.reset(); loose.reset()
+        u0 = ctrl.solve(x_start.copy(), traj, z[0])
+        assert ctrl.q8_margin <= ctrl.Q8_TOL                                              # every as-written extra row holds
+        o = coracle.solve_batch(par, x_start[None], traj[None], z, z, obs[None], hs=hs, as_written=True, max_iter=2000)
+        assert o["status"][0] == 0
+        assert np.abs(u0 - o["U"][0, 0]).max() < TOL and np.abs(ctrl.x_guess - o["X"][0]).max() < TOL
+        prob = nlp.Problem(par, x_start, traj, z[0], z[0], obs, hs, as_written=True)
+        c = nlp.kkt_certificate_ipopt(prob, ctrl.x_guess, ctrl.u_latest, o["s"][0])
+        assert c["E0"] <= 3e-8 and c["ineq_violation"] <= 1e-8, (case, c)
+        u0i = loose.solve(x_start.copy(), traj, z[0])
+        oi = coracle.solve_batch(par, x_start[None], traj[None], z, z, obs[None], hs=hs, max_iter=2000)
+        assert oi["status"][0] == 0
+        assert np.abs(u0i - oi["U"][0, 0]).max() < TOL and np.abs(loose.x_guess - oi["X"][0]).max() < TOL
+        if case == 0:
+            assert np.abs(u0 - u0i).max() < 1e-6                                          # extra rows inactive: same optimum
+        else:
+            assert u0[0] < -1.99 and u0i[0] > -0.2                                        # the two NLPs differ under the ridge
+            q8 = mm.controllers._q8
+            assert q8.as_written_extra_rows(loose.x_guess, oi["s"][0], hs).max() > 1e-2   # intended optimum violates an extra row
+    # batched call, as-written: status and margin per instance
+    xs = np.stack([s_[0] for s_ in starts]); trs = np.stack([np.linspace(a, b, 51)[:21] for a, b in starts])
+    cb = mm.MPCWholeBody(robot, obstacles, oml, N=20, max_batch=2)
+    r = cb.solve_batch(xs, trs, np.zeros((2, 20, 5)))
+    assert (r["status"] == 0).all() and (r["q8_margin"] <= cb.Q8_TOL).all()
 
 
 def test_full_size_properties(mm):
@@ -288,7 +293,7 @@ def test_closed_loop_demo_state_machine(mm):
     manip = [(np.array([2.5, 2, 0.35 + 0.606 + 0.333]), np.array([[r2, 0, r2]])),
              (np.array([2.5, 2, 0.35 + 0.606 + 0.333]), np.array([[-r2, 0, r2]]))]
     target = np.array([5 - 0.6, 5, 0.606 + 0.333 + 0.5, -np.pi])
-    ctrl = mm.MPCWholeBody(mm.MobileManipulator(dt), obstacles, manip, N=N, faithful_convex=False)
+    ctrl = mm.MPCWholeBody(mm.MobileManipulator(dt), obstacles, manip, N=N)      # the NLP as written (two planes: quirk Q8 rows)
     world = mm.Interface(dt, 5, 2, np.zeros(9), target, ctrl, physical_sim=False)
     import contextlib, io
     with contextlib.redirect_stdout(io.StringIO()):
@@ -302,6 +307,7 @@ def test_closed_loop_demo_state_machine(mm):
         assert (np.hypot(X[:, 0] - o.x, X[:, 1] - o.y) >= o.radius + 0.4 - 5e-3).all()   # soft rows (S = 1e5): mm-level slack
     assert np.linalg.norm(world.current_joints_pose[:3] - target[:3]) <= 0.01
     assert np.abs(X[-1, :2] - world.x_target[:2]).max() < 0.02
+    assert ctrl.q8_margin <= ctrl.Q8_TOL
 
 
 @pytest.mark.gpu

@@ -70,3 +70,35 @@ def test_ridge_crossing_violates_only_the_as_written_rows():
     s = np.zeros(2)
     assert (-c[:, i].max(axis=-1) - s).max() <= 0                  # the intended rows of this point hold at both stages
     assert q8.as_written_extra_rows(X, s, HS2)[0, i, 0] > 0        # the as-written row of stage 1 does not
+
+
+def test_c_oracle_solves_the_nlp_as_written():
+    """oracle/mmpc_oracle.c with cfg.as_written: the start under the ridge of the demo's two planes.  The intended optimum
+    violates an extra row (refuted by the certificate of the as-written NLP); the as-written solve converges to a different
+    point - full braking - that passes it.  The host build of the generic kernel runs the same iterations."""
+    import emu_helper
+    from oracle import coracle
+    par = nlp.WholeBodyParams()
+    obs = np.array([[2.5, 3.0, 0.6], [2.5, 1.0, 0.6], [4.4, 5, 0.1]])
+    x0 = np.array([1.9, 2.0, 0.0, 0.3, 0, 0, 0.3, -1.2, 1.6]); tg = np.array([3.2, 2.0, 0, 0, 0, 0, 0.3, -1.2, 1.6])
+    traj = np.linspace(x0, tg, 51)[:21]
+    z = np.zeros((1, 20, 5))
+    prob = nlp.Problem(par, x0, traj, z[0], z[0], obs, HS2, as_written=True)
+    oi = coracle.solve_batch(par, x0[None], traj[None], z, z, obs[None], hs=HS2, max_iter=2000)
+    ci = nlp.kkt_certificate_ipopt(prob, oi["X"][0], oi["U"][0], oi["s"][0])
+    assert oi["status"][0] == 0 and ci["ineq_violation"] > 1e-2                  # intended optimum: not feasible for the NLP as written
+    ow = coracle.solve_batch(par, x0[None], traj[None], z, z, obs[None], hs=HS2, max_iter=2000, as_written=True)
+    cw = nlp.kkt_certificate_ipopt(prob, ow["X"][0], ow["U"][0], ow["s"][0])
+    assert ow["status"][0] == 0 and cw["E0"] <= 3e-8, cw
+    assert ow["U"][0, 0, 0] < -1.99 and oi["U"][0, 0, 0] > -0.2 and ow["cost"][0] > oi["cost"][0] + 1.0
+    for rev in (False, True):
+        e = emu_helper.solve_batch(par, x0[None], traj[None], z, z, obs[None], hs=HS2, max_iter=2000, as_written=True, reverse=rev)
+        assert e["status"][0] == 0 and e["iters"][0] == ow["iters"][0]
+        assert np.abs(e["X"] - ow["X"]).max() < 1e-9 and np.abs(e["U"] - ow["U"]).max() < 1e-9
+    # three planes (the mmax branch of obsAvoidConvex, :87): two extra rows per (stage, point)
+    o3 = coracle.solve_batch(par, x0[None], traj[None], z, z, obs[None], hs=HS3, max_iter=2000, as_written=True)
+    p3 = nlp.Problem(par, x0, traj, z[0], z[0], obs, HS3, as_written=True)
+    c3 = nlp.kkt_certificate_ipopt(p3, o3["X"][0], o3["U"][0], o3["s"][0])
+    assert o3["status"][0] == 0 and c3["E0"] <= 3e-8, c3
+    e3 = emu_helper.solve_batch(par, x0[None], traj[None], z, z, obs[None], hs=HS3, max_iter=2000, as_written=True)
+    assert e3["iters"][0] == o3["iters"][0] and np.abs(e3["X"] - o3["X"]).max() < 1e-9
