@@ -779,7 +779,11 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
         double sd = zsum / (double)(nrows_act + NS * NX);
         sd = (sd > 100.0 ? sd : 100.0) / 100.0;
         E0 = mmpc_max(mmpc_max(err_d / sd, err_p), tzmax / sd);
-        if (!(E0 == E0) || !mmpc_finite(E0)) { status = 2; break; }
+        if (!(E0 == E0) || !mmpc_finite(E0)) {
+#ifdef MMPC_EMU_DEBUG
+            fprintf(stderr, "generic: E0 not finite at it %d: err_d %g err_p %g tzmax %g zsum %g\n", it, err_d, err_p, tzmax, zsum);
+#endif
+            status = 2; break; }
         if (E0 <= tol) { status = 0; break; }
         if (it == P.max_iter) break;
         {
@@ -1075,12 +1079,12 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                         MF[e] = v;
                     } else if (e < NXX + NU * NX) {
                         const int e2 = e - NXX, a = e2 / NX, j = e2 % NX, col = NX + a;
-                        double v = (k == N - 1 ? HUXL[e2] : (NQ ? HUXS[k * NU * NX + e2] : 0.0)) + ((a == 0 && j == 2) ? HUX02[k] : 0.0);
+                        double v = (k == N - 1 ? HUXL[e2] : 0.0) + (NQ ? HUXS[k * NU * NX + e2] : 0.0) + ((a == 0 && j == 2) ? HUX02[k] : 0.0);
                         for (int q = 0; q < 4; q++) v += cv[TB::ccv(col, q)] * TT[TB::crow(col, q) * NV + j];
                         MG[e2] = v;
                     } else if (e < NXX + NU * NX + NUU) {
                         const int e2 = e - NXX - NU * NX, a = kTriI[e2], b = kTriJ[e2], col = NX + a;
-                        double v = WTS[MMPC_W_RW2 + a * NU + b] + (a == b ? HUUD[k * NU + a] : 0.0) + (k == N - 1 ? HUUL[e2] : (NQ ? HUUS[k * NUU + e2] : 0.0));
+                        double v = WTS[MMPC_W_RW2 + a * NU + b] + (a == b ? HUUD[k * NU + a] : 0.0) + (k == N - 1 ? HUUL[e2] : 0.0) + (NQ ? HUUS[k * NUU + e2] : 0.0);
                         for (int q = 0; q < 4; q++) v += cv[TB::ccv(col, q)] * TT[TB::crow(col, q) * NV + NX + b];
                         MH[e2] = v;
                     } else {
@@ -1172,6 +1176,9 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                 }
                 LANES_END
             }
+#ifdef MMPC_EMU_DEBUG
+            if (failed) fprintf(stderr, "generic it %d: attempt %d lost a pivot (prox %g)\n", it, attempt, prox);
+#endif
             if (!failed) break;
             if (attempt == 2) {
                 // even the Gauss-Newton pass lost a pivot (round-off under barrier weights z/t ~ 1e9 and more): raise the
@@ -1185,7 +1192,11 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
             if (lane == 0) MISC[0] = 0.0;
             LANES_END
         }
-        if (failed) { status = 2; break; }
+        if (failed) {
+#ifdef MMPC_EMU_DEBUG
+            fprintf(stderr, "generic: factorisation failed at it %d (prox %g)\n", it, prox);
+#endif
+            status = 2; break; }
 
         if (teq) {
             // the direction is affine in the two terminal multipliers: roll out the nu = 0 solution and the two
@@ -1455,6 +1466,9 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
             if (accepted || nfilt == 0) break;
             nfilt = 0;  // filter reset heuristic: the filter blocked every trial step
         }
+#ifdef MMPC_EMU_DEBUG
+        fprintf(stderr, "generic it %d mu %.2e E0 %.3e err_d %.3e err_p %.3e alpha %.3e ap %.3e ad %.3e prox %.1e dphi %.3e\n", it, mu, E0, err_d, err_p, alpha, ap, ad, prox, dphi);
+#endif
         if (!teq) mmpc_prox_update(alpha, prox, nsmall);   // (with the terminal equality the forced correction makes nu grow like prox)
         // ---- update
         LANES_BEGIN

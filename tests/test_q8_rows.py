@@ -102,3 +102,22 @@ def test_c_oracle_solves_the_nlp_as_written():
     assert o3["status"][0] == 0 and c3["E0"] <= 3e-8, c3
     e3 = emu_helper.solve_batch(par, x0[None], traj[None], z, z, obs[None], hs=HS3, max_iter=2000, as_written=True)
     assert e3["iters"][0] == o3["iters"][0] and np.abs(e3["X"] - o3["X"]).max() < 1e-9
+
+
+def test_as_written_tick_with_two_slacks_folded_into_the_last_stage():
+    """Tick 18 of the closed-loop demo (inputs recorded on the GPU run, tests/golden/q8_closed_loop_tick18.npz): s_N reaches
+    back to x_{N-1} while the terminal self rows tie s_{N-1} to x_N - stage N-1 then carries the dense blocks of BOTH
+    eliminations.  The host build of the generic kernel must run the C oracle's iterations (it lost its pivots when only
+    one of the two blocks reached the recursion)."""
+    import os
+    import emu_helper
+    from oracle import coracle
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "q8_closed_loop_tick18.npz"))
+    par = nlp.WholeBodyParams(); par.Q, par.P, par.R, par.W = z["Q"], z["P"], z["R"], z["W"]
+    o = coracle.solve_batch(par, z["x"], z["t"], z["u"], z["ul"], z["o"], hs=HS2, max_iter=2000, as_written=True)
+    e = emu_helper.solve_batch(par, z["x"], z["t"], z["u"], z["ul"], z["o"], hs=HS2, max_iter=2000, as_written=True)
+    assert o["status"][0] == 0 and e["status"][0] == 0 and e["iters"][0] == o["iters"][0]
+    assert np.abs(e["X"] - o["X"]).max() < 1e-9 and np.abs(e["U"] - o["U"]).max() < 1e-9
+    prob = nlp.Problem(par, z["x"][0], z["t"][0], z["u"][0], z["ul"][0], z["o"][0], HS2, as_written=True)
+    c = nlp.kkt_certificate_ipopt(prob, e["X"][0], e["U"][0], e["s"][0])
+    assert c["E0"] <= 3e-8, c
