@@ -351,3 +351,46 @@ def test_iteration_budget_and_continuation(mm):
     eng.set_iteration_budget(0)
     with pytest.raises(RuntimeError):
         mm.MPCWholeBody(mm.MobileManipulator(0.1), [], [], N=12, max_batch=4, n_obstacles=2)._engine.set_iteration_budget(8)   # generic kernel
+
+
+@pytest.mark.parametrize("nplanes", [2, 3])
+def test_as_written_halfspace_rows_batch(mm, nplanes):
+    """64 starts around the demo's 'tent', half-space rows AS WRITTEN (quirk Q8, mmpc_config.as_written; L = 2: the if_else
+    branch of obsAvoidConvex, L = 3: mmax): GPU (generic kernel) vs the C oracle, and the certificate of the as-written NLP on
+    every converged GPU output.  In about a third of these starts the intended optimum violates an as-written row."""
+    r2 = 1 / np.sqrt(2)
+    if nplanes == 2:
+        hs = np.array([[2.5, 2, 0.35 + 0.606 + 0.333, r2, 0, r2], [2.5, 2, 0.35 + 0.606 + 0.333, -r2, 0, r2]])
+    else:
+        hs = np.array([[2.5, 2, 1.3, r2, 0, r2], [2.5, 2, 1.3, -r2, 0, r2], [2.5, 2, 1.5, 0, 0, 1.0]])
+    B, N = 64, 20
+    rng = np.random.default_rng(11)
+    x = np.zeros((B, 9)); tr = np.zeros((B, N + 1, 9))
+    for b in range(B):
+        x0 = np.array([rng.uniform(1.4, 2.6), rng.uniform(1.6, 2.4), rng.uniform(-0.4, 0.4), rng.uniform(0, 0.8), 0, 0,
+                       rng.uniform(-0.3, 0.6), rng.uniform(-1.6, -0.6), rng.uniform(0.8, 2.2)])
+        x0[4] = x0[3] * np.sin(x0[2]); x0[3] = x0[3] * np.cos(x0[2])
+        tg = x0.copy(); tg[0] += rng.uniform(0.8, 1.8); tg[1] += rng.uniform(-0.3, 0.3); tg[3:6] = 0
+        x[b] = x0; tr[b] = np.linspace(x0, tg, 51)[:N + 1]
+    obs = np.broadcast_to(np.array([[2.5, 3.4, 0.3], [2.5, 0.6, 0.3], [6, 6, 0.1]]), (B, 3, 3)).copy()
+    z = np.zeros((B, N, 5))
+    par = nlp.WholeBodyParams()
+    oml = [(h[:3], h[3:].reshape(1, 3)) for h in hs]
+    ctrl = mm.MPCWholeBody(mm.MobileManipulator(0.1), [], oml, N=N, max_batch=B, n_obstacles=3)      # the NLP as written
+    r = ctrl.solve_batch(x, tr, z, obs)
+    o = coracle.solve_batch(par, x, tr, z, z, obs, hs=hs, max_iter=2000, nthreads=16, as_written=True)
+    conv = (r["status"] == 0) & (o["status"] == 0)
+    assert conv.sum() >= (B if nplanes == 2 else B - 4), (np.nonzero(r["status"])[0].tolist(), np.nonzero(o["status"])[0].tolist())
+    assert (r["q8_margin"][r["status"] == 0] <= ctrl.Q8_TOL).all()
+    same = conv & (np.abs(r["cost"] / o["cost"] - 1) < 1e-6)
+    assert same.sum() >= conv.sum() - 3
+    assert np.abs(r["X"][same] - o["X"][same]).max() < 1e-5 and np.abs(r["U"][same] - o["U"][same]).max() < 1e-5
+    ok = np.nonzero(r["status"] == 0)[0]
+    cs = certify([(nlp.Problem(par, x[b], tr[b], z[b], z[b], obs[b], hs, as_written=True), r["X"][b], r["U"][b], r["s"][b]) for b in ok])
+    E0 = np.array([c["E0"] for c in cs])
+    assert E0.max() <= CERT_TOL, (int(ok[int(np.argmax(E0))]), E0.max())
+    # the as-written rows matter here: solved with the intended rows only, many of these optima violate one
+    loose = mm.MPCWholeBody(mm.MobileManipulator(0.1), [], oml, N=N, max_batch=B, n_obstacles=3, faithful_convex=False)
+    ri = loose.solve_batch(x, tr, z, obs)
+    viol = mm.controllers._q8.as_written_extra_rows(ri["X"], ri["s"], hs).reshape(B, -1).max(1)
+    assert (viol > 1e-6).sum() >= 8
