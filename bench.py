@@ -339,6 +339,28 @@ def main():
                     lat.append(time.perf_counter() - l0)
             res["single_solve_latency_ms"] = {"median": 1e3 * float(np.median(lat[2:])), "max": 1e3 * float(np.max(lat[2:])),
                                               "note": "MPCWholeBody.solve() for one instance, host arrays in, u0 out (10 solves)"}
+            # (5) a four times larger resident batch (seeds s, s+1, s+2, s+3 of the generator in one launch): the drain of a launch
+            # - CUs idling while the last waves finish - is a fixed cost, so bigger shards amortise it
+            if (N, M) == (20, 5) and Bl == 8192:
+                parts = [d] + [synth.make_batch(Bl, N=N, M=M, config_id=args.seed_base + q) for q in (1, 2, 3)]
+                cat = lambda key: torch.from_numpy(np.ascontiguousarray(np.concatenate([p_[key] for p_ in parts]))).to(dev)
+                ctrl4 = mm.MPCWholeBody(robot, [], [], N=N, max_batch=4 * Bl, device=local_dev, n_obstacles=M)
+                ctrl4._engine.set_schedule_hint(2)
+                x4 = torch.from_numpy(np.clip(np.concatenate([p_["x_init"] for p_ in parts]), ctrl.xlim[0], ctrl.xlim[1])).to(dev)
+                t4, u4, o4 = cat("traj_ref"), cat("u_ref"), cat("obs")
+                ul4 = torch.zeros((4 * Bl, N, nu), dtype=torch.float64, device=dev)
+                out4 = ctrl4._engine.solve_batch_device(x4, t4, u4, ul4, o4)
+                ts = []
+                for _ in range(3):
+                    ev0.record()
+                    ctrl4._engine.solve_batch_device(x4, t4, u4, ul4, o4, out=out4)
+                    ev1.record(); ev1.synchronize()
+                    ts.append(ev0.elapsed_time(ev1))
+                l_ms = sorted(ts)[1]
+                res["large_batch"] = {"batch": 4 * Bl, "ms": l_ms, "value": 4 * Bl / (l_ms * 1e-3), "unit": "solves/s",
+                                      "max_iters": int(out4["iters"].max()), "converged_frac": float((out4["status"] == 0).double().mean()),
+                                      "note": "one launch of 32768 instances (seeds %d..%d), a-priori order" % (args.seed_base, args.seed_base + 3)}
+                del ctrl4, out4, x4, t4, u4, o4, ul4
             res["cpu_baseline"] = cpu_baseline(d, N, M, min(args.cpu_sample, Bl), out["X"])
         print(json.dumps(res))
     if world > 1:
@@ -363,9 +385,13 @@ def cpu_baseline(d, N, M, ns, gpu_X, obs=None, u_last=None, x_init=None, traj=No
         o = coracle.solve_batch(par, xi, tr, d["u_ref"][:ns], ul, ob, nthreads=cores, max_iter=2000)
         passes += 1
     ct = (time.perf_counter() - c0) / passes
+    n1 = min(512, ns)                                     # the same port on ONE core (a 512-instance sample)
+    c1 = time.perf_counter()
+    coracle.solve_batch(par, xi[:n1], tr[:n1], d["u_ref"][:n1], ul[:n1], ob[:n1], nthreads=1, max_iter=2000)
+    one_core = n1 / (time.perf_counter() - c1)
     gX = gpu_X[:ns].cpu().numpy()
     dev = np.abs(gX - o["X"]).reshape(ns, -1).max(1)
-    return {"value": ns / ct, "unit": "solves/s", "cores": cores, "kind": "port",
+    return {"value": ns / ct, "unit": "solves/s", "cores": cores, "kind": "port", "value_1_core": one_core,
             "sample": "first %d instances of the same batch, oracle/mmpc_oracle.c (OpenMP), %d passes, %.1f s in all" % (ns, passes, ct * passes),
             "max_abs_dX_vs_gpu": float(dev.max()), "n_dX_above_1e-6": int((dev > 1e-6).sum()),
             "casadi": "CasADi/IPOPT baseline unavailable on this host" if not _has_casadi() else "importable"}
