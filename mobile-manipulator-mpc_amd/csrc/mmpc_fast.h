@@ -147,10 +147,11 @@ MMPC_DEV void mmpc_arm_segments_fast(double q1, double q2, double q3, double dr[
 MMPC_HD constexpr int mmpc_y(int a) { return a < 3 ? a : a + 3; }
 
 #ifndef MMPC_UNROLL_NMAX
-#define MMPC_UNROLL_NMAX 20
+#define MMPC_UNROLL_NMAX 30  // (round 2, after the Riccati rewrite: the N = 30 instantiation gains 10.5 % from the unrolled loops; round 1: it lost)
 #endif
 #ifndef MMPC_FWD_UNROLL
-#define MMPC_FWD_UNROLL 20  // stages per trip of the forward roll-out loop (measured with the register-exchange loop: 2, 4, 10, 20 -> 1098, 1108, 1104, 1124 k solves/s)
+#define MMPC_FWD_UNROLL 64  // stages per trip of the forward roll-out loop; >= N: fully unrolled (measured at N = 20: 2, 4, 10, 20 -> 1098, 1108,
+                            // 1104, 1124 k solves/s; at N = 30 on C5: 1, 2, 5, 10, 30 -> 197, 214, 214, 215, 218 k solves/s)
 #endif
 #ifndef MMPC_RIC_UNROLL
 #define MMPC_RIC_UNROLL 2   // stages per trip of the Riccati loop (measured best of 1, 2, 4, 5)
@@ -367,9 +368,13 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
     constexpr int M = MC;   // number of circle obstacles is a template parameter on this path
     // stages per trip of the Riccati / forward loops: unrolling saves the per-stage pointer bumps and register shuffles,
     // but costs registers - it only pays where the kernel does not spill (measured per instantiation)
+#ifdef MMPC_UNROLL_BASE
+    constexpr bool ROOMY = N <= MMPC_UNROLL_NMAX;
+#else
     constexpr bool ROOMY = KIND == 0 && N <= MMPC_UNROLL_NMAX;
+#endif
     constexpr bool SLIM = N >= MMPC_SLIM_NMIN;   // references and per-stage obstacles are read from HBM/L2 (see mmpc_fast_layout)
-    constexpr int RIC_UNROLL = ROOMY ? MMPC_RIC_UNROLL : 1, FWD_UNROLL = ROOMY ? MMPC_FWD_UNROLL : 1;
+    constexpr int RIC_UNROLL = ROOMY ? MMPC_RIC_UNROLL : 1, FWD_UNROLL = ROOMY ? (MMPC_FWD_UNROLL < N ? MMPC_FWD_UNROLL : N) : 1;
     const MmpcFastLayout L = mmpc_fast_layout<KIND, N>(M, P.obs_per_stage);
     double *XU = lds + L.XU, *S = lds + L.S, *LAM = lds + L.LAM, *XUREF = lds + L.XUREF, *ULAST = lds + L.ULAST,
            *OBS = lds + L.OBS, *CST = lds + L.CST, *CV = lds + L.CV, *CD = lds + L.CD, *TRG = lds + L.TRG, *HXX = lds + L.HXX,
