@@ -250,6 +250,20 @@ MMPC_DEV void mmpc_arm_segments(double q1, double q2, double q3, double dr[3], d
     dz[2] = -MMPC_A6 * sB - MMPC_A7 * cB;
 }
 
+// n = sqrt(m) and inv = -1 / (2 n).  Device: v_rsq_f64 + one cubic step and one correction of the root (<= 1-2 ulp) - the
+// IEEE sqrt and division sequences are ~75 instructions per row, this is 11
+MMPC_DEV void mmpc_sqrt_pair(double m, double *n, double *inv) {
+#ifdef MMPC_EMU
+    *n = sqrt(m); *inv = -1.0 / (2 * *n);
+#else
+    const double y0 = __builtin_amdgcn_rsq(m), e = fma(-(m * y0), y0, 1.0);
+    const double y = fma(y0 * e, fma(0.375, e, 0.5), y0);   // cubic step: 1.4e-16 (tools/rcp_probe.hip)
+    const double r = m * y;
+    *n = fma(fma(-r, r, m), 0.5 * y, r);
+    *inv = -0.5 * y;
+#endif
+}
+
 // self-collision row i (mpc_wholebody_qref.py:219-222): h = 0.05 - ||alpha j2 + beta j3 - e||
 // (world points).  g6 (may be null) = dh/d(x,y,psi,q1,q2,q3).
 MMPC_DEV double mmpc_self_row(int i, double px, double py, double c, double s, const double dr[3], const double dz[3],
@@ -261,14 +275,14 @@ MMPC_DEV double mmpc_self_row(int i, double px, double py, double c, double s, c
     const double Z = kap * MMPC_BZ + cm0 * dz[0] + cm1 * dz[1] + cm2 * dz[2];
     const double C = px * c + py * s, Dv = -px * s + py * c;
     const double mm = kap * kap * (px * px + py * py) + 2 * kap * R * C + R * R + Z * Z;
-    const double n = sqrt(mm);
+    double n, inv;
+    mmpc_sqrt_pair(mm, &n, &inv);
     if (g6) {
         // segment m rotates with angle a_m.q, a_1=(1,0,0), a_2=(1,-1,0), a_3=(1,-1,-1)
         const double z0 = cm0 * dz[0], z1 = cm1 * dz[1], z2 = cm2 * dz[2];
         const double r0 = cm0 * dr[0], r1 = cm1 * dr[1], r2 = cm2 * dr[2];
         const double Ri0 = z0 + z1 + z2, Ri1 = -z1 - z2, Ri2 = -z2;
         const double Zi0 = -(r0 + r1 + r2), Zi1 = r1 + r2, Zi2 = r2;
-        const double inv = -1.0 / (2 * n);
         const double f = 2 * (kap * C + R);
         g6[0] = (2 * kap * kap * px + 2 * kap * R * c) * inv;
         g6[1] = (2 * kap * kap * py + 2 * kap * R * s) * inv;

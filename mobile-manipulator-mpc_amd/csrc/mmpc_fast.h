@@ -78,6 +78,16 @@ MMPC_DEV void mmpc_sincos(double x, double *sn, double *cs) {
     *sn = (q & 2) ? -sa : sa;
     *cs = ((q + 1) & 2) ? -ca : ca;
 }
+// max / min of this path: v_max_f64 / v_min_f64 on the device (the ternary form of mmpc_core.h costs a compare and two selects
+// per use - it hands a NaN in its second argument through; here NaNs are caught by the sums of the evaluation instead, see the
+// status 2 test of the main loop)
+#ifdef MMPC_EMU
+MMPC_DEV double mmpc_vmax(double a, double b) { return a > b ? a : b; }
+MMPC_DEV double mmpc_vmin(double a, double b) { return a < b ? a : b; }
+#else
+MMPC_DEV double mmpc_vmax(double a, double b) { return __builtin_fmax(a, b); }
+MMPC_DEV double mmpc_vmin(double a, double b) { return __builtin_fmin(a, b); }
+#endif
 #ifdef MMPC_EMU
 MMPC_DEV double mmpc_rcp(double x) { return 1.0 / x; }
 MMPC_DEV double mmpc_rsqrt(double x) { return 1.0 / sqrt(x); }
@@ -85,21 +95,16 @@ MMPC_DEV double mmpc_rcp3(double x) { return 1.0 / x; }
 MMPC_DEV double mmpc_powf(double x, float e) { return (double)exp2f(e * log2f((float)x)); }
 MMPC_DEV void mmpc_sched_fence() {}
 #else
-// v_rcp_f64 / v_rsq_f64 + Newton steps (<= 1-2 ulp); the IEEE division / sqrt sequences are ~3x longer
+// v_rcp_f64 / v_rsq_f64 (seeds good to 2^-24, tools/rcp_probe.hip) + one cubic step: 1.1e-16 / 1.4e-16 worst relative error in three
+// / five dependent operations; the IEEE division / sqrt sequences are ~3x longer
 MMPC_DEV double mmpc_rcp(double x) {
-    double r = __builtin_amdgcn_rcp(x);
-    r = fma(fma(-x, r, 1.0), r, r);
-    return fma(fma(-x, r, 1.0), r, r);
-}
-// one cubic step r0 (1 + e + e^2), e = 1 - x r0: full precision from the ~2^-23 seed with a shorter dependent chain
-MMPC_DEV double mmpc_rcp3(double x) {
     const double r = __builtin_amdgcn_rcp(x), e = fma(-x, r, 1.0);
-    return fma(fma(e, e, e), r, r);
+    return fma(fma(e, e, e), r, r);                    // r (1 + e + e^2), e = 1 - x r
 }
+MMPC_DEV double mmpc_rcp3(double x) { return mmpc_rcp(x); }
 MMPC_DEV double mmpc_rsqrt(double x) {
-    double y = __builtin_amdgcn_rsq(x);
-    y = y * fma(-0.5 * x * y, y, 1.5);
-    return y * fma(-0.5 * x * y, y, 1.5);
+    const double y = __builtin_amdgcn_rsq(x), e = fma(-(x * y), y, 1.0);
+    return fma(y * e, fma(0.375, e, 0.5), y);          // y (1 + e/2 + 3 e^2/8), e = 1 - x y^2
 }
 // x^e in single precision (only used by the filter's switching rule, a heuristic threshold)
 MMPC_DEV double mmpc_powf(double x, float e) { return (double)__builtin_amdgcn_exp2f(e * __builtin_amdgcn_logf((float)x)); }
@@ -114,7 +119,7 @@ MMPC_DEV void mmpc_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 // two IEEE divisions (38 inlined call sites in the trial-point phase)
 MMPC_DEV double mmpc_z_safeguard_fast(double z, double t, double mu) {
     const double rt = mmpc_rcp(t);
-    return mmpc_min(mmpc_max(z, (mu * (1.0 / MMPC_KAPPA_SIGMA)) * rt), (MMPC_KAPPA_SIGMA * mu) * rt);
+    return mmpc_vmin(mmpc_vmax(z, (mu * (1.0 / MMPC_KAPPA_SIGMA)) * rt), (MMPC_KAPPA_SIGMA * mu) * rt);
 }
 // natural log of a product of mantissas m in (0,1]: renormalise to [sqrt(1/2), sqrt(2)), then
 // log m = 2 atanh(s), s = (m-1)/(m+1), |s| < 0.1716, odd series to s^21 (< 1e-17)
@@ -160,7 +165,7 @@ MMPC_HD constexpr int mmpc_y(int a) { return a < 3 ? a : a + 3; }
 // slack of a box row = distance of the variable to its bound.  The fraction-to-boundary rule keeps it positive in exact
 // arithmetic ((1-tau) t with 1-tau down to 1e-9), but v + alpha dv is rounded to the grid of v (4e-16 near |v| = 2), so a
 // distance of that size can round to zero: floor it at a couple of ulps.
-MMPC_DEV double mmpc_box_t(double d) { return mmpc_max(d, 1e-15); }
+MMPC_DEV double mmpc_box_t(double d) { return mmpc_vmax(d, 1e-15); }
 
 template <int KIND, int N>
 struct MmpcFastDims {
@@ -317,12 +322,12 @@ MMPC_DEV double mmpc_wave_sum(double v) {
 }
 MMPC_DEV double mmpc_wave_max(double v) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = mmpc_max(v, __shfl_xor(v, o));
+    for (int o = 32; o > 0; o >>= 1) v = mmpc_vmax(v, __shfl_xor(v, o));
     return v;
 }
 MMPC_DEV double mmpc_wave_min(double v) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = mmpc_min(v, __shfl_xor(v, o));
+    for (int o = 32; o > 0; o >>= 1) v = mmpc_vmin(v, __shfl_xor(v, o));
     return v;
 }
 #define MMPC_RED_SUM(i) mmpc_wave_sum(wr_one[i])
@@ -409,7 +414,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
         double val, ref;
         if (v < NX) {
             double x0 = io.x_init[v];
-            if (KIND == 0) x0 = mmpc_max(mmpc_min(x0, P.xlim[1][v]), P.xlim[0][v]);
+            if (KIND == 0) x0 = mmpc_vmax(mmpc_vmin(x0, P.xlim[1][v]), P.xlim[0][v]);
             val = (io.x_guess && k >= 1) ? io.x_guess[k * NX + v] : x0;
             ref = io.traj_ref[k * NX + v];
         } else {
@@ -533,8 +538,8 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
         } else {
             const int a = v - NX;
             const double ul = ulast_at(k, a);
-            lo = mmpc_max(CST[MMPC_C_ULIM + a], ul + CST[MMPC_C_DULIM + a]);
-            hi = mmpc_min(CST[MMPC_C_ULIM + 5 + a], ul + CST[MMPC_C_DULIM + 5 + a]);
+            lo = mmpc_vmax(CST[MMPC_C_ULIM + a], ul + CST[MMPC_C_DULIM + a]);
+            hi = mmpc_vmin(CST[MMPC_C_ULIM + 5 + a], ul + CST[MMPC_C_DULIM + 5 + a]);
             const bool ex = k < N;
             alo = ex && mmpc_finite(lo); ahi = ex && mmpc_finite(hi);
         }
@@ -585,7 +590,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
             const double *o = obs_ptr(k, m);
             const double dx = xk[0] - o[0], dy = xk[1] - o[1];
             const double h = (o[2] + MMPC_BASE_R) - sqrt(dx * dx + dy * dy) - S[k];
-            ls.ct[m] = mmpc_max(-h, 1e-2); ls.cz[m] = mu / ls.ct[m];
+            ls.ct[m] = mmpc_vmax(-h, 1e-2); ls.cz[m] = mu / ls.ct[m];
         }
         if (NSELF) {
             double dr[3], dz[3], sn, cs;
@@ -594,7 +599,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
 #pragma unroll
             for (int i = 0; i < NSELF; i++) {
                 const double h = mmpc_self_row(i, xk[0], xk[1], cs, sn, dr, dz, nullptr) - S[slack_idx(k)];
-                ls.st[i] = mmpc_max(-h, 1e-2); ls.sz[i] = mu / ls.st[i];
+                ls.st[i] = mmpc_vmax(-h, 1e-2); ls.sz[i] = mu / ls.st[i];
             }
         }
     }
@@ -606,6 +611,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
     MMPC_WR(0) = cnt;
     LANES_END
     const double nrows_act = MMPC_RED_SUM(0);
+    const double inv_rows = 1.0 / (nrows_act + (double)(NS * NX));
 
     int status = 1, it = 0, nfilt = 0, filt_init = 0;
     double E0 = 0.0, th_max = 0.0, th_min = 0.0;
@@ -724,7 +730,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                 c[5] = xk[5] + dt * uk[1] - xn1[5];
                 if (KIND == 0) { c[6] = xk[6] + dt * uk[2] - xn1[6]; c[7] = xk[7] + dt * uk[3] - xn1[7]; c[8] = xk[8] + dt * uk[4] - xn1[8]; }
 #pragma unroll
-                for (int j = 0; j < NX; j++) { CD[k * NX + j] = c[j]; e_p = mmpc_max(e_p, fabs(c[j])); th += fabs(c[j]); zsum += fabs(ln[j]); }
+                for (int j = 0; j < NX; j++) { CD[k * NX + j] = c[j]; e_p = mmpc_vmax(e_p, fabs(c[j])); th += fabs(c[j]); zsum += fabs(ln[j]); }
                 // - A^T lam_{k+1}, - B^T lam_{k+1}  (sparse, base.py:19-26)
                 rb[0] -= ln[0]; rb[1] -= ln[1];
                 rb[2] -= ln[2] + a32 * ln[3] + a42 * ln[4];
@@ -748,8 +754,8 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                 const double h = (ob[3 * m + 2] + MMPC_BASE_R) - d - sk;
                 const double t = ls.ct[m], z = ls.cz[m];
                 rb[0] -= nxv * z; rb[1] -= nyv * z; rds -= z;
-                e_p = mmpc_max(e_p, fabs(h + t)); th += fabs(h + t); la.mul(t);
-                tzmax = mmpc_max(tzmax, t * z); tzmin = mmpc_min(tzmin, t * z); zsum += z;
+                e_p = mmpc_vmax(e_p, fabs(h + t)); th += fabs(h + t); la.mul(t);
+                tzmax = mmpc_vmax(tzmax, t * z); tzmin = mmpc_vmin(tzmin, t * z); zsum += z;
             }
             if (NSELF) {
                 double dr[3], dz[3];
@@ -767,8 +773,8 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
 #pragma unroll
                     for (int a = 0; a < 6; a++) rb[mmpc_y(a)] += g6[a] * z;
                     selfz += z;
-                    e_p = mmpc_max(e_p, fabs(h + t)); th += fabs(h + t); la.mul(t);
-                    tzmax = mmpc_max(tzmax, t * z); tzmin = mmpc_min(tzmin, t * z); zsum += z;
+                    e_p = mmpc_vmax(e_p, fabs(h + t)); th += fabs(h + t); la.mul(t);
+                    tzmax = mmpc_vmax(tzmax, t * z); tzmin = mmpc_vmin(tzmin, t * z); zsum += z;
                     if (k == N) {
                         const double it_ = mmpc_rcp(t), w = z * it_;
                         sw += w; sit += it_; swr += w * (h + t);
@@ -824,17 +830,17 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                     const double tl = alo ? mmpc_box_t(val - lo) : 1.0, zl = ls.lo_z[p], th_ = ahi ? mmpc_box_t(hi - val) : 1.0, zh = ls.hi_z[p];
                     const double pl = tl * zl, ph = th_ * zh;
                     r += zh - zl; la.mul(tl); la.mul(th_);
-                    tzmax = mmpc_max(tzmax, mmpc_max(pl, ph));
-                    tzmin = mmpc_min(tzmin, mmpc_min(alo ? pl : 1e300, ahi ? ph : 1e300));
+                    tzmax = mmpc_vmax(tzmax, mmpc_vmax(pl, ph));
+                    tzmin = mmpc_vmin(tzmin, mmpc_vmin(alo ? pl : 1e300, ahi ? ph : 1e300));
                     zsum += zl + zh;
                 }
                 RB[idx] = g;   // keep the plain cost gradient for the assembly / directional derivative
                 const bool isvar = v < NX ? (k >= 1) : (k < N);
-                if (isvar) e_d = mmpc_max(e_d, fabs(r));
+                if (isvar) e_d = mmpc_vmax(e_d, fabs(r));
             }
         }
         MMPC_WR(7) += la.value();   // sum of log t over all rows (the barrier term is applied after the mu update)
-        if (lane < NS) e_d = mmpc_max(e_d, fabs(RDS[lane] - (lane == N - 1 ? SN[3] : 0.0)));
+        if (lane < NS) e_d = mmpc_vmax(e_d, fabs(RDS[lane] - (lane == N - 1 ? SN[3] : 0.0)));
         MMPC_WR(0) = e_d; MMPC_WR(1) = e_p; MMPC_WR(2) = tzmax; MMPC_WR(3) = tzmin; MMPC_WR(4) = zsum; MMPC_WR(5) = phi; MMPC_WR(6) = th;
         LANES_END
         err_d = MMPC_RED_MAX(0); err_p = MMPC_RED_MAX(1); tzmax = MMPC_RED_MAX(2); tzmin = MMPC_RED_MIN(3);
@@ -869,10 +875,11 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
             mmpc_prox_update(alpha, prox, nsmall);
             MMPC_TS(12)
         }
-        double sd = zsum / (nrows_act + (double)(NS * NX));
-        sd = (sd > 100.0 ? sd : 100.0) / 100.0;
-        E0 = mmpc_max(mmpc_max(err_d / sd, err_p), tzmax / sd);
-        if (!(E0 == E0) || !mmpc_finite(E0)) {
+        double sd = zsum * inv_rows;
+        sd = (sd > 100.0 ? sd : 100.0) * 0.01;
+        const double isd = mmpc_rcp(sd);
+        E0 = mmpc_vmax(mmpc_vmax(err_d * isd, err_p), tzmax * isd);
+        if (!(E0 == E0) || !mmpc_finite(E0) || !(th_c + cost_c + zsum == th_c + cost_c + zsum)) {   // (the sums carry every NaN of the point)
 #ifdef MMPC_EMU_DEBUG
             fprintf(stderr, "E0 nan it %d: err_d %g err_p %g tzmax %g tzmin %g zsum %g sumlog %g\n", it, err_d, err_p, tzmax, tzmin, zsum, sumlog);
 #endif
@@ -908,10 +915,10 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
         {
             bool changed = false;
             for (;;) {
-                const double compmu = mmpc_max(fabs(tzmax - mu), fabs(tzmin - mu));
-                const double Emu = mmpc_max(mmpc_max(err_d / sd, err_p), compmu / sd);
+                const double compmu = mmpc_vmax(fabs(tzmax - mu), fabs(tzmin - mu));
+                const double Emu = mmpc_vmax(mmpc_vmax(err_d * isd, err_p), compmu * isd);
                 if (!(Emu <= 10.0 * mu && mu > tol / 10)) break;
-                mu = mmpc_max(tol / 10, mmpc_min(0.2 * mu, mu * sqrt(mu)));
+                mu = mmpc_vmax(tol / 10, mmpc_vmin(0.2 * mu, mu * sqrt(mu)));
                 changed = true;
             }
             if (changed) filt_init = 0;
@@ -1204,7 +1211,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                 // even the Gauss-Newton pass lost a pivot: round-off of the recursion under barrier weights z/t ~ 1e9 and
                 // more.  Same remedy as for crawling iterations - the proximal term, raised until the pass goes through
                 if (prox >= MMPC_PROX_MAX) break;
-                prox = mmpc_min(MMPC_PROX_MAX, mmpc_max(MMPC_PROX0, 4.0 * prox));
+                prox = mmpc_vmin(MMPC_PROX_MAX, mmpc_vmax(MMPC_PROX0, 4.0 * prox));
                 attempt = 1;
             }
             failed = 0;
@@ -1354,7 +1361,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
         LANES_END
         MMPC_TS(10)
         // ---- D2: row steps, fraction-to-boundary, directional derivative
-        const double tau = mmpc_max(0.99, 1.0 - mu);
+        const double tau = mmpc_vmax(0.99, 1.0 - mu);
         LANES_BEGIN
         auto &ls = MMPC_LS;
         // fraction to the boundary without divisions or branches: alpha = min(1, tau / max_i(-dt_i / t_i)) (1/t_i is at hand),
@@ -1376,8 +1383,8 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                 const double jd = -(ddx * dx[0] + ddy * dx[1]) * id - dsk;
                 const double dtv = -(hv + t) - jd, it_ = mmpc_rcp(t), dzv = mu * it_ - z - z * it_ * dtv;
                 ls.cdt[m] = dtv;
-                rp = mmpc_max(rp, -dtv * it_);
-                rd = mmpc_max(rd, -dzv * mmpc_rcp(z));
+                rp = mmpc_vmax(rp, -dtv * it_);
+                rd = mmpc_vmax(rd, -dzv * mmpc_rcp(z));
                 dphi -= mu * dtv * it_;
             }
             double sn = 0.0, cs = 0.0, dr[3] = {0, 0, 0}, dz[3] = {0, 0, 0};
@@ -1397,8 +1404,8 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                 for (int a = 0; a < 6; a++) jd += g6[a] * dx[mmpc_y(a)];
                 const double dtv = -(hv + t) - jd, it_ = mmpc_rcp(t), dzv = mu * it_ - z - z * it_ * dtv;
                 ls.sdt[i] = dtv;
-                rp = mmpc_max(rp, -dtv * it_);
-                rd = mmpc_max(rd, -dzv * mmpc_rcp(z));
+                rp = mmpc_vmax(rp, -dtv * it_);
+                rd = mmpc_vmax(rd, -dzv * mmpc_rcp(z));
                 dphi -= mu * dtv * it_;
             }
             dphi += 2 * Sw * S[k] * dsk;
@@ -1415,24 +1422,24 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                 dphi += RB[idx] * dv;   // RB = plain cost gradient of this variable (kept by the evaluation)
                 if (alo) {
                     const double t = mmpc_box_t(val - lo), z = ls.lo_z[p], dtv = dv, it_ = mmpc_rcp(t), dzv = mu * it_ - z - z * it_ * dtv;
-                    rp = mmpc_max(rp, -dtv * it_);
-                    rd = mmpc_max(rd, -dzv * mmpc_rcp(z));
+                    rp = mmpc_vmax(rp, -dtv * it_);
+                    rd = mmpc_vmax(rd, -dzv * mmpc_rcp(z));
                     dphi -= mu * dtv * it_;
                 }
                 if (ahi) {
                     const double t = mmpc_box_t(hi - val), z = ls.hi_z[p], dtv = -dv, it_ = mmpc_rcp(t), dzv = mu * it_ - z - z * it_ * dtv;
-                    rp = mmpc_max(rp, -dtv * it_);
-                    rd = mmpc_max(rd, -dzv * mmpc_rcp(z));
+                    rp = mmpc_vmax(rp, -dtv * it_);
+                    rd = mmpc_vmax(rd, -dzv * mmpc_rcp(z));
                     dphi -= mu * dtv * it_;
                 }
             }
         }
         MMPC_WR(0) = rp; MMPC_WR(1) = rd; MMPC_WR(2) = dphi;
         LANES_END
-        { const double rp_ = MMPC_RED_MAX(0), rd_ = MMPC_RED_MAX(1); ap = rp_ > tau ? tau / rp_ : 1.0; ad = rd_ > tau ? tau / rd_ : 1.0; dphi = MMPC_RED_SUM(2); }
+        { const double rp_ = MMPC_RED_MAX(0), rd_ = MMPC_RED_MAX(1); ap = rp_ > tau ? tau * mmpc_rcp(rp_) : 1.0; ad = rd_ > tau ? tau * mmpc_rcp(rd_) : 1.0; dphi = MMPC_RED_SUM(2); }
 
         MMPC_TS(11)
-        if (!filt_init) { nfilt = 0; th_max = 1e4 * mmpc_max(1.0, th0); th_min = 1e-4 * mmpc_max(1.0, th0); filt_init = 1; }
+        if (!filt_init) { nfilt = 0; th_max = 1e4 * mmpc_vmax(1.0, th0); th_min = 1e-4 * mmpc_vmax(1.0, th0); filt_init = 1; }
         // ---- first trial of the line search: multipliers with alpha_d, primal variables / slacks with alpha = alpha_p
         alpha = ap; lspass = 0; lsi = 0;
         apply_step(alpha, true);

@@ -1,7 +1,7 @@
 """Per-phase wave-cycle shares of the fast kernel (diagnostic build libmmpc_stamp.so, -DMMPC_STAMP)."""
 import sys, os, ctypes, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
-os.environ["MMPC_LIB"] = os.path.join(ROOT, "mobile-manipulator-mpc_amd", "csrc", "libmmpc_stamp.so")
+os.environ["MMPC_LIB"] = os.environ.get("MMPC_STAMP_LIB", os.path.join(ROOT, "mobile-manipulator-mpc_amd", "csrc", "libmmpc_stamp.so"))
 import torch, mmpc_loader
 from oracle import synth
 mm = mmpc_loader.load()
