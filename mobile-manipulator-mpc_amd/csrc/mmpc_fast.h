@@ -980,23 +980,50 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                         const double hv = mmpc_self_row(i, px, py, cs, sn, dr, dz, g6) - sks;
                         const double t = ls.st[i], z = ls.sz[i], it_ = mmpc_rcp(t), w = z * it_;
                         const double zh = mu * it_ + w * (hv + t);
+                        // (the terminal stage's self rows belong to s_{N-1}, quirk Q1: they do not enter this lane's s_k block)
+                        const double wk = k < N ? w : 0.0, zhk = k < N ? zh : 0.0;
 #pragma unroll
                         for (int a = 0; a < 6; a++) {
                             const double wa = w * g6[a];
 #pragma unroll
                             for (int b = 0; b <= a; b++) hxx[mmpc_y(a) * (mmpc_y(a) + 1) / 2 + mmpc_y(b)] += wa * g6[b];
                             qx[mmpc_y(a)] += g6[a] * zh;
-                            if (k < N) vx[a] += wa;
+                            vx[a] += wk * g6[a];
                         }
-                        if (k < N) { hss += w; gss -= zh; }
+                        hss += wk; gss -= zhk;
                     }
                 }
-                if (k == N - 1 && NSELF) {
-                    // Q1: terminal self rows -> s_{N-1}.  a = v + A^T vN, b = B^T vN, gamma = g_s - vN.c.  This lane publishes
-                    // (a, b, gamma, 1/h_ss); the dense rank-one blocks are applied by all lanes in the next phase
+                // Q1: terminal self rows -> s_{N-1}.  a = v + A^T vN, b = B^T vN, gamma = g_s - vN.c.  Lane N-1 publishes
+                // (a, b, gamma, 1/h_ss); the dense rank-one blocks are applied by all lanes in the next phase, so this lane
+                // stores its blocks WITHOUT the elimination of s (weight 0 below; one store sequence for every lane)
+                const bool q1 = NSELF && k == N - 1;
+                if (q1) {
                     const double hssN = SN[0], gssN = -(mu * SN[1] + SN[2]);
                     hss += hssN; gss += gssN;
-                    const double ih = mmpc_rcp(hss);
+                }
+                const double ih = mmpc_rcp(hss), ihs = q1 ? 0.0 : ih;
+                if (!NSELF && k == N - 1) {
+                    for (int c = 0; c < NU * NX; c++) HUXL[c] = 0.0;
+                    for (int c = 0; c < NUU; c++) HUUL[c] = 0.0;
+                }
+                {
+                    constexpr int ny = NSELF ? 6 : 2;
+#pragma unroll
+                    for (int a = 0; a < ny; a++) {
+#pragma unroll
+                        for (int b = 0; b <= a; b++) hxx[mmpc_y(a) * (mmpc_y(a) + 1) / 2 + mmpc_y(b)] -= vx[a] * vx[b] * ihs;
+                        qx[mmpc_y(a)] += vx[a] * gss * ihs;
+                    }
+                    if (k < N) {
+#pragma unroll
+                        for (int c = 0; c < NU; c++) QXU[k * NV + NX + c] = RB[k * NV + NX + c];
+                    }
+#pragma unroll
+                    for (int e = 0; e < NXX; e++) HXX[k * NXX + e] = hxx[e];
+#pragma unroll
+                    for (int j = 0; j < NX; j++) QXU[k * NV + j] = qx[j];
+                }
+                if (q1) {
                     double vf[NX], a[NX], b[NU];
 #pragma unroll
                     for (int j = 0; j < NX; j++) { vf[j] = 0.0; a[j] = 0.0; }
@@ -1019,33 +1046,6 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
 #pragma unroll
                     for (int c = 0; c < NU; c++) Q1V[NX + c] = b[c];
                     Q1V[NV] = gam * ih; Q1V[NV + 1] = ih;
-#pragma unroll
-                    for (int e = 0; e < NXX; e++) HXX[k * NXX + e] = hxx[e];
-#pragma unroll
-                    for (int j = 0; j < NX; j++) QXU[k * NV + j] = qx[j];
-#pragma unroll
-                    for (int c = 0; c < NU; c++) QXU[k * NV + NX + c] = RB[k * NV + NX + c];
-                } else {
-                    if (k == N - 1) {
-                        for (int c = 0; c < NU * NX; c++) HUXL[c] = 0.0;
-                        for (int c = 0; c < NUU; c++) HUUL[c] = 0.0;
-                    }
-                    const double ih = mmpc_rcp(hss);
-                    constexpr int ny = NSELF ? 6 : 2;
-#pragma unroll
-                    for (int a = 0; a < ny; a++) {
-#pragma unroll
-                        for (int b = 0; b <= a; b++) hxx[mmpc_y(a) * (mmpc_y(a) + 1) / 2 + mmpc_y(b)] -= vx[a] * vx[b] * ih;
-                        qx[mmpc_y(a)] += vx[a] * gss * ih;
-                    }
-                    if (k < N) {
-#pragma unroll
-                        for (int c = 0; c < NU; c++) QXU[k * NV + NX + c] = RB[k * NV + NX + c];
-                    }
-#pragma unroll
-                    for (int e = 0; e < NXX; e++) HXX[k * NXX + e] = hxx[e];
-#pragma unroll
-                    for (int j = 0; j < NX; j++) QXU[k * NV + j] = qx[j];
                 }
                 ls.hss = hss; ls.gss = gss;
 #pragma unroll
