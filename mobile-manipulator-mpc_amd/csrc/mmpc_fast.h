@@ -939,27 +939,39 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
             LANES_BEGIN
             auto &ls = MMPC_LS;
             if (lane < NS) {
-                const int k = lane;
-                double hxx[NXX], qx[NX];
+                const int k = lane, k1 = k < N ? k + 1 : k;
+                // every LDS word of this stage first (one round trip instead of one per block below)
+                double hxx[NXX], qx[NX], wd[NX], ob[(MC > 0 ? MC : 1) * 3];
+#pragma unroll
+                for (int j = 0; j < NX; j++) { wd[j] = CST[(k < N ? MMPC_C_WQ : MMPC_C_WP) + j]; qx[j] = RB[k * NV + j]; }
+                const double *cv = CV + k * MMPC_NCV;
+                const double l3 = LAM[k1 * NX + 3], l4 = LAM[k1 * NX + 4], cv3 = cv[3], cv4 = cv[4], cv9 = cv[9], cv10 = cv[10];
+                const double px = XU[k * NV], py = XU[k * NV + 1], sk = S[k], sks = S[slack_idx(k)];
+#pragma unroll
+                for (int m = 0; m < M; m++) { const double *o = obs_ptr(k, m); ob[3 * m] = o[0]; ob[3 * m + 1] = o[1]; ob[3 * m + 2] = o[2]; }
+                double sn = 0.0, cs = 0.0, dr[3] = {0, 0, 0}, dz[3] = {0, 0, 0};
+                if (NSELF) {
+                    sn = TRG[k * 8]; cs = TRG[k * 8 + 1];
+#pragma unroll
+                    for (int a = 0; a < 3; a++) { dr[a] = TRG[k * 8 + 2 + a]; dz[a] = TRG[k * 8 + 5 + a]; }
+                }
+                mmpc_sched_fence();
 #pragma unroll
                 for (int e = 0; e < NXX; e++) hxx[e] = 0.0;
 #pragma unroll
-                for (int j = 0; j < NX; j++) { hxx[j * (j + 1) / 2 + j] = CST[(k < N ? MMPC_C_WQ : MMPC_C_WP) + j] + reg; qx[j] = RB[k * NV + j]; }
+                for (int j = 0; j < NX; j++) hxx[j * (j + 1) / 2 + j] = wd[j] + reg;
                 double h02 = 0.0;
                 if (k < N && dyn_curv) {
-                    const double *cv = CV + k * MMPC_NCV;
-                    const double l3 = LAM[(k + 1) * NX + 3], l4 = LAM[(k + 1) * NX + 4];
-                    hxx[5] += l3 * cv[4] - l4 * cv[3];
+                    hxx[5] += l3 * cv4 - l4 * cv3;
                     hxx[19] += dt * l3;
                     hxx[18] -= dt * l4;
-                    h02 = -(-l3 * cv[10] + l4 * cv[9]);
+                    h02 = -(-l3 * cv10 + l4 * cv9);
                 }
-                double hss = 2 * Sw, gss = 2 * Sw * S[k], vx[6] = {0, 0, 0, 0, 0, 0};
-                const double px = XU[k * NV], py = XU[k * NV + 1], sk = S[k];
+                double hss = 2 * Sw, gss = 2 * Sw * sk, vx[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
                 for (int m = 0; m < M; m++) {
                     // row geometry is re-derived from x_k (cheaper than keeping it in registers)
-                    const double *o = obs_ptr(k, m);
+                    const double *o = ob + 3 * m;
                     const double ddx = px - o[0], ddy = py - o[1], m2 = ddx * ddx + ddy * ddy, id = mmpc_rsqrt(m2), d = m2 * id;
                     const double g0 = -ddx * id, g1 = -ddy * id, hv = (o[2] + MMPC_BASE_R) - d - sk;
                     const double t = ls.ct[m], z = ls.cz[m], it_ = mmpc_rcp(t), w = z * it_;
@@ -970,10 +982,6 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                     hss += w; gss -= zh; vx[0] += w * g0; vx[1] += w * g1;
                 }
                 if (NSELF) {
-                    const double sn = TRG[k * 8], cs = TRG[k * 8 + 1], sks = S[slack_idx(k)];
-                    double dr[3], dz[3];
-#pragma unroll
-                    for (int a = 0; a < 3; a++) { dr[a] = TRG[k * 8 + 2 + a]; dz[a] = TRG[k * 8 + 5 + a]; }
 #pragma unroll
                     for (int i = 0; i < NSELF; i++) {
                         double g6[6];
