@@ -167,6 +167,9 @@ MMPC_HD constexpr int mmpc_y(int a) { return a < 3 ? a : a + 3; }
 // distance of that size can round to zero: floor it at a couple of ulps.
 MMPC_DEV double mmpc_box_t(double d) { return mmpc_vmax(d, 1e-15); }
 
+#ifndef MMPC_SLIM_NMIN
+#define MMPC_SLIM_NMIN 21  // horizons from here on: "slim" LDS layout (see mmpc_fast_layout) and circle rows spread over lanes
+#endif
 template <int KIND, int N>
 struct MmpcFastDims {
     typedef MmpcDims<KIND> D;
@@ -179,6 +182,12 @@ struct MmpcFastDims {
     // the input rows, accumulator registers that hold the input rows NX+1..NV of the stage matrix
     static constexpr int NKB = (NX + 1 + 3) / 4;
     static constexpr int NPU = NU * (NU - 1) / 2;   // couplings between the inputs of a stage kept for the gain back-substitution
+    // Long horizons spread the circle rows of a stage over RG lanes (lane s NS + k owns the rows m = s + RG r of stage k): their
+    // instantiation carries 8 rows per stage and is short of registers, not of lanes.  (At most 3: the partial sums of the other
+    // lanes travel through the first words of the stage's own - at that point dead - Hessian block.)  Short horizons keep the rows
+    // in the stage lane, where their arithmetic fills the latency of the trigonometry around it (measured: -0.9 % at N = 20
+    // when split, +11 % at N = 30).
+    static constexpr int RG = (N >= MMPC_SLIM_NMIN && 2 * NS <= MMPC_WAVE) ? (MMPC_WAVE / NS < 3 ? MMPC_WAVE / NS : 3) : 1;
     static_assert(NV + 1 <= 16, "stage matrix over (x, 1, u) must fit one 16x16 tile");
 };
 
@@ -231,9 +240,6 @@ struct MmpcFastLayout {
 // Long horizons (N >= MMPC_SLIM_NMIN) leave the read-only inputs that are touched once or twice per iteration - the
 // reference trajectory, the previous inputs and the per-stage obstacle table - in HBM/L2 instead of LDS: at N = 30, M = 8 that is 63.2 -> 52.6 KB
 // per problem, i.e. three resident problems per CU instead of two.
-#ifndef MMPC_SLIM_NMIN
-#define MMPC_SLIM_NMIN 21
-#endif
 template <int KIND, int N>
 MMPC_HD MmpcFastLayout mmpc_fast_layout(int M, int obs_per_stage) {
     typedef MmpcFastDims<KIND, N> F;
@@ -277,8 +283,10 @@ struct MmpcLaneState {
     double lo_z[F::NPASS], hi_z[F::NPASS];
     // the bounds themselves (constant during a solve: the merged input box uses U_last); -+1e300 marks an absent side
     double b_lo[F::NPASS], b_hi[F::NPASS];
-    // circle rows of stage `lane`
-    double ct[MC > 0 ? MC : 1], cz[MC > 0 ? MC : 1], cdt[MC > 0 ? MC : 1];
+    // circle rows m = s + RG r of stage k, lane = s NS + k  (RG = 1: the rows of stage `lane`)
+    static constexpr int MCR = MC > 0 ? (MC + F::RG - 1) / F::RG : 1;   // circle rows per lane
+    double ct[MCR], cz[MCR], cdt[MCR];
+    double cp[F::RG > 1 ? 9 : 1];                    // RG > 1: partial sums of this lane's circle rows, from a row phase to the stage phase after it
     // self-collision rows of stage `lane`
     double st[4], sz[4], sdt[4];
     // s_k elimination data of stage `lane`
@@ -371,6 +379,9 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
     constexpr int NX = F::NX, NU = F::NU, NV = F::NV, NXX = F::NXX, NUU = F::NUU, NSELF = F::NSELF, NS = F::NS;
     constexpr int NPASS = F::NPASS, NPAIR = F::NPAIR, NKB = F::NKB, NPU = F::NPU;
     constexpr int M = MC;   // number of circle obstacles is a template parameter on this path
+    constexpr int RG = F::RG, MCR = MmpcLaneState<KIND, N, MC>::MCR;   // circle rows: RG lanes per stage, MCR rows per lane
+// lane -> (row group rs, stage rk) of the circle rows; row slot r of the lane is obstacle rs + RG r
+#define MMPC_ROW_LANE const int rs = RG > 1 ? lane / NS : 0, rk = lane - rs * NS; const bool rlane = M > 0 && lane < RG * NS;
     // stages per trip of the Riccati / forward loops: unrolling saves the per-stage pointer bumps and register shuffles,
     // but costs registers - it only pays where the kernel does not spill (measured per instantiation)
 #ifdef MMPC_UNROLL_BASE
@@ -579,19 +590,28 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
         }
     }
 #pragma unroll
-    for (int m = 0; m < M; m++) { ls.ct[m] = 1.0; ls.cz[m] = 0.0; }
+    for (int r = 0; r < MCR; r++) { ls.ct[r] = 1.0; ls.cz[r] = 0.0; ls.cdt[r] = 0.0; }
+    {
+        MMPC_ROW_LANE
+        if (rlane) {
+            const double px = XU[rk * NV], py = XU[rk * NV + 1], sk = S[rk];
+#pragma unroll
+            for (int r = 0; r < MCR; r++) {
+                const int m = rs + RG * r;
+                if (m < M) {
+                    const double *o = obs_ptr(rk, m);
+                    const double dx = px - o[0], dy = py - o[1];
+                    const double h = (o[2] + MMPC_BASE_R) - sqrt(dx * dx + dy * dy) - sk;
+                    ls.ct[r] = mmpc_vmax(-h, 1e-2); ls.cz[r] = mu / ls.ct[r];
+                }
+            }
+        }
+    }
 #pragma unroll
     for (int i = 0; i < 4; i++) { ls.st[i] = 1.0; ls.sz[i] = 0.0; }
     if (lane < NS) {
         const int k = lane;
         const double *xk = XU + k * NV;
-#pragma unroll
-        for (int m = 0; m < M; m++) {
-            const double *o = obs_ptr(k, m);
-            const double dx = xk[0] - o[0], dy = xk[1] - o[1];
-            const double h = (o[2] + MMPC_BASE_R) - sqrt(dx * dx + dy * dy) - S[k];
-            ls.ct[m] = mmpc_vmax(-h, 1e-2); ls.cz[m] = mu / ls.ct[m];
-        }
         if (NSELF) {
             double dr[3], dz[3], sn, cs;
             mmpc_sincos(xk[2], &sn, &cs);
@@ -636,7 +656,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
 #pragma unroll
         for (int p = 0; p < NPASS; p++) { ls.lo_z[p] = q[p]; ls.hi_z[p] = q[NPASS + p]; }
 #pragma unroll
-        for (int m = 0; m < MCS; m++) { ls.ct[m] = q[2 * NPASS + m]; ls.cz[m] = q[2 * NPASS + MCS + m]; }
+        for (int m = 0; m < MCR; m++) { ls.ct[m] = q[2 * NPASS + m]; ls.cz[m] = q[2 * NPASS + MCS + m]; }
 #pragma unroll
         for (int i = 0; i < 4; i++) { ls.st[i] = q[2 * NPASS + 2 * MCS + i]; ls.sz[i] = q[2 * NPASS + 2 * MCS + 4 + i]; }
         LANES_END
@@ -658,13 +678,20 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
     auto apply_step = [&](double d_alpha, bool first) {
         LANES_BEGIN
         auto &ls = MMPC_LS;
-        if (lane < NS) {
+        {
+            MMPC_ROW_LANE
+            if (rlane) {
 #pragma unroll
-            for (int m = 0; m < M; m++) {
-                const double t = ls.ct[m], z = ls.cz[m], dtv = ls.cdt[m], tn = t + d_alpha * dtv;
-                if (first) { const double it_ = mmpc_rcp(t); ls.cz[m] = mmpc_z_safeguard_fast(z + ad * (mu * it_ - z - z * it_ * dtv), tn, mu); }
-                ls.ct[m] = tn;
+                for (int r = 0; r < MCR; r++) {
+                    if (RG == 1 || rs + RG * r < M) {
+                        const double t = ls.ct[r], z = ls.cz[r], dtv = ls.cdt[r], tn = t + d_alpha * dtv;
+                        if (first) { const double it_ = mmpc_rcp(t); ls.cz[r] = mmpc_z_safeguard_fast(z + ad * (mu * it_ - z - z * it_ * dtv), tn, mu); }
+                        ls.ct[r] = tn;
+                    }
+                }
             }
+        }
+        if (lane < NS) {
 #pragma unroll
             for (int i = 0; i < NSELF; i++) {
                 const double t = ls.st[i], z = ls.sz[i], dtv = ls.sdt[i], tn = t + d_alpha * dtv;
@@ -698,20 +725,64 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
 #pragma unroll 1
     for (;;) {
         MMPC_TS(0)
+        // ============================================================ E1 (circle rows where RG lanes share a stage)
+        if (RG > 1 && M > 0) {
+            LANES_BEGIN
+            auto &ls = MMPC_LS;
+            double e_p = 0.0, tzmax = 0.0, tzmin = 1e300, zsum = 0.0, th = 0.0, rb0 = 0.0, rb1 = 0.0, rz = 0.0;
+            MmpcLogAcc la; la.init();
+            MMPC_ROW_LANE
+            if (rlane) {
+                const double px = XU[rk * NV], py = XU[rk * NV + 1], sk = S[rk];
+                double ob[MCR * 3];
+#pragma unroll
+                for (int r = 0; r < MCR; r++) {
+                    const double *o = obs_ptr(rk, rs + RG * r < M ? rs + RG * r : 0);
+                    ob[3 * r] = o[0]; ob[3 * r + 1] = o[1]; ob[3 * r + 2] = o[2];
+                }
+#pragma unroll
+                for (int r = 0; r < MCR; r++) {
+                    if (rs + RG * r < M) {
+                        const double dx = px - ob[3 * r], dy = py - ob[3 * r + 1], m2 = dx * dx + dy * dy, id = mmpc_rsqrt(m2), d = m2 * id;
+                        const double nxv = dx * id, nyv = dy * id;
+                        const double h = (ob[3 * r + 2] + MMPC_BASE_R) - d - sk;
+                        const double t = ls.ct[r], z = ls.cz[r];
+                        rb0 -= nxv * z; rb1 -= nyv * z; rz += z;
+                        e_p = mmpc_vmax(e_p, fabs(h + t)); th += fabs(h + t); la.mul(t);
+                        tzmax = mmpc_vmax(tzmax, t * z); tzmin = mmpc_vmin(tzmin, t * z); zsum += z;
+                    }
+                }
+                // the stage lane (rs = 0) keeps its sums in registers, the others hand theirs over through the stage's Hessian block
+                if (rs > 0) { double *cpo = HXX + rk * NXX + (rs - 1) * 3; cpo[0] = rb0; cpo[1] = rb1; cpo[2] = rz; }
+            }
+            ls.cp[0] = rb0; ls.cp[1] = rb1; ls.cp[2] = rz;
+            MMPC_WR(1) = e_p; MMPC_WR(2) = tzmax; MMPC_WR(3) = tzmin; MMPC_WR(4) = zsum; MMPC_WR(6) = th; MMPC_WR(7) = la.mant; MMPC_WR(0) = (double)la.ex;
+            LANES_END
+        }
         // ============================================================ E1 (stage lanes)
         LANES_BEGIN
         auto &ls = MMPC_LS;
         double e_p = 0.0, tzmax = 0.0, tzmin = 1e300, zsum = 0.0, phi = 0.0, th = 0.0, slog = 0.0;
+        MmpcLogAcc la; la.init();
+        if (RG > 1 && M > 0) {
+            e_p = MMPC_WR(1); tzmax = MMPC_WR(2); tzmin = MMPC_WR(3); zsum = MMPC_WR(4); th = MMPC_WR(6); la.mant = MMPC_WR(7); la.ex = (int)MMPC_WR(0);
+        }
         if (lane < NS) {
             const int k = lane, k1 = k < N ? k + 1 : k;
             // every LDS word of this stage first (the stores below would otherwise pin each later load behind them)
-            double xk[NV], xn1[NX], ln[NX], rb[NV], ob[(MC > 0 ? MC : 1) * 3];
+            // (ob: the obstacles of this stage where the stage lane owns all circle rows, else the sums of the other lanes' rows)
+            double xk[NV], xn1[NX], ln[NX], rb[NV], ob[RG > 1 ? (RG - 1) * 3 : (MC > 0 ? MC : 1) * 3];
 #pragma unroll
             for (int j = 0; j < NV; j++) { xk[j] = XU[k * NV + j]; rb[j] = 0.0; }
 #pragma unroll
             for (int j = 0; j < NX; j++) { xn1[j] = XU[k1 * NV + j]; ln[j] = LAM[k1 * NX + j]; rb[j] = k >= 1 ? LAM[k * NX + j] : 0.0; }
+            if (RG > 1) {
 #pragma unroll
-            for (int m = 0; m < M; m++) { const double *o = obs_ptr(k, m); ob[3 * m] = o[0]; ob[3 * m + 1] = o[1]; ob[3 * m + 2] = o[2]; }
+                for (int q = 0; q < (RG - 1) * 3; q++) ob[q] = M > 0 ? HXX[k * NXX + q] : 0.0;
+            } else {
+#pragma unroll
+                for (int m = 0; m < M; m++) { const double *o = obs_ptr(k, m); ob[3 * m] = o[0]; ob[3 * m + 1] = o[1]; ob[3 * m + 2] = o[2]; }
+            }
             const double sk = S[k], sks_ld = S[slack_idx(k)];
             mmpc_sched_fence();
             double sn, cs;
@@ -746,9 +817,14 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
             }
             double rds = 2 * Sw * sk, selfz = 0.0;
             phi += Sw * sk * sk;
-            MmpcLogAcc la; la.init();
+            if (RG > 1 && M > 0) {   // circle rows of this stage: own rows first, then the other lanes' sums in lane order
+                double c0 = ls.cp[0], c1 = ls.cp[1], c2 = ls.cp[2];
 #pragma unroll
-            for (int m = 0; m < M; m++) {
+                for (int g = 0; g < RG - 1; g++) { c0 += ob[3 * g]; c1 += ob[3 * g + 1]; c2 += ob[3 * g + 2]; }
+                rb[0] += c0; rb[1] += c1; rds -= c2;
+            }
+#pragma unroll
+            for (int m = 0; m < (RG > 1 ? 0 : M); m++) {
                 const double dx = xk[0] - ob[3 * m], dy = xk[1] - ob[3 * m + 1], m2 = dx * dx + dy * dy, id = mmpc_rsqrt(m2), d = m2 * id;
                 const double nxv = dx * id, nyv = dy * id;
                 const double h = (ob[3 * m + 2] + MMPC_BASE_R) - d - sk;
@@ -789,11 +865,11 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                 }
             }
             if (k < N) rds -= selfz;
-            slog = la.value();
             RDS[k] = rds;
 #pragma unroll
             for (int j = 0; j < NV; j++) RB[k * NV + j] = rb[j];
         }
+        if (RG > 1 || lane < NS) slog = la.value();
         MMPC_WR(1) = e_p; MMPC_WR(2) = tzmax; MMPC_WR(3) = tzmin; MMPC_WR(4) = zsum; MMPC_WR(5) = phi; MMPC_WR(6) = th; MMPC_WR(7) = slog;
         if (NSELF == 0 && lane == 0) { for (int a = 0; a < 10; a++) SN[a] = 0.0; }
         LANES_END
@@ -901,7 +977,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
 #pragma unroll
             for (int p = 0; p < NPASS; p++) { q[p] = ls.lo_z[p]; q[NPASS + p] = ls.hi_z[p]; }
 #pragma unroll
-            for (int m = 0; m < MCS; m++) { q[2 * NPASS + m] = ls.ct[m]; q[2 * NPASS + MCS + m] = ls.cz[m]; }
+            for (int m = 0; m < MCR; m++) { q[2 * NPASS + m] = ls.ct[m]; q[2 * NPASS + MCS + m] = ls.cz[m]; }
 #pragma unroll
             for (int i = 0; i < 4; i++) { q[2 * NPASS + 2 * MCS + i] = ls.st[i]; q[2 * NPASS + 2 * MCS + 4 + i] = ls.sz[i]; }
             if (lane == 0) {
@@ -935,20 +1011,63 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
             const bool exact = attempt <= 1, dyn_curv = attempt == 0;
             const double reg = prox;
             int ric_bad = 0;   // a pivot of this pass was not positive (every lane factorises the same matrix: uniform)
+            // ---- A1 (circle rows where RG lanes share a stage): w g g^T (+ exact curvature), gradient and s_k coupling of the
+            //      lane's rows: cp = (Hxx, Hxy, Hyy, qx, qy, h_ss, g_ss, vx, vy)
+            if (RG > 1 && M > 0) {
+                LANES_BEGIN
+                auto &ls = MMPC_LS;
+                MMPC_ROW_LANE
+                double cp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+                if (rlane) {
+                    const double px = XU[rk * NV], py = XU[rk * NV + 1], sk = S[rk];
+                    double ob[MCR * 3];
+#pragma unroll
+                    for (int r = 0; r < MCR; r++) {
+                        const double *o = obs_ptr(rk, rs + RG * r < M ? rs + RG * r : 0);
+                        ob[3 * r] = o[0]; ob[3 * r + 1] = o[1]; ob[3 * r + 2] = o[2];
+                    }
+#pragma unroll
+                    for (int r = 0; r < MCR; r++) {
+                        if (rs + RG * r < M) {
+                            const double ddx = px - ob[3 * r], ddy = py - ob[3 * r + 1], m2 = ddx * ddx + ddy * ddy, id = mmpc_rsqrt(m2), d = m2 * id;
+                            const double g0 = -ddx * id, g1 = -ddy * id, hv = (ob[3 * r + 2] + MMPC_BASE_R) - d - sk;
+                            const double t = ls.ct[r], z = ls.cz[r], it_ = mmpc_rcp(t), w = z * it_;
+                            const double zh = mu * it_ + w * (hv + t);
+                            cp[0] += w * g0 * g0; cp[1] += w * g1 * g0; cp[2] += w * g1 * g1;
+                            if (exact) { const double zi = z * id; cp[0] -= zi * (1 - g0 * g0); cp[1] += zi * g0 * g1; cp[2] -= zi * (1 - g1 * g1); }
+                            cp[3] += g0 * zh; cp[4] += g1 * zh;
+                            cp[5] += w; cp[6] -= zh; cp[7] += w * g0; cp[8] += w * g1;
+                        }
+                    }
+                    if (rs > 0) {
+                        double *cpo = HXX + rk * NXX + (rs - 1) * 9;
+#pragma unroll
+                        for (int q = 0; q < 9; q++) cpo[q] = cp[q];
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 9; q++) ls.cp[q] = cp[q];
+                LANES_END
+            }
             // ---- A1 (stage lanes): stage Hessian incl. elimination of s_k
             LANES_BEGIN
             auto &ls = MMPC_LS;
             if (lane < NS) {
                 const int k = lane, k1 = k < N ? k + 1 : k;
                 // every LDS word of this stage first (one round trip instead of one per block below)
-                double hxx[NXX], qx[NX], wd[NX], ob[(MC > 0 ? MC : 1) * 3];
+                double hxx[NXX], qx[NX], wd[NX], ob[RG > 1 ? (RG - 1) * 9 : (MC > 0 ? MC : 1) * 3];   // (ob: as in the evaluation)
 #pragma unroll
                 for (int j = 0; j < NX; j++) { wd[j] = CST[(k < N ? MMPC_C_WQ : MMPC_C_WP) + j]; qx[j] = RB[k * NV + j]; }
                 const double *cv = CV + k * MMPC_NCV;
                 const double l3 = LAM[k1 * NX + 3], l4 = LAM[k1 * NX + 4], cv3 = cv[3], cv4 = cv[4], cv9 = cv[9], cv10 = cv[10];
                 const double px = XU[k * NV], py = XU[k * NV + 1], sk = S[k], sks = S[slack_idx(k)];
+                if (RG > 1) {
 #pragma unroll
-                for (int m = 0; m < M; m++) { const double *o = obs_ptr(k, m); ob[3 * m] = o[0]; ob[3 * m + 1] = o[1]; ob[3 * m + 2] = o[2]; }
+                    for (int q = 0; q < (RG - 1) * 9; q++) ob[q] = M > 0 ? HXX[k * NXX + q] : 0.0;
+                } else {
+#pragma unroll
+                    for (int m = 0; m < M; m++) { const double *o = obs_ptr(k, m); ob[3 * m] = o[0]; ob[3 * m + 1] = o[1]; ob[3 * m + 2] = o[2]; }
+                }
                 double sn = 0.0, cs = 0.0, dr[3] = {0, 0, 0}, dz[3] = {0, 0, 0};
                 if (NSELF) {
                     sn = TRG[k * 8]; cs = TRG[k * 8 + 1];
@@ -968,8 +1087,17 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                     h02 = -(-l3 * cv10 + l4 * cv9);
                 }
                 double hss = 2 * Sw, gss = 2 * Sw * sk, vx[6] = {0, 0, 0, 0, 0, 0};
+                if (RG > 1 && M > 0) {   // circle rows: own lane's sums first, then the other lanes' in lane order
 #pragma unroll
-                for (int m = 0; m < M; m++) {
+                    for (int q = 0; q < 9; q++) {
+                        double c = ls.cp[q];
+#pragma unroll
+                        for (int g = 0; g < RG - 1; g++) c += ob[9 * g + q];
+                        if (q < 3) hxx[q] += c; else if (q < 5) qx[q - 3] += c; else if (q == 5) hss += c; else if (q == 6) gss += c; else vx[q - 7] += c;
+                    }
+                }
+#pragma unroll
+                for (int m = 0; m < (RG > 1 ? 0 : M); m++) {
                     // row geometry is re-derived from x_k (cheaper than keeping it in registers)
                     const double *o = ob + 3 * m;
                     const double ddx = px - o[0], ddy = py - o[1], m2 = ddx * ddx + ddy * ddy, id = mmpc_rsqrt(m2), d = m2 * id;
@@ -1375,6 +1503,33 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
         // fraction to the boundary without divisions or branches: alpha = min(1, tau / max_i(-dt_i / t_i)) (1/t_i is at hand),
         // likewise for the multipliers with 1/z_i
         double rp = 0.0, rd = 0.0, dphi = 0.0;
+        if (RG > 1 && M > 0) {   // circle rows where RG lanes share a stage
+            MMPC_ROW_LANE
+            if (rlane) {
+                const double dx0 = DXU[rk * NV], dx1 = DXU[rk * NV + 1], dsk = DS[rk];
+                const double px = XU[rk * NV], py = XU[rk * NV + 1], sk = S[rk];
+                double ob[MCR * 3];
+#pragma unroll
+                for (int r = 0; r < MCR; r++) {
+                    const double *o = obs_ptr(rk, rs + RG * r < M ? rs + RG * r : 0);
+                    ob[3 * r] = o[0]; ob[3 * r + 1] = o[1]; ob[3 * r + 2] = o[2];
+                }
+#pragma unroll
+                for (int r = 0; r < MCR; r++) {
+                    if (rs + RG * r < M) {
+                        const double ddx = px - ob[3 * r], ddy = py - ob[3 * r + 1], m2 = ddx * ddx + ddy * ddy, id = mmpc_rsqrt(m2), d = m2 * id;
+                        const double hv = (ob[3 * r + 2] + MMPC_BASE_R) - d - sk;
+                        const double t = ls.ct[r], z = ls.cz[r];
+                        const double jd = -(ddx * dx0 + ddy * dx1) * id - dsk;
+                        const double dtv = -(hv + t) - jd, it_ = mmpc_rcp(t), dzv = mu * it_ - z - z * it_ * dtv;
+                        ls.cdt[r] = dtv;
+                        rp = mmpc_vmax(rp, -dtv * it_);
+                        rd = mmpc_vmax(rd, -dzv * mmpc_rcp(z));
+                        dphi -= mu * dtv * it_;
+                    }
+                }
+            }
+        }
         if (lane < NS) {
             const int k = lane;
             const double *dx = DXU + k * NV;
@@ -1382,9 +1537,9 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
             const double px = XU[k * NV], py = XU[k * NV + 1], sk = S[k];
             double ob[(MC > 0 ? MC : 1) * 3];
 #pragma unroll
-            for (int m = 0; m < M; m++) { const double *o = obs_ptr(k, m); ob[3 * m] = o[0]; ob[3 * m + 1] = o[1]; ob[3 * m + 2] = o[2]; }
+            for (int m = 0; m < (RG > 1 ? 0 : M); m++) { const double *o = obs_ptr(k, m); ob[3 * m] = o[0]; ob[3 * m + 1] = o[1]; ob[3 * m + 2] = o[2]; }
 #pragma unroll
-            for (int m = 0; m < M; m++) {
+            for (int m = 0; m < (RG > 1 ? 0 : M); m++) {
                 const double ddx = px - ob[3 * m], ddy = py - ob[3 * m + 1], m2 = ddx * ddx + ddy * ddy, id = mmpc_rsqrt(m2), d = m2 * id;
                 const double hv = (ob[3 * m + 2] + MMPC_BASE_R) - d - sk;
                 const double t = ls.ct[m], z = ls.cz[m];
