@@ -182,12 +182,13 @@ struct MmpcFastDims {
     // the input rows, accumulator registers that hold the input rows NX+1..NV of the stage matrix
     static constexpr int NKB = (NX + 1 + 3) / 4;
     static constexpr int NPU = NU * (NU - 1) / 2;   // couplings between the inputs of a stage kept for the gain back-substitution
-    // Long horizons spread the circle rows of a stage over RG lanes (lane s NS + k owns the rows m = s + RG r of stage k): their
-    // instantiation carries 8 rows per stage and is short of registers, not of lanes.  (At most 3: the partial sums of the other
+    // Long horizons and the base kind spread the circle rows of a stage over RG lanes (lane s NS + k owns the rows m = s + RG r
+    // of stage k): those instantiations are short of registers (8 rows per stage; the 256-register cap of two waves per SIMD),
+    // not of lanes.  (At most 3: the partial sums of the other
     // lanes travel through the first words of the stage's own - at that point dead - Hessian block.)  Short horizons keep the rows
     // in the stage lane, where their arithmetic fills the latency of the trigonometry around it (measured: -0.9 % at N = 20
-    // when split, +11 % at N = 30).
-    static constexpr int RG = (N >= MMPC_SLIM_NMIN && 2 * NS <= MMPC_WAVE) ? (MMPC_WAVE / NS < 3 ? MMPC_WAVE / NS : 3) : 1;
+    // when split, +11 % at N = 30, +2.6 % for the base kind).
+    static constexpr int RG = ((N >= MMPC_SLIM_NMIN || KIND == 1) && 2 * NS <= MMPC_WAVE) ? (MMPC_WAVE / NS < 3 ? MMPC_WAVE / NS : 3) : 1;
     static_assert(NV + 1 <= 16, "stage matrix over (x, 1, u) must fit one 16x16 tile");
 };
 
