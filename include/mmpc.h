@@ -37,7 +37,9 @@ extern "C" {
 /* per-instance solver status written to status[B] */
 #define MMPC_STATUS_CONVERGED 0 /* scaled KKT error <= tol */
 #define MMPC_STATUS_MAXITER 1
-#define MMPC_STATUS_NUMERIC 2   /* NaN / non-PD even with the Gauss-Newton Hessian */
+#define MMPC_STATUS_NUMERIC 2   /* NaN / non-PD even with the Gauss-Newton Hessian; also: NaN or inf in the instance's data (x_init,
+                                   references, obstacles, u_last) - detected at the first evaluation, the other instances of the
+                                   batch are not affected (opti.solve() raises for such an instance, mpc_wholebody_qref.py:315) */
 #define MMPC_STATUS_SUSPENDED 3 /* iteration budget of the launch used up (mmpc_set_iteration_budget): X, U, s hold the current
                                    iterate, mmpc_resume_batch_device continues the solve */
 

@@ -223,6 +223,9 @@ MMPC_DEV double mmpc_bound_push(double v, double lo, double hi) {
     return v < lo2 ? lo2 : (v > hi2 ? hi2 : v);
 }
 MMPC_DEV double mmpc_max(double a, double b) { return a > b ? a : b; }
+// the same for running error maxima: a NaN on EITHER side stays (mmpc_max hands only a NaN in b through), so that a
+// non-finite residual anywhere reaches the status 2 test of the main loop
+MMPC_DEV double mmpc_max_err(double a, double b) { return (a > b || a != a) ? a : b; }
 MMPC_DEV double mmpc_z_safeguard(double z, double t, double mu) {
     const double p = z * t;
     if (p > MMPC_KAPPA_SIGMA * mu) return MMPC_KAPPA_SIGMA * mu / t;
@@ -528,7 +531,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
     for (int i = lane; i < NS * NX; i += MMPC_WAVE) {
         const int j = i % NX;
         double x0 = io.x_init[j];
-        if (KIND != 1) x0 = mmpc_max(mmpc_min(x0, WTS[MMPC_W_XLIM + 9 + j]), WTS[MMPC_W_XLIM + j]);  // :290-291
+        if (KIND != 1) { const double lo = WTS[MMPC_W_XLIM + j], hi = WTS[MMPC_W_XLIM + 9 + j]; x0 = x0 > hi ? hi : (x0 < lo ? lo : x0); }  // :290-291 (a NaN stays a NaN)
         if (i < NS * NREF) XREF[i] = io.traj_ref[i];
         X[i] = (io.x_guess && i >= NX) ? io.x_guess[i] : x0;  // :302 / mpc_base.py:200
         LAM[i] = 0.0;
@@ -652,7 +655,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                 for (int j = 0; j < NX; j++) {
                     const double c = xn[j] - X[(k + 1) * NX + j];
                     CD[k * NX + j] = c;
-                    e_p = mmpc_max(e_p, fabs(c));
+                    e_p = mmpc_max_err(e_p, fabs(c));
                     zsum += fabs(LAM[(k + 1) * NX + j]);
                 }
                 for (int a = 0; a < NU; a++) {
@@ -680,7 +683,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                 else if (r < SL_XLO) { h = U[k * NU + r - NU] - b; rdu[r - NU] += z; }
                 else if (r < SL_XHI) { h = b - xk[r - SL_XLO]; rdx[r - SL_XLO] -= z; }
                 else { h = xk[r - SL_XHI] - b; rdx[r - SL_XHI] += z; }
-                e_p = mmpc_max(e_p, fabs(h + t));
+                e_p = mmpc_max_err(e_p, fabs(h + t));
                 tzmax = mmpc_max(tzmax, t * z); tzmin = mmpc_min(tzmin, t * z); zsum += z;
             }
             // circle rows: value, gradient, Hessian (mpc_wholebody_qref.py:49-54)
@@ -696,7 +699,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                 HC[(k * M + m) * 3 + 2] = -(1 - nyv * nyv) * id;
                 const double t = T[k * R + SL_C + m], z = Z[k * R + SL_C + m];
                 rdx[0] -= nxv * z; rdx[1] -= nyv * z; rds -= z;
-                e_p = mmpc_max(e_p, fabs(h + t));
+                e_p = mmpc_max_err(e_p, fabs(h + t));
                 tzmax = mmpc_max(tzmax, t * z); tzmin = mmpc_min(tzmin, t * z); zsum += z;
             }
             if (NSELF) {
@@ -710,7 +713,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                     const double t = T[k * R + SL_S + i], z = Z[k * R + SL_S + i];
                     for (int a = 0; a < 6; a++) { GSF[(k * NSELF + i) * 6 + a] = g6[a]; rdx[kY[a]] += g6[a] * z; }
                     selfz += z;
-                    e_p = mmpc_max(e_p, fabs(h + t));
+                    e_p = mmpc_max_err(e_p, fabs(h + t));
                     tzmax = mmpc_max(tzmax, t * z); tzmin = mmpc_min(tzmin, t * z); zsum += z;
                 }
                 for (int i = 0; i < NHS; i++) {   // half-space rows, bound to s_k (s_N at the end, :268)
@@ -720,7 +723,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                     const double t = T[k * R + SL_H + i], z = Z[k * R + SL_H + i];
                     for (int a = 0; a < 6; a++) { GHS[(k * 6 + i) * 6 + a] = g6[a]; rdx[kY[a]] += g6[a] * z; }
                     rds -= z;
-                    e_p = mmpc_max(e_p, fabs(h + t));
+                    e_p = mmpc_max_err(e_p, fabs(h + t));
                     tzmax = mmpc_max(tzmax, t * z); tzmin = mmpc_min(tzmin, t * z); zsum += z;
                 }
                 if (NQ) {   // rows of the NLP as written (quirk Q8): planes 0..j at x_k, planes j+1.. at x_{k-1}
@@ -742,7 +745,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                                 if (br) rq[a] += g6[a] * z; else rdx[kY[a]] += g6[a] * z;
                             }
                             rds -= z;
-                            e_p = mmpc_max(e_p, fabs(h + t));
+                            e_p = mmpc_max_err(e_p, fabs(h + t));
                             tzmax = mmpc_max(tzmax, t * z); tzmin = mmpc_min(tzmin, t * z); zsum += z;
                         }
                     }
@@ -755,13 +758,13 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
             if (teq && k == N) {   // X[N,:2] == X_ref[N,:2] with multiplier nu
                 for (int j = 0; j < 2; j++) {
                     rdx[j] += NUEQ[j];
-                    e_p = mmpc_max(e_p, fabs(xk[j] - XREF[N * NX + j]));
+                    e_p = mmpc_max_err(e_p, fabs(xk[j] - XREF[N * NX + j]));
                     zsum += fabs(NUEQ[j]);
                 }
             }
             if (NQ) { for (int i = 0; i < NX; i++) RDX[k * NX + i] = rdx[i]; }   // finished in E1b (the next stage's rows add to it)
-            else if (k >= 1) for (int i = 0; i < NX; i++) e_d = mmpc_max(e_d, fabs(rdx[i]));
-            if (k < N) for (int a = 0; a < NU; a++) e_d = mmpc_max(e_d, fabs(rdu[a]));
+            else if (k >= 1) for (int i = 0; i < NX; i++) e_d = mmpc_max_err(e_d, fabs(rdx[i]));
+            if (k < N) for (int a = 0; a < NU; a++) e_d = mmpc_max_err(e_d, fabs(rdu[a]));
         }
         RED[0 * MMPC_WAVE + lane] = e_d; RED[1 * MMPC_WAVE + lane] = e_p; RED[2 * MMPC_WAVE + lane] = tzmax;
         RED[3 * MMPC_WAVE + lane] = tzmin; RED[4 * MMPC_WAVE + lane] = zsum;
@@ -771,29 +774,29 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
         // ---- E1b: finish the s residual (terminal self rows are bound to s_{N-1})
         LANES_BEGIN
         double e_s = 0.0;
-        for (int k = lane; k < NS; k += MMPC_WAVE) e_s = mmpc_max(e_s, fabs(DS[k] - (k == N - 1 ? MISC[1] : 0.0)));
+        for (int k = lane; k < NS; k += MMPC_WAVE) e_s = mmpc_max_err(e_s, fabs(DS[k] - (k == N - 1 ? MISC[1] : 0.0)));
         if (NQ)
             for (int k = lane; k < NS; k += MMPC_WAVE) {
                 if (k < 1) continue;
                 double r9[NX];
                 for (int i = 0; i < NX; i++) r9[i] = RDX[k * NX + i];
                 for (int a = 0; a < 6; a++) r9[kY[a]] += RQ[(k + 1) * 6 + a];
-                for (int i = 0; i < NX; i++) e_s = mmpc_max(e_s, fabs(r9[i]));
+                for (int i = 0; i < NX; i++) e_s = mmpc_max_err(e_s, fabs(r9[i]));
             }
         RED[5 * MMPC_WAVE + lane] = e_s;
         LANES_END
         double err_d = 0.0, err_p = 0.0, tzmax = 0.0, tzmin = 1e300, zsum = 0.0;
         for (int i = 0; i < MMPC_WAVE; i++) {
-            err_d = mmpc_max(err_d, mmpc_max(RED[0 * MMPC_WAVE + i], RED[5 * MMPC_WAVE + i]));
-            err_p = mmpc_max(err_p, RED[1 * MMPC_WAVE + i]);
+            err_d = mmpc_max_err(err_d, mmpc_max_err(RED[0 * MMPC_WAVE + i], RED[5 * MMPC_WAVE + i]));
+            err_p = mmpc_max_err(err_p, RED[1 * MMPC_WAVE + i]);
             tzmax = mmpc_max(tzmax, RED[2 * MMPC_WAVE + i]);
             tzmin = mmpc_min(tzmin, RED[3 * MMPC_WAVE + i]);
             zsum += RED[4 * MMPC_WAVE + i];
         }
         double sd = zsum / (double)(nrows_act + NS * NX);
         sd = (sd > 100.0 ? sd : 100.0) / 100.0;
-        E0 = mmpc_max(mmpc_max(err_d / sd, err_p), tzmax / sd);
-        if (!(E0 == E0) || !mmpc_finite(E0)) {
+        E0 = mmpc_max_err(mmpc_max_err(err_d / sd, err_p), tzmax / sd);
+        if (!mmpc_finite(E0) || !mmpc_finite(zsum)) {   // (NaN fails the comparison inside mmpc_finite too)
 #ifdef MMPC_EMU_DEBUG
             fprintf(stderr, "generic: E0 not finite at it %d: err_d %g err_p %g tzmax %g zsum %g\n", it, err_d, err_p, tzmax, zsum);
 #endif
@@ -1443,6 +1446,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
         LANES_END
         double phi0 = 0.0, th0 = 0.0;
         for (int i = 0; i < MMPC_WAVE; i++) { phi0 += RED[3 * MMPC_WAVE + i]; th0 += RED[4 * MMPC_WAVE + i]; }
+        if (!mmpc_finite(phi0) || !mmpc_finite(th0)) { status = 2; break; }   // (an infinite reference / obstacle: opti.solve() raises)
         if (!filt_init) { nfilt = 0; th_max = 1e4 * mmpc_max(1.0, th0); th_min = 1e-4 * mmpc_max(1.0, th0); filt_init = 1; }
 
         // ---- filter line search (Waechter-Biegler acceptance rules, no restoration phase)

@@ -426,7 +426,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
         double val, ref;
         if (v < NX) {
             double x0 = io.x_init[v];
-            if (KIND == 0) x0 = mmpc_vmax(mmpc_vmin(x0, P.xlim[1][v]), P.xlim[0][v]);
+            if (KIND == 0) x0 = x0 > P.xlim[1][v] ? P.xlim[1][v] : (x0 < P.xlim[0][v] ? P.xlim[0][v] : x0);   // (a NaN stays a NaN: status 2)
             val = (io.x_guess && k >= 1) ? io.x_guess[k * NX + v] : x0;
             ref = io.traj_ref[k * NX + v];
         } else {
@@ -956,7 +956,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
         sd = (sd > 100.0 ? sd : 100.0) * 0.01;
         const double isd = mmpc_rcp(sd);
         E0 = mmpc_vmax(mmpc_vmax(err_d * isd, err_p), tzmax * isd);
-        if (!(E0 == E0) || !mmpc_finite(E0) || !(th_c + cost_c + zsum == th_c + cost_c + zsum)) {   // (the sums carry every NaN of the point)
+        if (!mmpc_finite(E0) || !mmpc_finite(th_c + cost_c + zsum)) {   // NaN or inf anywhere in the point or its data (the sums carry them)
 #ifdef MMPC_EMU_DEBUG
             fprintf(stderr, "E0 nan it %d: err_d %g err_p %g tzmax %g tzmin %g zsum %g sumlog %g\n", it, err_d, err_p, tzmax, tzmin, zsum, sumlog);
 #endif
