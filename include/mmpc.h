@@ -96,7 +96,9 @@ int mmpc_reset(mmpc_handle h);
  * instances 0..B-1 and replaces it for the instances that CONVERGED - the reference assigns u_latest / x_guess after a
  * successful solve only (:329-330 follow the exception of :315), a failed instance keeps what it had.
  * x_init of the whole-body kind is clipped to xlim (:290-291) inside.
- * Any out_* may be NULL except out_u0.  out_u0[B][nu] = U*[0] (the reference's return value). */
+ * Any out_* may be NULL except out_u0.  out_u0[B][nu] = U*[0] (the reference's return value).
+ * B = 0 (an empty batch, e.g. the shard of a rank beyond the end of the batch) is a no-op that returns MMPC_OK, here and in
+ * the device-pointer calls; B > max_batch is MMPC_E_ARG. */
 int mmpc_solve_batch(mmpc_handle h, int B, const double *x_init, const double *traj_ref, const double *u_ref,
                      const double *obs, double *out_u0, double *out_X, double *out_U, double *out_s, int *out_status,
                      int *out_iters, double *out_cost);

@@ -495,6 +495,7 @@ extern "C" int mmpc_resume_batch_device(mmpc_handle h, int B, const double *d_x_
                                         const double *d_u_ref, const double *d_u_last, const double *d_x_guess,
                                         const double *d_obs, double *d_X, double *d_U, double *d_s, int *d_status,
                                         int *d_iters, double *d_cost, double *d_err, void *stream) {
+    if (h && B == 0) return MMPC_OK;   // an empty batch (e.g. the shard of a rank beyond the batch) is a no-op
     if (!h || B < 1 || B > h->cfg.max_batch || !d_x_init || !d_traj_ref || !d_u_ref || !d_u_last || !d_X || !d_U || !d_s ||
         !d_status || !d_iters || !d_cost || !d_err || (h->cfg.M > 0 && !d_obs))
         return fail(h, MMPC_E_ARG, "mmpc_resume_batch_device: %s%s", "bad argument");
@@ -533,6 +534,7 @@ extern "C" int mmpc_solve_batch_device(mmpc_handle h, int B, const double *d_x_i
                                        const double *d_u_ref, const double *d_u_last, const double *d_x_guess,
                                        const double *d_obs, double *d_X, double *d_U, double *d_s, int *d_status,
                                        int *d_iters, double *d_cost, double *d_err, void *stream) {
+    if (h && B == 0) return MMPC_OK;   // an empty batch (e.g. the shard of a rank beyond the batch) is a no-op
     if (!h || B < 1 || !d_x_init || !d_traj_ref || !d_u_ref || !d_u_last || !d_X || !d_U || !d_s || !d_status ||
         !d_iters || !d_cost || !d_err || (h->cfg.M > 0 && !d_obs))
         return fail(h, MMPC_E_ARG, "mmpc_solve_batch_device: %s%s", "bad argument");
@@ -544,6 +546,7 @@ extern "C" int mmpc_solve_batch_device(mmpc_handle h, int B, const double *d_x_i
 extern "C" int mmpc_solve_batch(mmpc_handle h, int B, const double *x_init, const double *traj_ref, const double *u_ref,
                                 const double *obs, double *out_u0, double *out_X, double *out_U, double *out_s,
                                 int *out_status, int *out_iters, double *out_cost) {
+    if (h && B == 0) return MMPC_OK;   // an empty batch (e.g. the shard of a rank beyond the batch) is a no-op
     if (!h || B < 1 || B > h->cfg.max_batch || !x_init || !traj_ref || !u_ref || !out_u0 || (h->cfg.M > 0 && !obs))
         return fail(h, MMPC_E_ARG, "mmpc_solve_batch: %s%s", "bad argument (B must be in 1..max_batch)");
     HIPCHK(h, hipSetDevice(h->cfg.device));

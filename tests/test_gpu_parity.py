@@ -374,3 +374,23 @@ def test_weights_and_limits_surface(mm):
         # the limits bind: some inputs sit on the merged box min(ulim, u_last + dulim) = 1.0
         assert (np.abs(r["U"][:, :, 0]) > 1.0 - 1e-6).any()
         assert (r["U"] <= par.ulim[1] + 1e-9).all() and (r["U"] >= par.ulim[0] - 1e-9).all()
+
+
+@pytest.mark.gpu
+def test_empty_single_and_ragged_batches(mm):
+    """Edge sizes of the batch dimension: B = 0 returns empty arrays, B = 1 equals row 0 of a larger batch bit for bit, and
+    successive calls of different sizes on one handle (ragged use) give each instance the result it gets on its own."""
+    N, M = 20, 5
+    d = synth.make_batch(9, N=N, M=M)
+    par = nlp.WholeBodyParams(N=N)
+    xi = np.clip(d["x_init"], par.xlim[0], par.xlim[1])
+    ctrl = _wb(mm, N, M, 16)
+    r0 = ctrl.solve_batch(xi[:0], d["traj_ref"][:0], d["u_ref"][:0], d["obs"][:0])
+    assert r0["X"].shape == (0, N + 1, 9) and r0["U"].shape == (0, N, 5) and r0["status"].shape == (0,)
+    ctrl.reset()
+    r9 = ctrl.solve_batch(xi, d["traj_ref"], d["u_ref"], d["obs"])
+    assert (r9["status"] == 0).all()
+    for sl in (slice(0, 1), slice(3, 8), slice(8, 9)):
+        ctrl.reset()
+        r = ctrl.solve_batch(xi[sl], d["traj_ref"][sl], d["u_ref"][sl], d["obs"][sl])
+        assert np.array_equal(r["X"], r9["X"][sl]) and np.array_equal(r["U"], r9["U"][sl]) and np.array_equal(r["iters"], r9["iters"][sl])
