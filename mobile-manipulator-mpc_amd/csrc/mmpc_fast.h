@@ -307,6 +307,8 @@ struct MmpcLaneState {
     // f_v: coefficient ids (into CV[k]) of C_2..C_5, f_x: id of C_u << 8 | (a + 1) << 16 (a: the input of this row, -1 none)
     unsigned f_v, f_x;
     double fw[MMPC_FW_SLOTS];                        // dx_k[lane] during the roll-out (exchanged by v_readlane, not LDS)
+    int fw_a[5];                                     // where the lane stores dx_{k+1}[lane] and du_k[a]: LDS offsets at k = 0 and their stage stride
+                                                     // (set once per roll-out: the lane id is opaque to the compiler in every phase)
 };
 
 #ifndef MMPC_EMU
@@ -1390,6 +1392,14 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
             auto &ls = MMPC_LS;
             for (int j = lane; j < NV; j += MMPC_WAVE) DXU[j] = 0.0;
             ls.fw[MMPC_FW_SLOT(0)] = 0.0;
+            {   // (lanes that own no row / no input write to their dump slot: no branch in the loop)
+                const int a = (int)MMPC_B(ls.f_x, 2) - 1;
+                ls.fw_a[0] = lane < NX ? L.DXU + NV + lane : L.DUMP + lane;
+                ls.fw_a[1] = (lane < NX && a >= 0 && lane != 4) ? L.DXU + NX + a : L.DUMP + lane;
+                ls.fw_a[2] = lane < NX ? NV : 0;
+                ls.fw_a[3] = lane < NX ? lane : 0;        // row of the dynamics this lane carries
+                ls.fw_a[4] = a < 0 ? 0 : a;               // the input that enters this row
+            }
             LANES_END
 #ifndef MMPC_EMU
             {   // operands of stage 0
@@ -1408,9 +1418,8 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
             for (int k = 0; k < N; k++) {
                 LANES_BEGIN
                 auto &ls = MMPC_LS;
-                const int i = lane < NX ? lane : 0, a = (int)MMPC_B(ls.f_x, 2) - 1, aa = a < 0 ? 0 : a;
-                const int fw_st = lane < NX ? NV : 0, fw_dx = lane < NX ? L.DXU + NV + lane : L.DUMP + lane,
-                          fw_du = (lane < NX && a >= 0 && lane != 4) ? L.DXU + NX + a : L.DUMP + lane;
+                const int i = ls.fw_a[3], aa = ls.fw_a[4];
+                const int fw_dx = ls.fw_a[0], fw_du = ls.fw_a[1], fw_st = ls.fw_a[2];
                 double kr[NX], cf[5], kf0, c0;
 #ifdef MMPC_EMU
                 {
