@@ -148,6 +148,12 @@ MMPC_DEV void mmpc_arm_segments_fast(double q1, double q2, double q3, double dr[
     dr[2] = MMPC_A6 * cB - MMPC_A7 * sB;
     dz[2] = -MMPC_A6 * sB - MMPC_A7 * cB;
 }
+// product of two small non-negative integers (LDS offsets): v_mul_u32_u24 / v_mad_u32_u24 instead of the quarter-rate 32-bit multiply
+#ifdef MMPC_EMU
+#define MMPC_MUL24(a, b) ((a) * (b))
+#else
+#define MMPC_MUL24(a, b) ((int)__umul24((unsigned)(a), (unsigned)(b)))
+#endif
 // state entries the forward kinematics depends on (x, y, psi, q1, q2, q3), as a constant expression
 MMPC_HD constexpr int mmpc_y(int a) { return a < 3 ? a : a + 3; }
 
@@ -182,6 +188,9 @@ struct MmpcFastDims {
     // the input rows, accumulator registers that hold the input rows NX+1..NV of the stage matrix
     static constexpr int NKB = (NX + 1 + 3) / 4;
     static constexpr int NPU = NU * (NU - 1) / 2;   // couplings between the inputs of a stage kept for the gain back-substitution
+    // input elimination legs of a Riccati stage: inputs whose tile rows (2q, 2q+1) share an accumulator register go in pairs
+    static constexpr bool PAIRS = ((NX + 1) & 1) == 0;
+    static constexpr int NLEG = PAIRS ? (NU + 1) / 2 : NU;
     // Long horizons and the base kind spread the circle rows of a stage over RG lanes (lane s NS + k owns the rows m = s + RG r
     // of stage k): those instantiations are short of registers (8 rows per stage; the 256-register cap of two waves per SIMD),
     // not of lanes.  (At most 3: the partial sums of the other
@@ -298,8 +307,8 @@ struct MmpcLaneState {
                                                      // stage-(N-1) extra term (Q1 elimination of s_{N-1}) or of the constant 0
     unsigned h_m;                                    // bit r: register r is part of [P p; p^T .]; bit 4+r: ... and is stored (lower triangle, p)
     unsigned p_o[4];                                 // where register r of [P_k | p_k] is stored: h_o[r] for the stored entries, a dump slot otherwise
-    unsigned kr_o[F::NU];                            // where this lane stores its entry of the normalised pivot row of input a: LDS
-                                                     // offset | stage stride << 16 (gain row / kf / coupling; a dump slot otherwise)
+    int kl_b[F::NLEG], kl_s[F::NLEG];                // where this lane stores its entry of the normalised pivot row(s) of leg l: LDS byte
+                                                     // offset at stage 0 and per-stage stride (gain row / kf / coupling; a dump slot otherwise)
     MmpcAcc rP, rT, rM;                              // cost-to-go [P p; p^T .], its product T with the dynamics, stage matrix M
     double rAB[F::NKB], opa, opb;                    // MFMA operands
     double nab[F::NKB], nhm[4];                      // next stage's dynamics rows and stage-matrix entries (loaded one stage ahead)
@@ -511,17 +520,22 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
             ls.p_o[r] = ((ls.h_m >> (4 + r)) & 1u) ? ls.h_o[r] : (unsigned)(L.DUMP + lane);
         }
 #pragma unroll
-        for (int a = 0; a < NU; a++) {
+        for (int l = 0; l < F::NLEG; l++) {
             // pivot row of input a = row NX+1+a of the stage matrix, held by lane group (NX+1+a) & 3: its entry in column j,
-            // divided by the pivot, is a gain-row entry (j < NX), the feed-forward (j = NX) or the coupling to a later input
-            const int ta = NX + 1 + a;
+            // divided by the pivot, is a gain-row entry (j < NX), the feed-forward (j = NX) or the coupling to a later input.
+            // A leg eliminates input a0 or the pair (a0, a0 + 1), whose rows sit in neighbouring lane groups
+            const int a0 = F::PAIRS ? 2 * l : l;
             unsigned off = (unsigned)(L.DUMP + lane), stride = 0;
-            if (g == (ta & 3)) {
-                if (j < NX) { off = (unsigned)(L.KK + a * NX + j); stride = NU * NX; }
-                else if (j == NX) { off = (unsigned)(L.KF + a); stride = NU; }
-                else if (j > ta && j <= NV) { const int b2 = j - NX - 1; off = (unsigned)(L.KU + a * (2 * NU - a - 1) / 2 + (b2 - a - 1)); stride = NPU; }
+#pragma unroll
+            for (int a = a0; a < NU && a <= a0 + (F::PAIRS ? 1 : 0); a++) {
+                const int ta = NX + 1 + a;
+                if (g == (ta & 3)) {
+                    if (j < NX) { off = (unsigned)(L.KK + a * NX + j); stride = NU * NX; }
+                    else if (j == NX) { off = (unsigned)(L.KF + a); stride = NU; }
+                    else if (j > ta && j <= NV) { const int b2 = j - NX - 1; off = (unsigned)(L.KU + a * (2 * NU - a - 1) / 2 + (b2 - a - 1)); stride = NPU; }
+                }
             }
-            ls.kr_o[a] = off | (stride << 16);
+            ls.kl_b[l] = (int)off * 8; ls.kl_s[l] = (int)stride * 8;
         }
         {
             unsigned fv = 0, fx = 0;
@@ -1291,8 +1305,8 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                 // the second group fetching its partner's row entry from lane ^ 16.  What is left in rows / columns (x, 1) after the
                 // last input is [P_k p_k; p_k^T .].  The normalised rows c / d are kept: u_a = -(c/d) . (dx, 1,
                 // u_b>a), from which the gains are formed for all stages at once after the pass.
-                constexpr bool PAIRS = ((NX + 1) & 1) == 0;               // first input row even -> rows (2q, 2q+1) share a register
-                constexpr int NLEG = PAIRS ? (NU + 1) / 2 : NU;
+                constexpr bool PAIRS = F::PAIRS;                          // first input row even -> rows (2q, 2q+1) share a register
+                constexpr int NLEG = F::NLEG;
 #pragma unroll
                 for (int leg = 0; leg < NLEG; leg++) {
                     LANES_BEGIN
@@ -1303,7 +1317,6 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                     const double c = ls.rM[ra];
                     double w, cb = c;
                     bool own;
-                    unsigned o;
                     if (pair) {
                         const double d00 = MMPC_LANE_GET(rM[ra], 16 * ga + ta), d01 = MMPC_LANE_GET(rM[ra], 16 * ga + ta + 1),
                                      d11 = MMPC_LANE_GET(rM[ra], 16 * (ga + 1) + ta + 1);
@@ -1316,17 +1329,15 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                         own = g == ga || in1;
                         cb = in1 ? fma(-l, co, c) : c;
                         w = cb * (in1 ? i1 : i0);
-                        o = in1 ? ls.kr_o[a0 + 1 < NU ? a0 + 1 : a0] : ls.kr_o[a0];
                     } else {
                         const double d = MMPC_LANE_GET(rM[ra], 16 * ga + ta);
                         if (!(d > 0.0)) ric_bad = 1;
                         own = g == ga;
                         w = c * mmpc_rcp3(d);
-                        o = ls.kr_o[a0];
                     }
                     ls.opa = own ? -w : 0.0;
                     ls.opb = own ? cb : 0.0;
-                    lds[(o & 0xffffu) + k * (int)(o >> 16)] = w;   // (lanes that hold no entry of the row write to their dump slot: no branch)
+                    *(double *)((char *)lds + (ls.kl_b[leg] + MMPC_MUL24(k, ls.kl_s[leg]))) = w;   // (lanes that hold no entry of the row write to their dump slot: no branch)
                     LANES_END_REG
                     MMPC_MFMA(rM, ls.opa, ls.opb)
                 }
