@@ -251,10 +251,10 @@ struct MmpcFastLayout {
 // reference trajectory, the previous inputs and the per-stage obstacle table - in HBM/L2 instead of LDS: at N = 30, M = 8 that is 63.2 -> 52.6 KB
 // per problem, i.e. three resident problems per CU instead of two.
 template <int KIND, int N>
-MMPC_HD MmpcFastLayout mmpc_fast_layout(int M, int obs_per_stage) {
+MMPC_HD constexpr MmpcFastLayout mmpc_fast_layout(int M, int obs_per_stage) {
     typedef MmpcFastDims<KIND, N> F;
     constexpr bool SLIM = N >= MMPC_SLIM_NMIN;
-    MmpcFastLayout L;
+    MmpcFastLayout L{};
     int o = 0;
 #define MMPC_CARVE(name, n) L.name = o; o += (n); o = (o + 1) & ~1;
     MMPC_CARVE(XU, F::NS * F::NV) MMPC_CARVE(S, F::NS) MMPC_CARVE(LAM, F::NS * F::NX)
@@ -384,10 +384,13 @@ struct MmpcLogAcc {
 
 // CONT: built with the iteration budget / continuation code (a separate instantiation: the extra live values cost the
 // default kernel registers it does not have)
-template <int KIND, int N, int MC, bool CONT = false>
+// OPS: the configuration's obs_per_stage when it is a constant of the instantiation (the device kernels: every LDS offset is
+// then an immediate), -1: read from the parameter block
+template <int KIND, int N, int MC, bool CONT = false, int OPS = -1>
 MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds MMPC_EMU_ARG) {
     typedef MmpcFastDims<KIND, N> F;
     typedef MmpcTab<KIND> TB;
+    const int ops = OPS >= 0 ? OPS : P.obs_per_stage;
     constexpr int NX = F::NX, NU = F::NU, NV = F::NV, NXX = F::NXX, NUU = F::NUU, NSELF = F::NSELF, NS = F::NS;
     constexpr int NPASS = F::NPASS, NPAIR = F::NPAIR, NKB = F::NKB, NPU = F::NPU;
     constexpr int M = MC;   // number of circle obstacles is a template parameter on this path
@@ -403,7 +406,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
 #endif
     constexpr bool SLIM = N >= MMPC_SLIM_NMIN;   // references and per-stage obstacles are read from HBM/L2 (see mmpc_fast_layout)
     constexpr int RIC_UNROLL = ROOMY ? MMPC_RIC_UNROLL : 1, FWD_UNROLL = ROOMY ? (MMPC_FWD_UNROLL < N ? MMPC_FWD_UNROLL : N) : 1;
-    const MmpcFastLayout L = mmpc_fast_layout<KIND, N>(M, P.obs_per_stage);
+    const MmpcFastLayout L = mmpc_fast_layout<KIND, N>(M, ops);
     double *XU = lds + L.XU, *S = lds + L.S, *LAM = lds + L.LAM, *XUREF = lds + L.XUREF, *ULAST = lds + L.ULAST,
            *OBS = lds + L.OBS, *CST = lds + L.CST, *CV = lds + L.CV, *CD = lds + L.CD, *TRG = lds + L.TRG, *HXX = lds + L.HXX,
            *QXU = lds + L.QXU, *HUXL = lds + L.HUXL, *HUUL = lds + L.HUUL, *HUX02 = lds + L.HUX02,
@@ -418,8 +421,8 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
     MmpcLaneState<KIND, N, MC> ls_one;
     double wr_one[8];
 #endif
-    const double *const OBSP = (SLIM && P.obs_per_stage) ? io.obs : OBS;
-    auto obs_ptr = [&](int k, int m) -> const double * { return OBSP + ((P.obs_per_stage ? k * M : 0) + m) * 3; };
+    const double *const OBSP = (SLIM && ops) ? io.obs : OBS;
+    auto obs_ptr = [&](int k, int m) -> const double * { return OBSP + ((ops ? k * M : 0) + m) * 3; };
     auto ulast_at = [&](int k, int a) -> double {
         if (!SLIM) return ULAST[k * NU + a];
         return k < N ? io.u_last[k * NU + a] : 0.0;
@@ -451,8 +454,8 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
         for (int i = lane; i < NS * NU; i += MMPC_WAVE) ULAST[i] = i < N * NU ? io.u_last[i] : 0.0;
     for (int i = lane; i < NS * NX; i += MMPC_WAVE) LAM[i] = 0.0;
     for (int i = lane; i < NS; i += MMPC_WAVE) S[i] = 0.0;
-    if (!(SLIM && P.obs_per_stage))
-        for (int i = lane; i < (P.obs_per_stage ? NS : 1) * M * 3; i += MMPC_WAVE) OBS[i] = io.obs[i];
+    if (!(SLIM && ops))
+        for (int i = lane; i < (ops ? NS : 1) * M * 3; i += MMPC_WAVE) OBS[i] = io.obs[i];
     for (int i = lane; i < MMPC_C_SIZE; i += MMPC_WAVE) {
         double v = 0.0;
         if (i < 18) v = P.xlim[i / 9][i % 9];

@@ -48,14 +48,17 @@ __global__ __launch_bounds__(MMPC_WAVE) void mmpc_solve_kernel(
 }
 
 // WPE = waves per SIMD the register allocation is sized for (2: <= 256 registers, only pays when LDS allows >4 problems/CU)
-template <int KIND, int N, int MC, int WPE, bool CONT>
+// OPS = obstacle table per stage (config obs_per_stage): part of the LDS layout.  The LDS block is STATIC (its size is a
+// constant of the instantiation): with `extern __shared__` the base of the dynamic block is resolved after instruction
+// selection and every lane-derived LDS address carries an add of that constant 0 (14 of the ~200 instructions of a Riccati stage).
+template <int KIND, int N, int MC, int WPE, bool CONT, int OPS>
 __global__ __launch_bounds__(MMPC_WAVE, WPE) void mmpc_fast_kernel(
     const MmpcParams *__restrict__ Pp, int B, const double *__restrict__ x_init, const double *__restrict__ traj_ref,
     const double *__restrict__ u_ref, const double *__restrict__ u_last, const double *__restrict__ x_guess,
     const double *__restrict__ obs, double *__restrict__ X, double *__restrict__ U, double *__restrict__ s,
     int *__restrict__ status, int *__restrict__ iters, double *__restrict__ cost, double *__restrict__ err,
     const int *__restrict__ order, int budget, double *__restrict__ state, int state_stride, const int *__restrict__ resume_count) {
-    extern __shared__ double lds[];
+    __shared__ double lds[mmpc_fast_layout<KIND, N>(MC, OPS).total];
     typedef MmpcDims<KIND> D;
     if ((int)blockIdx.x >= B) return;
     // a continuation launch: `order` is the compacted list of the suspended instances, *resume_count its length
@@ -83,7 +86,7 @@ __global__ __launch_bounds__(MMPC_WAVE, WPE) void mmpc_fast_kernel(
     io.state = state ? state + (size_t)b * state_stride : nullptr;
     io.budget = budget;
     io.resume = resume_count ? 1 : 0;
-    mmpc_solve_fast<KIND, N, MC, CONT>(P, io, lds);
+    mmpc_solve_fast<KIND, N, MC, CONT, OPS>(P, io, lds);
 }
 
 // (kind, N, M) triples with a specialised kernel; everything else runs the generic kernel.
@@ -328,9 +331,8 @@ extern "C" int mmpc_create(const mmpc_config *cfg, mmpc_handle *out) {
             h->fast = 1;                                                                                               \
             h->state_doubles = mmpc_fast_state_doubles<K, NN>(MM);                                                     \
             h->fast_lds_bytes = mmpc_fast_layout<K, NN>(MM, p.obs_per_stage).total * (int)sizeof(double);         \
-            HIPCHK(h, hipFuncSetAttribute((const void *)mmpc_fast_kernel<K, NN, MM, WW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, h->fast_lds_bytes)); \
-            HIPCHK(h, hipFuncSetAttribute((const void *)mmpc_fast_kernel<K, NN, MM, WW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, h->fast_lds_bytes)); \
-            HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&h->fast_per_cu, mmpc_fast_kernel<K, NN, MM, WW, false>, MMPC_WAVE, h->fast_lds_bytes)); \
+            if (p.obs_per_stage) HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&h->fast_per_cu, mmpc_fast_kernel<K, NN, MM, WW, false, 1>, MMPC_WAVE, 0)); \
+            else HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&h->fast_per_cu, mmpc_fast_kernel<K, NN, MM, WW, false, 0>, MMPC_WAVE, 0)); \
         }
         MMPC_FAST_LIST(MMPC_X)
 #undef MMPC_X
@@ -437,19 +439,22 @@ static int launch(mmpc_handle h, int B, const double *x_init, const double *traj
     }
     const int *order = (history || (lpt && h->cfg.M > 0)) ? h->d_order : nullptr;
     if (use_fast) {
-#define MMPC_X(K, NN, MM, WW)                                                                                          \
-        if (h->cfg.kind == K && h->cfg.N == NN && h->cfg.M == MM) {                                                                        \
+#define MMPC_LAUNCH_FAST(K, NN, MM, WW, OPS)                                                                              \
             if (resume || h->budget > 0)                                                                                               \
-                hipLaunchKernelGGL((mmpc_fast_kernel<K, NN, MM, WW, true>), dim3(B), dim3(MMPC_WAVE), h->fast_lds_bytes, st, h->dp, B,     \
+                hipLaunchKernelGGL((mmpc_fast_kernel<K, NN, MM, WW, true, OPS>), dim3(B), dim3(MMPC_WAVE), 0, st, h->dp, B,               \
                                    x_init, traj, uref, ulast, xguess, obs, X, U, s, status, iters, cost, err, resume ? h->d_list : order, \
                                    resume ? 0 : h->budget, h->d_state, h->state_doubles, resume ? h->d_count : (const int *)nullptr);   \
             else                                                                                                                       \
-                hipLaunchKernelGGL((mmpc_fast_kernel<K, NN, MM, WW, false>), dim3(B), dim3(MMPC_WAVE), h->fast_lds_bytes, st, h->dp, B,    \
+                hipLaunchKernelGGL((mmpc_fast_kernel<K, NN, MM, WW, false, OPS>), dim3(B), dim3(MMPC_WAVE), 0, st, h->dp, B,              \
                                    x_init, traj, uref, ulast, xguess, obs, X, U, s, status, iters, cost, err, order, 0,                  \
-                                   (double *)nullptr, 0, (const int *)nullptr);                                                         \
+                                   (double *)nullptr, 0, (const int *)nullptr);
+#define MMPC_X(K, NN, MM, WW)                                                                                          \
+        if (h->cfg.kind == K && h->cfg.N == NN && h->cfg.M == MM) {                                                   \
+            if (h->cfg.obs_per_stage) { MMPC_LAUNCH_FAST(K, NN, MM, WW, 1) } else { MMPC_LAUNCH_FAST(K, NN, MM, WW, 0) }   \
         }
         MMPC_FAST_LIST(MMPC_X)
 #undef MMPC_X
+#undef MMPC_LAUNCH_FAST
     } else if (h->cfg.kind == MMPC_KIND_WHOLEBODY)
         hipLaunchKernelGGL(mmpc_solve_kernel<0>, dim3(B), dim3(MMPC_WAVE), h->lds_bytes, st, h->dp, B, x_init, traj, uref,
                            ulast, xguess, obs, X, U, s, status, iters, cost, err, order);
