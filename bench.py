@@ -300,6 +300,12 @@ def main():
                                      "max_abs_dX_vs_specialised": float((outg["X"] - out["X"]).abs().max()),
                                      "note": "mmpc_solve_kernel<0> (all state in LDS, scalar Riccati) on the same batch"}
             del ctrlg, outg
+            # (1d) the demo's shape (config C1: N = 20, three circle obstacles, two half-space planes): generic kernel with a
+            # static LDS block (MMPC_STATIC_LIST), 2048 starts around the planes' ridge, intended rows and rows as written
+            try:
+                res["c1_shape_generic_kernel"] = c1_shape_extra(mm, robot, dev)
+            except Exception as e:                                             # an extra: never takes the bench line down
+                res["c1_shape_generic_kernel"] = {"error": repr(e)}
             # (2) two batches in flight (two handles, two HIP streams, alternating): the drain of one launch - waves still
             # iterating on its slowest instances while CUs idle - is filled by the next launch.  No hint.
             eng.set_schedule_hint(2)
@@ -365,6 +371,39 @@ def main():
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
+
+
+def c1_shape_extra(mm, robot, dev, B=2048, N=20):
+    """Generic kernel on the demo's shape (starts as in tests/test_gpu_certificates.py::test_as_written_halfspace_rows_batch)."""
+    import torch
+    r2 = 1 / np.sqrt(2)
+    hs = np.array([[2.5, 2, 0.35 + 0.606 + 0.333, r2, 0, r2], [2.5, 2, 0.35 + 0.606 + 0.333, -r2, 0, r2]])
+    rng = np.random.default_rng(11)
+    x = np.zeros((B, 9)); tr = np.zeros((B, N + 1, 9))
+    for b in range(B):
+        x0 = np.array([rng.uniform(1.4, 2.6), rng.uniform(1.6, 2.4), rng.uniform(-0.4, 0.4), rng.uniform(0, 0.8), 0, 0,
+                       rng.uniform(-0.3, 0.6), rng.uniform(-1.6, -0.6), rng.uniform(0.8, 2.2)])
+        x0[4] = x0[3] * np.sin(x0[2]); x0[3] = x0[3] * np.cos(x0[2])
+        tg = x0.copy(); tg[0] += rng.uniform(0.8, 1.8); tg[1] += rng.uniform(-0.3, 0.3); tg[3:6] = 0
+        x[b] = x0; tr[b] = np.linspace(x0, tg, 51)[:N + 1]
+    obs = np.broadcast_to(np.array([[2.5, 3.4, 0.3], [2.5, 0.6, 0.3], [6, 6, 0.1]]), (B, 3, 3)).copy()
+    oml = [(h[:3], h[3:].reshape(1, 3)) for h in hs]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    xi, trd, ob = t(x), t(tr), t(obs)
+    z = torch.zeros((B, N, 5), dtype=torch.float64, device=dev)
+    out = {"unit": "solves/s", "batch": B, "note": "mmpc_solve_kernel_static<0,20,3,0,2,*>: all state in LDS, scalar Riccati; a-priori order"}
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for name, fc in (("intended_rows", False), ("rows_as_written", None)):
+        ctrl = mm.MPCWholeBody(robot, [], oml, N=N, max_batch=B, device=dev.index if dev.index is not None else 0, n_obstacles=3, faithful_convex=fc)
+        eng = ctrl._engine
+        eng.set_schedule_hint(2)
+        o = eng.solve_batch_device(xi, trd, z, z, ob)
+        e0.record(); o = eng.solve_batch_device(xi, trd, z, z, ob, out=o); e1.record(); e1.synchronize()
+        ms = e0.elapsed_time(e1)
+        out[name] = {"ms": ms, "value": B / (ms * 1e-3), "converged_frac": float((o["status"] == 0).double().mean()),
+                     "mean_iters": float(o["iters"].double().mean()), "lds_bytes_per_problem": eng.lds_bytes, "problems_per_cu": eng.problems_per_cu}
+        del ctrl, o
+    return out
 
 
 def cpu_baseline(d, N, M, ns, gpu_X, obs=None, u_last=None, x_init=None, traj=None):

@@ -168,9 +168,9 @@ struct MmpcLayout {
 };
 
 template <int KIND>
-MMPC_HD MmpcLayout mmpc_layout(int N, int M, int obs_per_stage, int nhs = 0, int nq = 0) {
+MMPC_HD constexpr MmpcLayout mmpc_layout(int N, int M, int obs_per_stage, int nhs = 0, int nq = 0) {
     typedef MmpcDims<KIND> D;
-    MmpcLayout L;
+    MmpcLayout L{};
     int o = 0;
     const int NS = N + 1;
     // nhs = 6 half-space rows per stage when L > 0; nq = 6 (L-1) rows of the NLP as written (quirk Q8; none at stage 0)
@@ -446,7 +446,9 @@ MMPC_DEV double mmpc_state_cost(const double *WTS, bool terminal, const double *
 // NC, MC, OPSC, LC: horizon, circle obstacles, per-stage obstacle table and number of half-space planes as compile-time
 // constants (0 / -1: taken from P at run time).  With run-time sizes the 54 LDS offsets of the layout are live scalars for
 // the whole solve - they spill to vector lanes, and those to scratch; instantiated for a shape they are constants.
-template <int KIND, int NC = 0, int MC = -1, int OPSC = -1, int LC = -1>
+// NC, MC, OPSC, LC, AWC: horizon, circle obstacles, obs_per_stage, half-space planes and the as-written flag when they are
+// constants of the instantiation (the demo's shapes: every LDS offset is then an immediate), 0 / -1: read from the parameter block
+template <int KIND, int NC = 0, int MC = -1, int OPSC = -1, int LC = -1, int AWC = -1>
 MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds MMPC_EMU_ARG) {
     typedef MmpcDims<KIND> D;
     typedef MmpcTab<KIND> TB;
@@ -454,7 +456,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
     const int N = NC ? NC : P.N, M = MC >= 0 ? MC : P.M, NS = N + 1;
     const int OPS = OPSC >= 0 ? OPSC : P.obs_per_stage, PL = LC >= 0 ? LC : P.L;
     const int NHS = (KIND == 0 && PL > 0) ? 6 : 0;
-    const int NQ = (KIND == 0 && P.as_written && PL >= 2) ? 6 * (PL - 1) : 0;   // rows of the NLP as written (quirk Q8), stages >= 1
+    const int NQ = (KIND == 0 && (AWC >= 0 ? AWC : P.as_written) && PL >= 2) ? 6 * (PL - 1) : 0;   // rows of the NLP as written (quirk Q8), stages >= 1
     constexpr int NREF = D::NREF;
     constexpr int HRMAX = KIND == 0 ? 16 + 4 + 6 + 42 : 16 + 4 + 6;
     const MmpcLayout L = mmpc_layout<KIND>(N, M, OPS, NHS, NQ);

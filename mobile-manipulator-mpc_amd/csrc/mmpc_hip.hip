@@ -48,6 +48,45 @@ __global__ __launch_bounds__(MMPC_WAVE) void mmpc_solve_kernel(
 }
 
 // WPE = waves per SIMD the register allocation is sized for (2: <= 256 registers, only pays when LDS allows >4 problems/CU)
+// The generic kernel for a shape that is a constant of the instantiation (the demo's shapes, MMPC_STATIC_LIST): static LDS block
+// and compile-time layout, as for the specialised kernels below; same code, same results as mmpc_solve_kernel<KIND>.
+template <int KIND, int NC, int MC, int OPSC, int LC, int AWC>
+__global__ __launch_bounds__(MMPC_WAVE) void mmpc_solve_kernel_static(
+    const MmpcParams *__restrict__ Pp, int B, const double *__restrict__ x_init, const double *__restrict__ traj_ref,
+    const double *__restrict__ u_ref, const double *__restrict__ u_last, const double *__restrict__ x_guess,
+    const double *__restrict__ obs, double *__restrict__ X, double *__restrict__ U, double *__restrict__ s,
+    int *__restrict__ status, int *__restrict__ iters, double *__restrict__ cost, double *__restrict__ err,
+    const int *__restrict__ order) {
+    typedef MmpcDims<KIND> D;
+    constexpr int NHS = (KIND == 0 && LC > 0) ? 6 : 0, NQ = (KIND == 0 && AWC && LC >= 2) ? 6 * (LC - 1) : 0;
+    __shared__ double lds[mmpc_layout<KIND>(NC, MC, OPSC, NHS, NQ).total];
+    if ((int)blockIdx.x >= B) return;
+    const int b = order ? order[blockIdx.x] : (int)blockIdx.x;
+    const MmpcParams &P = *Pp;
+    constexpr int N = NC, M = MC;
+    constexpr size_t so = (size_t)(OPSC ? N + 1 : 1) * M * 3;
+    MmpcIO io;
+    io.x_init = x_init + (size_t)b * D::NX;
+    io.traj_ref = traj_ref + (size_t)b * (N + 1) * D::NREF;
+    io.u_ref = u_ref + (size_t)b * N * D::NU;
+    io.u_last = u_last + (size_t)b * N * D::NU;
+    io.x_guess = x_guess ? x_guess + (size_t)b * (N + 1) * D::NX : nullptr;
+    io.u_guess = P.u_guess ? P.u_guess + (size_t)b * N * D::NU : nullptr;
+    io.obs = obs + (size_t)b * so;
+    io.X = X + (size_t)b * (N + 1) * D::NX;
+    io.U = U + (size_t)b * N * D::NU;
+    io.s = s + (size_t)b * (N + 1);
+    io.status = status + b;
+    io.iters = iters + b;
+    io.cost = cost + b;
+    io.err = err + b;
+    io.state = nullptr; io.budget = 0; io.resume = 0;
+    mmpc_solve_one<KIND, NC, MC, OPSC, LC, AWC>(P, io, lds);
+}
+// (kind, N, M, obs_per_stage, L, as_written): demo_wholebody_qref.py scenario 2 (two planes) as written and with the intended
+// rows, scenario 1 (three planes) as written, and the plane-free shape (the terminal-xy 'approach' phase of scenario 0)
+#define MMPC_STATIC_LIST(X) X(0, 20, 3, 0, 2, 1) X(0, 20, 3, 0, 2, 0) X(0, 20, 3, 0, 3, 1) X(0, 20, 3, 0, 0, 0)
+
 // OPS = obstacle table per stage (config obs_per_stage): part of the LDS layout.  The LDS block is STATIC (its size is a
 // constant of the instantiation): with `extern __shared__` the base of the dynamic block is resolved after instruction
 // selection and every lane-derived LDS address carries an add of that constant 0 (14 of the ~200 instructions of a Riccati stage).
@@ -183,6 +222,7 @@ struct mmpc_handle_s {
     int nx, nu, nref, lds_bytes;
     int fast;               // 1: specialised kernel exists for (kind, N, M)
     int fast_lds_bytes;
+    int gen_static;    // the shape has a static-LDS instantiation of the generic kernel (MMPC_STATIC_LIST)
     int per_cu, fast_per_cu;   // resident workgroups (= problems) per CU the runtime reports for the two kernels
     int diag;               // weights are diagonal (required by the specialised kernel)
     // one stream at a time: launches of a handle share device state (params, schedule hint, warm start), so work on a
@@ -324,6 +364,16 @@ extern "C" int mmpc_create(const mmpc_config *cfg, mmpc_handle *out) {
         HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&h->per_cu, mmpc_solve_kernel<1>, MMPC_WAVE, h->lds_bytes));
     else
         HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&h->per_cu, mmpc_solve_kernel<2>, MMPC_WAVE, h->lds_bytes));
+    h->gen_static = 0;
+    if (!getenv("MMPC_NO_STATIC_GENERIC")) {
+#define MMPC_X(K, NN, MM, OO, LL, AA)                                                                                \
+        if (cfg->kind == K && cfg->N == NN && cfg->M == MM && p.obs_per_stage == OO && cfg->L == LL && p.as_written == AA) {         \
+            h->gen_static = 1;                                                                                         \
+            HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&h->per_cu, mmpc_solve_kernel_static<K, NN, MM, OO, LL, AA>, MMPC_WAVE, 0)); \
+        }
+        MMPC_STATIC_LIST(MMPC_X)
+#undef MMPC_X
+    }
     h->fast = 0; h->fast_lds_bytes = 0; h->fast_per_cu = 0;
     {
 #define MMPC_X(K, NN, MM, WW)                                                                                        \
@@ -455,6 +505,13 @@ static int launch(mmpc_handle h, int B, const double *x_init, const double *traj
         MMPC_FAST_LIST(MMPC_X)
 #undef MMPC_X
 #undef MMPC_LAUNCH_FAST
+    } else if (h->gen_static) {
+#define MMPC_X(K, NN, MM, OO, LL, AA)                                                                                \
+        if (h->cfg.kind == K && h->cfg.N == NN && h->cfg.M == MM && h->hp.obs_per_stage == OO && h->cfg.L == LL && h->hp.as_written == AA) \
+            hipLaunchKernelGGL((mmpc_solve_kernel_static<K, NN, MM, OO, LL, AA>), dim3(B), dim3(MMPC_WAVE), 0, st, h->dp, B, x_init, traj, \
+                               uref, ulast, xguess, obs, X, U, s, status, iters, cost, err, order);
+        MMPC_STATIC_LIST(MMPC_X)
+#undef MMPC_X
     } else if (h->cfg.kind == MMPC_KIND_WHOLEBODY)
         hipLaunchKernelGGL(mmpc_solve_kernel<0>, dim3(B), dim3(MMPC_WAVE), h->lds_bytes, st, h->dp, B, x_init, traj, uref,
                            ulast, xguess, obs, X, U, s, status, iters, cost, err, order);
