@@ -23,7 +23,9 @@ def build_extension(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB] + \
+    # -amdgpu-mfma-vgpr-form: the Riccati tiles stay in VGPRs (the pivots are read back by VALU instructions after every
+    # rank-one MFMA; from AGPRs that is a v_accvgpr_read per word): +1.1 % on C4 and C5
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form", "-fPIC", "-shared", "-o", LIB] + \
           [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
