@@ -1330,7 +1330,10 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                         const double i1 = mmpc_rcp3(d1), co = MMPC_LANE_XOR16(rM[ra]);
                         const bool in1 = g == ga + 1;
                         own = g == ga || in1;
-                        cb = in1 ? fma(-l, co, c) : c;
+                        // (the exchanged value is used by EVERY lane, with a zero multiplier where it does not apply: written as
+                        //  in1 ? fma(-l, co, c) : c the compiler may sink the cross-lane operation under the lane-dependent branch,
+                        //  where it reads inactive lanes - seen with a four-input variant of this leg)
+                        cb = fma(in1 ? -l : 0.0, co, c);
                         w = cb * (in1 ? i1 : i0);
                     } else {
                         const double d = MMPC_LANE_GET(rM[ra], 16 * ga + ta);
