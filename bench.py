@@ -7,6 +7,8 @@ collective), followed by the one all-gather of the solved trajectories the metri
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import contextlib
+_nullcontext = contextlib.nullcontext   # (main() has a local `import contextlib` further down: nested functions use this name)
 import json
 import os
 import sys
@@ -54,6 +56,11 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=8192, help="instances timed on the host cores (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--seed-base", type=int, default=SEED_BASE, help="weak scaling: rank r solves the C4 seed SEED_BASE + r")
+    ap.add_argument("--budget", type=int, default=None,
+                    help="iterations per launch (mmpc_set_iteration_budget); instances that need more are finished by a continuation "
+                         "launch on a side stream while the next batches run (--handles handles in rotation).  Default: 0 (off) on one "
+                         "GPU - the headline -, 96 in multi-rank runs, where one rank's 450-iteration straggler would hold the job")
+    ap.add_argument("--handles", type=int, default=6, help="handles in rotation when --budget > 0")
     ap.add_argument("--gather", default="full", choices=["full", "u0"],
                     help="what the one all-gather of the path collects: the solved (X,U,s) records (310 doubles per instance) "
                          "or only the first inputs u0 the closed loop applies (5 doubles per instance, SURVEY 8e)")
@@ -119,37 +126,66 @@ def main():
     traj, uref, obs = t(d["traj_ref"]), t(d["u_ref"]), t(d["obs"])
     ulast = torch.zeros((Bl, N, nu), dtype=torch.float64, device=dev)   # cold start: u_latest = 0 (:298-299)
     out = eng.solve_batch_device(x_init, traj, uref, ulast, obs)
+    # Iteration budget + continuation (multi-rank default): a launch gives every instance at most `budget` iterations; the few
+    # that need more park their state and are finished by a continuation launch on a side stream while the next batches run.
+    # The handle's state (save area, launch lists) belongs to one batch in flight, so NH handles take turns; a handle's next
+    # launch is ordered after its continuation by the engine itself (event across streams).  Results are bitwise those of one
+    # uninterrupted solve.  A batch takes as long as its slowest instance - a 450-iteration straggler is 16 ms against 6.5 ms -
+    # but the throughput of a stream of batches no longer does.
+    budget = args.budget if args.budget is not None else (96 if world > 1 else 0)
+    NH = args.handles if budget > 0 else 1
+    engs, outs, sides = [eng], [out], [None]
+    if budget > 0:
+        for _ in range(NH - 1):
+            c_ = mm.MPCWholeBody(robot, [], [], N=N, max_batch=Bl, device=local_dev, n_obstacles=M)
+            c_._engine.set_schedule_hint(2)
+            engs.append(c_._engine); outs.append(None)
+        sides = [torch.cuda.Stream(device=dev) for _ in range(NH)]
+        for h in range(NH):
+            engs[h].set_iteration_budget(budget)
     packed = gathered = None
-    pending = [None, None]
+    pending = [None] * max(2, NH)
     rec = sharding.record_len(N, nx, nu) if args.gather == "full" else nu
     if world > 1:
-        packed = [torch.empty((Bl, rec), dtype=torch.float64, device=dev) for _ in range(2)]
-        gathered = [torch.empty((Bg, rec), dtype=torch.float64, device=dev) for _ in range(2)]
+        packed = [torch.empty((Bl, rec), dtype=torch.float64, device=dev) for _ in range(max(2, NH))]
+        gathered = [torch.empty((Bg, rec), dtype=torch.float64, device=dev) for _ in range(max(2, NH))]
 
-    def gather(i):
+    def solve_step(i):
+        # one pass of the hot path over the resident batch; returns the output set it writes and the stream its last launch is on
+        if budget == 0:
+            eng.solve_batch_device(x_init, traj, uref, ulast, obs, out=out)
+            return out, None
+        h = i % NH
+        outs[h] = engs[h].solve_batch_device(x_init, traj, uref, ulast, obs, out=outs[h])
+        engs[h].resume_batch_device(x_init, traj, uref, ulast, obs, outs[h], stream=sides[h].cuda_stream)
+        return outs[h], sides[h]
+
+    def gather(i, o, side):
         # the one collective of the path: all-gather of the solved (X,U,s) - or of u0 only - over xGMI (RCCL), inside the
-        # timed region.  Double-buffered and asynchronous: the gather of step i travels on RCCL's stream while step i+1 is
-        # solved; a buffer pair is reused only after its previous gather has completed, and drain() waits for the last ones.
-        b = i & 1
+        # timed region.  Multi-buffered and asynchronous: the gather of step i travels on RCCL's stream while step i+1 is
+        # solved; a buffer set is reused only after its previous gather has completed, and drain() waits for the last ones.
+        # With a continuation in flight the packing and the gather are issued on that continuation's stream (behind it).
+        b = i % len(pending)
         if pending[b] is not None:
             pending[b].wait()
             pending[b] = None
-        if args.gather == "full":
-            sharding.pack_solution(out["X"], out["U"], out["s"], out=packed[b])
-        else:
-            packed[b].copy_(out["U"][:, 0, :])
-        _, pending[b] = sharding.allgather_solutions(packed[b], Bg, dist, gathered=gathered[b], async_op=True)
+        with torch.cuda.stream(side) if side is not None else _nullcontext():
+            if args.gather == "full":
+                sharding.pack_solution(o["X"], o["U"], o["s"], out=packed[b])
+            else:
+                packed[b].copy_(o["U"][:, 0, :])
+            _, pending[b] = sharding.allgather_solutions(packed[b], Bg, dist, gathered=gathered[b], async_op=True)
 
     def drain():
-        for b in range(2):
+        for b in range(len(pending)):
             if pending[b] is not None:
                 pending[b].wait()
                 pending[b] = None
 
-    for i in range(args.warmup):
-        eng.solve_batch_device(x_init, traj, uref, ulast, obs, out=out)
+    for i in range(max(args.warmup, NH if budget > 0 else 0)):
+        o_, side_ = solve_step(i)
         if world > 1:
-            gather(i)
+            gather(i, o_, side_)
     if world > 1:
         drain()
     torch.cuda.synchronize()
@@ -160,13 +196,14 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         evs[i][0].record()
-        eng.solve_batch_device(x_init, traj, uref, ulast, obs, out=out)
+        o_, side_ = solve_step(i)
         evs[i][1].record()
         if world > 1:
-            gather(i)
+            gather(i, o_, side_)
     if world > 1:
         drain()
     torch.cuda.synchronize()
+    out = o_                                               # (every output set holds the same batch's solution)
     t_rank = time.perf_counter() - t0                      # this rank's own time for its K steps (before the barrier)
     if world > 1:
         dist.barrier()
@@ -228,7 +265,11 @@ def main():
                                    % (N, M, Bl, "" if args.scaling == "weak" else " [strong: global batch fixed]", Bg),
                        "batch_per_gpu": Bl,
                        "seeds": ([args.seed_base + r for r in range(world)] if args.scaling == "weak" else [args.seed_base]),
-                       "parallelism": "batch-sharded x%d%s" % (world, (" + all-gather(%s)" % ("X,U,s" if args.gather == "full" else "u0")) if world > 1 else "")},
+                       "parallelism": "batch-sharded x%d%s" % (world, (" + all-gather(%s)" % ("X,U,s" if args.gather == "full" else "u0")) if world > 1 else ""),
+                       "iteration_budget": budget,
+                       "iteration_budget_note": ("off" if budget == 0 else "at most %d iterations per launch; the instances that need more are "
+                                                 "finished by a continuation launch on a side stream while the next batches run (%d handles in "
+                                                 "rotation); same results as one uninterrupted solve" % (budget, NH))},
             "solver": {"converged_frac": n_conv / Bg, "mean_iters": mean_iters, "max_iters": it_max,
                        "max_scaled_kkt": err_max, "lds_bytes_per_problem": eng.lds_bytes, "problems_per_cu": eng.problems_per_cu},
             "median_kernel_ms": step_ms[len(step_ms) // 2],
