@@ -59,8 +59,9 @@ def main():
     ap.add_argument("--budget", type=int, default=None,
                     help="iterations per launch (mmpc_set_iteration_budget); instances that need more are finished by a continuation "
                          "launch on a side stream while the next batches run (--handles handles in rotation).  Default: 0 (off) on one "
-                         "GPU - the headline -, 96 in multi-rank runs, where one rank's 450-iteration straggler would hold the job")
-    ap.add_argument("--handles", type=int, default=6, help="handles in rotation when --budget > 0")
+                         "GPU - the headline -, 64 in multi-rank runs, where one rank's 450-iteration straggler would hold the job")
+    ap.add_argument("--handles", type=int, default=8, help="handles in rotation when --budget > 0")
+    ap.add_argument("--side-streams", type=int, default=6, help="streams the continuation launches rotate over when --budget > 0")
     ap.add_argument("--gather", default="full", choices=["full", "u0"],
                     help="what the one all-gather of the path collects: the solved (X,U,s) records (310 doubles per instance) "
                          "or only the first inputs u0 the closed loop applies (5 doubles per instance, SURVEY 8e)")
@@ -70,6 +71,13 @@ def main():
     args = ap.parse_args()
     if args.config == "c5":
         return main_c5(args)
+
+    # Pipelined continuation (see --budget): the launch stream plus the side streams of the continuations must not share a
+    # hardware queue - a queue runs its kernels one after the other, the next batch would wait behind a 20 ms continuation.
+    # ROCm's default is 4 queues per process; read at runtime initialisation, hence before torch is imported.
+    _budget = args.budget if args.budget is not None else (64 if int(os.environ.get("WORLD_SIZE", "1")) > 1 else 0)
+    if _budget > 0:
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
     import torch
     import mmpc_loader
@@ -132,7 +140,7 @@ def main():
     # launch is ordered after its continuation by the engine itself (event across streams).  Results are bitwise those of one
     # uninterrupted solve.  A batch takes as long as its slowest instance - a 450-iteration straggler is 16 ms against 6.5 ms -
     # but the throughput of a stream of batches no longer does.
-    budget = args.budget if args.budget is not None else (96 if world > 1 else 0)
+    budget = _budget
     NH = args.handles if budget > 0 else 1
     engs, outs, sides = [eng], [out], [None]
     if budget > 0:
@@ -140,7 +148,8 @@ def main():
             c_ = mm.MPCWholeBody(robot, [], [], N=N, max_batch=Bl, device=local_dev, n_obstacles=M)
             c_._engine.set_schedule_hint(2)
             engs.append(c_._engine); outs.append(None)
-        sides = [torch.cuda.Stream(device=dev) for _ in range(NH)]
+        # (fewer side streams than hardware queues, see GPU_MAX_HW_QUEUES above; continuations on one stream run one after the other)
+        sides = [torch.cuda.Stream(device=dev) for _ in range(min(NH, args.side_streams))]
         for h in range(NH):
             engs[h].set_iteration_budget(budget)
     packed = gathered = None
@@ -157,8 +166,9 @@ def main():
             return out, None
         h = i % NH
         outs[h] = engs[h].solve_batch_device(x_init, traj, uref, ulast, obs, out=outs[h])
-        engs[h].resume_batch_device(x_init, traj, uref, ulast, obs, outs[h], stream=sides[h].cuda_stream)
-        return outs[h], sides[h]
+        side = sides[i % len(sides)]
+        engs[h].resume_batch_device(x_init, traj, uref, ulast, obs, outs[h], stream=side.cuda_stream)
+        return outs[h], side
 
     def gather(i, o, side):
         # the one collective of the path: all-gather of the solved (X,U,s) - or of u0 only - over xGMI (RCCL), inside the

@@ -99,38 +99,45 @@ __global__ __launch_bounds__(MMPC_WAVE, WPE) void mmpc_fast_kernel(
     const int *__restrict__ order, int budget, double *__restrict__ state, int state_stride, const int *__restrict__ resume_count) {
     __shared__ double lds[mmpc_fast_layout<KIND, N>(MC, OPS).total];
     typedef MmpcDims<KIND> D;
-    if ((int)blockIdx.x >= B) return;
-    // a continuation launch: `order` is the compacted list of the suspended instances, *resume_count its length
-    if (resume_count && (int)blockIdx.x >= *resume_count) return;
-    // launch order: workgroup i solves instance order[i] (a permutation / a list; results do not depend on it)
-    const int b = order ? order[blockIdx.x] : (int)blockIdx.x;
-    const MmpcParams &P = *Pp;
-    const int M = MC;
-    const size_t so = (size_t)(P.obs_per_stage ? N + 1 : 1) * M * 3;
-    MmpcIO io;
-    io.x_init = x_init + (size_t)b * D::NX;
-    io.traj_ref = traj_ref + (size_t)b * (N + 1) * D::NX;
-    io.u_ref = u_ref + (size_t)b * N * D::NU;
-    io.u_last = u_last + (size_t)b * N * D::NU;
-    io.x_guess = x_guess ? x_guess + (size_t)b * (N + 1) * D::NX : nullptr;
-    io.u_guess = P.u_guess ? P.u_guess + (size_t)b * N * D::NU : nullptr;
-    io.obs = obs + (size_t)b * so;
-    io.X = X + (size_t)b * (N + 1) * D::NX;
-    io.U = U + (size_t)b * N * D::NU;
-    io.s = s + (size_t)b * (N + 1);
-    io.status = status + b;
-    io.iters = iters + b;
-    io.cost = cost + b;
-    io.err = err + b;
-    io.state = state ? state + (size_t)b * state_stride : nullptr;
-    io.budget = budget;
-    io.resume = resume_count ? 1 : 0;
-    mmpc_solve_fast<KIND, N, MC, CONT, OPS>(P, io, lds);
+    // A continuation launch (resume_count != null): `order` is the compacted list of the suspended instances, *resume_count its
+    // length, and the grid is SMALL (MMPC_RESUME_GRID workgroups that stride over the list): a handful of instances is left,
+    // and a grid of B workgroups that almost all exit at once would still have to be dispatched one by one - in a stream of
+    // batches that competes with the next batch's launch.
+    const int limit = resume_count ? *resume_count : B;
+    for (int w = (int)blockIdx.x; w < limit; w += (int)gridDim.x) {
+        // launch order: workgroup i solves instance order[i] (a permutation / a list; results do not depend on it)
+        const int b = order ? order[w] : w;
+        const MmpcParams &P = *Pp;
+        const int M = MC;
+        const size_t so = (size_t)(P.obs_per_stage ? N + 1 : 1) * M * 3;
+        MmpcIO io;
+        io.x_init = x_init + (size_t)b * D::NX;
+        io.traj_ref = traj_ref + (size_t)b * (N + 1) * D::NX;
+        io.u_ref = u_ref + (size_t)b * N * D::NU;
+        io.u_last = u_last + (size_t)b * N * D::NU;
+        io.x_guess = x_guess ? x_guess + (size_t)b * (N + 1) * D::NX : nullptr;
+        io.u_guess = P.u_guess ? P.u_guess + (size_t)b * N * D::NU : nullptr;
+        io.obs = obs + (size_t)b * so;
+        io.X = X + (size_t)b * (N + 1) * D::NX;
+        io.U = U + (size_t)b * N * D::NU;
+        io.s = s + (size_t)b * (N + 1);
+        io.status = status + b;
+        io.iters = iters + b;
+        io.cost = cost + b;
+        io.err = err + b;
+        io.state = state ? state + (size_t)b * state_stride : nullptr;
+        io.budget = budget;
+        io.resume = resume_count ? 1 : 0;
+        mmpc_solve_fast<KIND, N, MC, CONT, OPS>(P, io, lds);
+        if (!CONT || !resume_count) break;      // (one instance per workgroup except in a continuation launch)
+        __builtin_amdgcn_s_barrier();           // the next instance reuses the LDS block
+    }
 }
 
 // (kind, N, M) triples with a specialised kernel; everything else runs the generic kernel.
 // BASELINE configs C3/C4 (0,20,5), C5 (0,30,8), C2 (1,15,3); the reference demo (0,20,3).
 // The base-only kernel needs 16 KB of LDS per problem (9 problems/CU): it is built for 2 waves/SIMD (+21 % measured).
+#define MMPC_RESUME_GRID 256   // workgroups of a continuation launch (they stride over the list of suspended instances)
 #define MMPC_FAST_LIST(X) X(0, 20, 5, 1) X(0, 30, 8, 1) X(0, 20, 3, 1) X(1, 15, 3, 2)
 
 // Longest-processing-time-first order for the NEXT launch: instances sorted by descending iteration count of
@@ -491,7 +498,7 @@ static int launch(mmpc_handle h, int B, const double *x_init, const double *traj
     if (use_fast) {
 #define MMPC_LAUNCH_FAST(K, NN, MM, WW, OPS)                                                                              \
             if (resume || h->budget > 0)                                                                                               \
-                hipLaunchKernelGGL((mmpc_fast_kernel<K, NN, MM, WW, true, OPS>), dim3(B), dim3(MMPC_WAVE), 0, st, h->dp, B,               \
+                hipLaunchKernelGGL((mmpc_fast_kernel<K, NN, MM, WW, true, OPS>), dim3(resume ? (B < MMPC_RESUME_GRID ? B : MMPC_RESUME_GRID) : B), dim3(MMPC_WAVE), 0, st, h->dp, B, \
                                    x_init, traj, uref, ulast, xguess, obs, X, U, s, status, iters, cost, err, resume ? h->d_list : order, \
                                    resume ? 0 : h->budget, h->d_state, h->state_doubles, resume ? h->d_count : (const int *)nullptr);   \
             else                                                                                                                       \

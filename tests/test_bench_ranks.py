@@ -46,7 +46,7 @@ def test_two_rank_bench_line():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 3 and d["unit"] == "solves/s"
     assert d["config"]["seeds"] == [3, 4] and d["config"]["batch_per_gpu"] == 1024      # consecutive seeds, nothing filtered
-    assert d["config"]["iteration_budget"] == 96                                         # multi-rank default: budget + pipelined continuation
+    assert d["config"]["iteration_budget"] == 64                                         # multi-rank default: budget + pipelined continuation
     assert len(d["per_rank"]) == 2 and all(p["converged"] == 1024 for p in d["per_rank"]) and "no schedule hint from earlier solves" in d["config"]["workload"]
     assert d["solver"]["converged_frac"] == 1.0 and d["solver"]["max_scaled_kkt"] <= 1e-8
     assert d["value"] > 0 and abs(d["value"] - 2 * 1024 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
