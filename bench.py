@@ -76,8 +76,7 @@ def main():
     # hardware queue - a queue runs its kernels one after the other, the next batch would wait behind a 20 ms continuation.
     # ROCm's default is 4 queues per process; read at runtime initialisation, hence before torch is imported.
     _budget = args.budget if args.budget is not None else (64 if int(os.environ.get("WORLD_SIZE", "1")) > 1 else 0)
-    if _budget > 0:
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")       # (also for the one-GPU run: its extras time the same pattern)
 
     import torch
     import mmpc_loader
@@ -418,10 +417,60 @@ def main():
                                       "max_iters": int(out4["iters"].max()), "converged_frac": float((out4["status"] == 0).double().mean()),
                                       "note": "one launch of 32768 instances (seeds %d..%d), a-priori order" % (args.seed_base, args.seed_base + 3)}
                 del ctrl4, out4, x4, t4, u4, o4, ul4
+                # (6) a stream of DIFFERENT batches, some of which hold a straggler (seeds s..s+7: what the ranks of an 8-GPU run
+                # hold; slowest instances 84, 66, 72, 146, 238, 456, 88, 68 iterations): one after the other, and with an
+                # iteration budget of 64 + continuation launches on side streams while the next batches run
+                try:
+                    res["stream_of_batches"] = stream_of_batches_extra(mm, robot, dev, local_dev, args.seed_base, N, M, Bl, nu, ctrl.xlim)
+                except Exception as e:
+                    res["stream_of_batches"] = {"error": repr(e)}
             res["cpu_baseline"] = cpu_baseline(d, N, M, min(args.cpu_sample, Bl), out["X"])
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
+
+
+def stream_of_batches_extra(mm, robot, dev, local_dev, seed0, N, M, B, nu, xlim, nseeds=8, rounds=5, budget=64, nh=8, nside=6):
+    """Eight different seeded batches solved in a stream, `rounds` times over: plain (one launch per batch, a-priori order) and
+    with the iteration budget + pipelined continuation (as the multi-rank runs use it).  Every output is checked for status 0."""
+    import torch
+    from oracle import synth
+    data = []
+    for q in range(nseeds):
+        d = synth.make_batch(B, N=N, M=M, config_id=seed0 + q)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        data.append((t(np.clip(d["x_init"], xlim[0], xlim[1])), t(d["traj_ref"]), t(d["u_ref"]), t(d["obs"])))
+    ul = torch.zeros((B, N, nu), dtype=torch.float64, device=dev)
+    ctrls = [mm.MPCWholeBody(robot, [], [], N=N, max_batch=B, device=local_dev, n_obstacles=M) for _ in range(nh)]
+    engs = [c._engine for c in ctrls]
+    for e in engs:
+        e.set_schedule_hint(2)
+    outs = [None] * nh
+    sides = [torch.cuda.Stream(device=dev) for _ in range(nside)]
+    res = {"seeds": [seed0 + q for q in range(nseeds)], "batches": nseeds * rounds, "unit": "ms per batch", "iteration_budget": budget,
+           "note": "plain: one launch per batch; pipelined: at most %d iterations per launch, the rest by continuation launches on side "
+                   "streams while the next batches run (%d handles, %d side streams); same results" % (budget, nh, nside)}
+    for mode in ("plain", "pipelined"):
+        for e in engs:
+            e.set_iteration_budget(budget if mode == "pipelined" else 0)
+        for rep in range(2):                                  # first pass: warm-up
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            bad = 0
+            for i in range(nseeds * rounds):
+                x, tr, ur, ob = data[i % nseeds]
+                h = i % nh
+                if mode == "plain":
+                    outs[h] = engs[h].solve_batch_device(x, tr, ur, ul, ob, out=outs[h])
+                else:
+                    outs[h] = engs[h].solve_batch_device(x, tr, ur, ul, ob, out=outs[h])
+                    engs[h].resume_batch_device(x, tr, ur, ul, ob, outs[h], stream=sides[i % nside].cuda_stream)
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+        conv = min(float((o["status"] == 0).double().mean()) for o in outs if o is not None)
+        res[mode] = {"ms_per_batch": 1e3 * el / (nseeds * rounds), "value": B * nseeds * rounds / el, "converged_frac_min": conv}
+    for e in engs:
+        e.set_iteration_budget(0)
+    return res
 
 
 def c1_shape_extra(mm, robot, dev, B=2048, N=20):
