@@ -1380,22 +1380,44 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
         // ---- gains of all stages from the normalised pivot rows, by back-substitution over the inputs (the last eliminated
         //      input depends on x only): K_a = -(w_a[x,1] + sum_{b>a} w_a[u_b] K_b), in place, one lane per (stage, column)
         LANES_BEGIN
-        for (int i = lane; i < N * (NX + 1); i += MMPC_WAVE) {
-            const int k = i / (NX + 1), j = i % (NX + 1);
-            double kv[NU], cu[NPU > 0 ? NPU : 1];
+        {
+            // two (stage, column) items per lane at a time, the loads of both ahead of the arithmetic: the update is in place, so the
+            // compiler cannot move the loads of one item above the stores of the one before
+            constexpr int NITEM = N * (NX + 1), NTRIP = (NITEM + MMPC_WAVE - 1) / MMPC_WAVE;
 #pragma unroll
-            for (int a = 0; a < NU; a++) kv[a] = j < NX ? KK[(k * NU + a) * NX + j] : KF[k * NU + a];
+            for (int t0 = 0; t0 < NTRIP; t0 += 2) {
+                double kv[2][NU], cu[2][NPU > 0 ? NPU : 1];
+                int kk[2], jj[2];
+                bool ok[2];
 #pragma unroll
-            for (int q = 0; q < NPU; q++) cu[q] = KU[k * NPU + q];
+                for (int u = 0; u < 2; u++) {
+                    const int i = lane + MMPC_WAVE * (t0 + u);
+                    ok[u] = t0 + u < NTRIP && i < NITEM;
+                    const int ii = ok[u] ? i : 0;
+                    kk[u] = ii / (NX + 1); jj[u] = ii % (NX + 1);
 #pragma unroll
-            for (int a = NU - 1; a >= 0; a--) {
-                double v = kv[a];
+                    for (int a = 0; a < NU; a++) kv[u][a] = jj[u] < NX ? KK[(kk[u] * NU + a) * NX + jj[u]] : KF[kk[u] * NU + a];
 #pragma unroll
-                for (int b2 = a + 1; b2 < NU; b2++) v += cu[a * (2 * NU - a - 1) / 2 + (b2 - a - 1)] * kv[b2];
-                kv[a] = -v;
+                    for (int q = 0; q < NPU; q++) cu[u][q] = KU[kk[u] * NPU + q];
+                }
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+#pragma unroll
+                    for (int a = NU - 1; a >= 0; a--) {
+                        double v = kv[u][a];
+#pragma unroll
+                        for (int b2 = a + 1; b2 < NU; b2++) v += cu[u][a * (2 * NU - a - 1) / 2 + (b2 - a - 1)] * kv[u][b2];
+                        kv[u][a] = -v;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    if (ok[u]) {
+#pragma unroll
+                        for (int a = 0; a < NU; a++) { if (jj[u] < NX) KK[(kk[u] * NU + a) * NX + jj[u]] = kv[u][a]; else KF[kk[u] * NU + a] = kv[u][a]; }
+                    }
+                }
             }
-#pragma unroll
-            for (int a = 0; a < NU; a++) { if (j < NX) KK[(k * NU + a) * NX + j] = kv[a]; else KF[k * NU + a] = kv[a]; }
         }
         LANES_END
         MMPC_TS(8)
