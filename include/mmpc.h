@@ -152,7 +152,10 @@ int mmpc_set_schedule_hint(mmpc_handle h, int mode);
  * launch it continues, any stream - runs the suspended instances to the end (no budget) with one workgroup each;
  * the other instances' outputs are not touched.  A resumed solve executes exactly the iterations the uninterrupted one
  * would have: results are bitwise identical.  mmpc_suspended_count waits for the handle's launches and returns how many
- * instances the last budgeted launch left suspended.  budget = 0 (default) switches the feature off. */
+ * instances the last budgeted launch left suspended.  budget = 0 (default) switches the feature off.
+ * A continuation belongs to the budgeted launch directly before it on the handle (same B): after any other launch, a first
+ * continuation, mmpc_reset or a change of the budget the save areas are stale and mmpc_resume_batch_device returns
+ * MMPC_E_UNSUPPORTED instead of overwriting results with the continuation of an older problem. */
 int mmpc_set_iteration_budget(mmpc_handle h, int budget);
 int mmpc_resume_batch_device(mmpc_handle h, int B, const double *d_x_init, const double *d_traj_ref, const double *d_u_ref,
                              const double *d_u_last, const double *d_x_guess, const double *d_obs, double *d_X, double *d_U,

@@ -244,6 +244,7 @@ struct mmpc_handle_s {
     int state_doubles;      // save area per instance
     double *d_state;        // [max_batch][state_doubles], allocated when a budget is first set
     int *d_list, *d_count;  // compacted list of the suspended instances of the last launch
+    int resume_B;           // batch size of the budgeted launch whose suspended instances can still be continued (0: nothing to resume)
     int no_lpt_env, force_generic_env;   // MMPC_NO_LPT / MMPC_FORCE_GENERIC, read once at create (diagnostics)
     int *d_warm;            // per instance: 1 once a CONVERGED solve has filled its u_latest / x_guess rows
     // device-side state and staging (capacity max_batch)
@@ -474,6 +475,7 @@ extern "C" int mmpc_reset(mmpc_handle h) {
     HIPCHK(h, hipMemset(h->d_ulatest, 0, n));
     HIPCHK(h, hipMemset(h->d_warm, 0, (size_t)h->cfg.max_batch * 4));
     h->order_B = 0;
+    h->resume_B = 0;
     return MMPC_OK;
 }
 
@@ -484,7 +486,11 @@ static int launch(mmpc_handle h, int B, const double *x_init, const double *traj
     // a launch on another stream than the previous one waits for it: both touch the handle's schedule hint
     if (h->ev_valid && st != h->last_stream) HIPCHK(h, hipStreamWaitEvent(st, h->ev, 0));
     const bool use_fast = h->fast && h->diag && !h->hp.terminal_xy_eq && !h->force_generic_env;
-    if (resume && !(use_fast && h->d_state)) return fail(h, MMPC_E_UNSUPPORTED, "%s%s", "nothing to resume: no budgeted launch of a specialised kernel precedes");
+    // a continuation belongs to the budgeted launch right before it (same B, same buffers): anything in between - another
+    // launch, a reset, a change of the budget, a first continuation - leaves the save areas and the list stale
+    if (resume && !(use_fast && h->d_state && h->resume_B == B))
+        return fail(h, MMPC_E_UNSUPPORTED, "%s%s", "nothing to resume: the handle's last launch was not a budgeted launch of this batch size on a specialised kernel");
+    h->resume_B = 0;
     // launch order of the workgroups (results do not depend on it): the iteration counts of the handle's previous launch of
     // this batch size when there are any and the mode allows them, else the a-priori difficulty key of THIS batch's data
     const bool lpt = !resume && h->hint_on && !h->no_lpt_env && B <= h->cfg.max_batch && B > 256;
@@ -533,6 +539,7 @@ static int launch(mmpc_handle h, int B, const double *x_init, const double *traj
         // who is suspended: compacted list for mmpc_resume_batch_device
         HIPCHK(h, hipMemsetAsync(h->d_count, 0, 4, st));
         hipLaunchKernelGGL(mmpc_collect_suspended, dim3((B + 255) / 256), dim3(256), 0, st, B, status, h->d_list, h->d_count);
+        h->resume_B = B;
     }
     if (lpt && h->hint_on == 1) {
         hipLaunchKernelGGL(mmpc_lpt_order, dim3(1), dim3(1024), 0, st, B, iters, h->d_order);
@@ -557,6 +564,7 @@ extern "C" int mmpc_set_iteration_budget(mmpc_handle h, int budget) {
     }
     if (h->ev_valid) HIPCHK(h, hipEventSynchronize(h->ev));
     h->budget = budget;
+    h->resume_B = 0;
     return MMPC_OK;
 }
 
@@ -604,9 +612,11 @@ extern "C" int mmpc_solve_batch_device(mmpc_handle h, int B, const double *d_x_i
                                        const double *d_obs, double *d_X, double *d_U, double *d_s, int *d_status,
                                        int *d_iters, double *d_cost, double *d_err, void *stream) {
     if (h && B == 0) return MMPC_OK;   // an empty batch (e.g. the shard of a rank beyond the batch) is a no-op
-    if (!h || B < 1 || !d_x_init || !d_traj_ref || !d_u_ref || !d_u_last || !d_X || !d_U || !d_s || !d_status ||
+    // B > max_batch: the handle's per-instance buffers (launch order, difficulty keys, save areas of suspended solves, list of
+    // the suspended, the opt-in U guess) are sized for max_batch instances
+    if (!h || B < 1 || B > h->cfg.max_batch || !d_x_init || !d_traj_ref || !d_u_ref || !d_u_last || !d_X || !d_U || !d_s || !d_status ||
         !d_iters || !d_cost || !d_err || (h->cfg.M > 0 && !d_obs))
-        return fail(h, MMPC_E_ARG, "mmpc_solve_batch_device: %s%s", "bad argument");
+        return fail(h, MMPC_E_ARG, "mmpc_solve_batch_device: %s%s", "bad argument (B must be in 1..max_batch)");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     return launch(h, B, d_x_init, d_traj_ref, d_u_ref, d_u_last, d_x_guess, d_obs ? d_obs : h->d_obs, d_X, d_U, d_s,
                   d_status, d_iters, d_cost, d_err, (hipStream_t)stream);

@@ -353,6 +353,43 @@ def test_iteration_budget_and_continuation(mm):
         mm.MPCWholeBody(mm.MobileManipulator(0.1), [], [], N=12, max_batch=4, n_obstacles=2)._engine.set_iteration_budget(8)   # generic kernel
 
 
+def test_device_pointer_calls_reject_oversized_and_stale(mm):
+    """include/mmpc.h: B > max_batch is MMPC_E_ARG for the device-pointer calls too (the handle's launch order, difficulty keys,
+    save areas and suspended list are sized for max_batch: with a budget set an oversized launch would write past them), and a
+    continuation is only valid directly after the budgeted launch it continues (same B)."""
+    import torch
+    B, N, M = 512, 20, 5
+    d = synth.make_batch(B + 1)
+    par = nlp.WholeBodyParams()
+    ctrl = _wb(mm, N, M, B)
+    eng = ctrl._engine
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    xi, tr, ur, ob = t(np.clip(d["x_init"], par.xlim[0], par.xlim[1])), t(d["traj_ref"]), t(d["u_ref"]), t(d["obs"])
+    ul = torch.zeros((B + 1, N, 5), dtype=torch.float64, device=dev)
+    for budget in (0, 8):
+        eng.set_iteration_budget(budget)
+        with pytest.raises(RuntimeError, match="max_batch"):
+            eng.solve_batch_device(xi, tr, ur, ul, ob)
+    # budget 8 is still set: a launch of B instances, then its continuation
+    out = eng.solve_batch_device(xi[:B], tr[:B], ur[:B], ul[:B], ob[:B])
+    torch.cuda.synchronize()
+    n_susp = eng.suspended_count()
+    assert 0 < n_susp <= B
+    with pytest.raises(RuntimeError, match="resume"):      # another batch size than the launch it would continue
+        eng.resume_batch_device(xi[:B // 2], tr[:B // 2], ur[:B // 2], ul[:B // 2], ob[:B // 2], out={k: v[:B // 2] for k, v in out.items()})
+    out = eng.solve_batch_device(xi[:B], tr[:B], ur[:B], ul[:B], ob[:B])
+    eng.resume_batch_device(xi[:B], tr[:B], ur[:B], ul[:B], ob[:B], out=out)
+    torch.cuda.synchronize()
+    assert bool((out["status"] == 0).all())
+    with pytest.raises(RuntimeError, match="resume"):      # a second continuation of the same launch
+        eng.resume_batch_device(xi[:B], tr[:B], ur[:B], ul[:B], ob[:B], out=out)
+    out = eng.solve_batch_device(xi[:B], tr[:B], ur[:B], ul[:B], ob[:B])
+    eng.set_iteration_budget(0)
+    with pytest.raises(RuntimeError, match="resume"):      # the budget changed in between
+        eng.resume_batch_device(xi[:B], tr[:B], ur[:B], ul[:B], ob[:B], out=out)
+
+
 @pytest.mark.parametrize("nplanes", [2, 3])
 def test_as_written_halfspace_rows_batch(mm, nplanes):
     """64 starts around the demo's 'tent', half-space rows AS WRITTEN (quirk Q8, mmpc_config.as_written; L = 2: the if_else
