@@ -476,17 +476,8 @@ def stream_of_batches_extra(mm, robot, dev, local_dev, seed0, N, M, B, nu, xlim,
 def c1_shape_extra(mm, robot, dev, B=2048, N=20):
     """Generic kernel on the demo's shape (starts as in tests/test_gpu_certificates.py::test_as_written_halfspace_rows_batch)."""
     import torch
-    r2 = 1 / np.sqrt(2)
-    hs = np.array([[2.5, 2, 0.35 + 0.606 + 0.333, r2, 0, r2], [2.5, 2, 0.35 + 0.606 + 0.333, -r2, 0, r2]])
-    rng = np.random.default_rng(11)
-    x = np.zeros((B, 9)); tr = np.zeros((B, N + 1, 9))
-    for b in range(B):
-        x0 = np.array([rng.uniform(1.4, 2.6), rng.uniform(1.6, 2.4), rng.uniform(-0.4, 0.4), rng.uniform(0, 0.8), 0, 0,
-                       rng.uniform(-0.3, 0.6), rng.uniform(-1.6, -0.6), rng.uniform(0.8, 2.2)])
-        x0[4] = x0[3] * np.sin(x0[2]); x0[3] = x0[3] * np.cos(x0[2])
-        tg = x0.copy(); tg[0] += rng.uniform(0.8, 1.8); tg[1] += rng.uniform(-0.3, 0.3); tg[3:6] = 0
-        x[b] = x0; tr[b] = np.linspace(x0, tg, 51)[:N + 1]
-    obs = np.broadcast_to(np.array([[2.5, 3.4, 0.3], [2.5, 0.6, 0.3], [6, 6, 0.1]]), (B, 3, 3)).copy()
+    from oracle import synth
+    x, tr, obs, hs = synth.make_c1_starts(B, N)
     oml = [(h[:3], h[3:].reshape(1, 3)) for h in hs]
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     xi, trd, ob = t(x), t(tr), t(obs)

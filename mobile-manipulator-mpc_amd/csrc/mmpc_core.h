@@ -159,11 +159,12 @@ struct MmpcDims {
 #define MMPC_W_ULIM 255  // [2][5]
 #define MMPC_W_DULIM 265 // [2][5]
 #define MMPC_W_SIZE 276
+#define MMPC_NBC 3   // border columns: terminal multipliers nu0, nu1 and the slack s_{N-1} of the NLP as written (see A2)
 // LDS slab layout (offsets in doubles).  Shared by host (size query) and device.
 struct MmpcLayout {
     int X, U, S, LAM, XREF, UREF, ULAST, OBS, T, Z, HR, DTR, GC, HC, GSF, CV, CD, GX, GU, HXX, QX, HUXL, HUUL,
         HUX02, HUUD, QU, HSS, GSS, VX, VXN, KK, KF, DX, DU, DS, DLAM, PF, TT, PC, MF, MG, MH, MGX, MGU, RED, FILT,
-        MISC, PNU, PNUS, KFV, GNU, FWV, NUEQ, GHS, WTS, GQ8, BQ8, VQ, RQ, HQX, QQX, HUXS, HUUS, RDX, total;
+        MISC, PNU, PNUS, KFV, GNU, FWV, NUEQ, GHS, WTS, GQ8, BQ8, VQ, RQ, HQX, QQX, HUXS, HUUS, RDX, SIGW, total;
     int R, NR;
 };
 
@@ -191,9 +192,10 @@ MMPC_HD constexpr MmpcLayout mmpc_layout(int N, int M, int obs_per_stage, int nh
     MMPC_CARVE(PF, D::NX * D::NX) MMPC_CARVE(TT, D::NX * D::NV) MMPC_CARVE(PC, D::NX) MMPC_CARVE(MF, D::NXX)
     MMPC_CARVE(MG, D::NU * D::NX) MMPC_CARVE(MH, D::NUU) MMPC_CARVE(MGX, D::NX) MMPC_CARVE(MGU, D::NU)
     MMPC_CARVE(RED, 8 * MMPC_WAVE) MMPC_CARVE(FILT, 2 * MMPC_FCAP) MMPC_CARVE(MISC, 8)
-    // terminal xy equality (interface_wholebody_qref.py:166-167): multiplier sensitivities
-    MMPC_CARVE(PNU, D::NX * 2) MMPC_CARVE(PNUS, NS * D::NX * 2) MMPC_CARVE(KFV, N * D::NU * 2) MMPC_CARVE(GNU, D::NV * 2)
-    MMPC_CARVE(FWV, 2 * 3 * D::NX) MMPC_CARVE(NUEQ, 4) MMPC_CARVE(GHS, NS * nhs * 6) MMPC_CARVE(WTS, MMPC_W_SIZE)
+    // border variables of the stage-wise system (MMPC_NBC columns): the two multipliers of the terminal xy equality
+    // (interface_wholebody_qref.py:166-167) and the slack s_{N-1} when it reaches back to x_{N-2} (NLP as written): sensitivities
+    MMPC_CARVE(PNU, D::NX * MMPC_NBC) MMPC_CARVE(PNUS, NS * D::NX * MMPC_NBC) MMPC_CARVE(KFV, N * D::NU * MMPC_NBC) MMPC_CARVE(GNU, D::NV * MMPC_NBC)
+    MMPC_CARVE(FWV, 2 * (1 + MMPC_NBC) * D::NX) MMPC_CARVE(NUEQ, 4) MMPC_CARVE(GHS, NS * nhs * 6) MMPC_CARVE(WTS, MMPC_W_SIZE) MMPC_CARVE(SIGW, 16)
     // as-written rows: gradient / branch per row; per stage: coupling of s_k to x_{k-1}, what stage k's rows add to stage k-1
     // (residual, Hessian y-block, gradient), dense blocks of a slack eliminated one stage earlier, x-stationarity residual
     MMPC_CARVE(GQ8, NS * nq * 6) MMPC_CARVE(BQ8, NS * nq) MMPC_CARVE(VQ, nq ? NS * 6 : 0) MMPC_CARVE(RQ, nq ? (NS + 1) * 6 : 0)
@@ -471,7 +473,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
            *DS = lds + L.DS, *DLAM = lds + L.DLAM, *PF = lds + L.PF, *TT = lds + L.TT, *PC = lds + L.PC,
            *MF = lds + L.MF, *MG = lds + L.MG, *MH = lds + L.MH, *MGX = lds + L.MGX, *MGU = lds + L.MGU,
            *RED = lds + L.RED, *FILT = lds + L.FILT, *MISC = lds + L.MISC, *PNU = lds + L.PNU, *PNUS = lds + L.PNUS,
-           *KFV = lds + L.KFV, *GNU = lds + L.GNU, *FWV = lds + L.FWV, *NUEQ = lds + L.NUEQ, *GHS = lds + L.GHS;
+           *KFV = lds + L.KFV, *GNU = lds + L.GNU, *FWV = lds + L.FWV, *NUEQ = lds + L.NUEQ, *GHS = lds + L.GHS, *SIGW = lds + L.SIGW;
     double *const WTS = lds + L.WTS;
     double *const GQ8 = lds + L.GQ8, *const BQ8 = lds + L.BQ8, *const VQ = lds + L.VQ, *const RQ = lds + L.RQ, *const HQX = lds + L.HQX,
            *const QQX = lds + L.QQX, *const HUXS = lds + L.HUXS, *const HUUS = lds + L.HUUS, *const RDX = lds + L.RDX;
@@ -545,6 +547,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
     }
     for (int i = lane; i < NS; i += MMPC_WAVE) S[i] = 0.0;  // :304
     if (lane < 4) NUEQ[lane] = 0.0;
+    if (lane < 16) SIGW[lane] = 0.0;
     for (int i = lane; i < (OPS ? NS : 1) * M * 3; i += MMPC_WAVE) OBS[i] = io.obs[i];
     LANES_END
     // bound push of the initial point (needs U_last of the previous phase for the merged input box)
@@ -965,6 +968,16 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
             // ---- A2: Schur complement of s_k (H_xs = -v); stage N-1 also carries the terminal
             //          self rows (Q1): a = v + A^T vN, b = B^T vN, gamma = g_s - vN.c
             LANES_BEGIN
+            // s_{N-1} reaching back to x_{N-2} touches three stages (x_{N-2}, x_{N-1} and - quirk Q1 - x_N): no stage-wise
+            // elimination of it is exact.  It then stays a BORDER variable sigma of the stage-wise system,
+            //   [K -v~; -v~^T h] [d; dsigma] = -[q; g_s],   v~ = (vq on x_{N-2}, v on x_{N-1}, vN on x_N),
+            // solved with one more right-hand side through the same recursion (column 2 of PNU / GNU / KFV, beside the two
+            // multipliers of the terminal equality) and a scalar pivot h - v~.K^{-1} v~.  (Round 2 kept the diagonal block of x_{N-2}
+            // only - an inexact Newton matrix in that corner: 2 % of 2048 starts around the demo's planes stalled at a dual
+            // residual of 1e-2 .. 1e-6 until the iteration cap, the others needed 82 iterations on average instead of 30.)
+            bool sig = false;
+            if (NQ && N >= 2) for (int a = 0; a < 6; a++) sig = sig || VQ[(N - 1) * 6 + a] != 0.0;
+            if (lane == 0) SIGW[0] = sig ? 1.0 : 0.0;
             for (int k = lane; k < NS; k += MMPC_WAVE) {
                 double *hxx = HXX + k * NXX, *qx = QX + k * NX;
                 bool back_self = false;   // s_k reaches back to x_{k-1}: eliminated at stage k-1, not here
@@ -1004,19 +1017,14 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                             QU[k * NU + c] += b[c] * gam * ih;
                         }
                     }
-                    if (k == N - 2 && N >= 2) {
-                        // s_{N-1} touches x_{N-2}, x_{N-1} and (quirk Q1) x_N: its reach-back part keeps the diagonal block and the
-                        // gradient on x_{N-2} only - an inexact Newton matrix in that corner, the residuals stay exact
-                        const double ih = 1.0 / (MISC[4] + (NSELF ? MISC[2] : 0.0)), g1 = MISC[5] + (NSELF ? MISC[3] : 0.0);
-                        for (int a = 0; a < 6; a++) {
-                            const int ia = kY[a];
-                            for (int b = 0; b <= a; b++) hxx[ia * (ia + 1) / 2 + kY[b]] -= VQ[(N - 1) * 6 + a] * VQ[(N - 1) * 6 + b] * ih;
-                            qx[ia] += VQ[(N - 1) * 6 + a] * g1 * ih;
-                        }
-                    }
                 }
                 if (back_self) {
                     // (nothing: the slack of this stage has been eliminated by the lane of stage k-1 above)
+                } else if (k == N - 1 && NSELF && sig) {
+                    // border variable: totals of its row block for the border solve and D1, no Schur complement
+                    HSS[k] = HSS[k] + MISC[2]; GSS[k] = GSS[k] + MISC[3];
+                    for (int c = 0; c < NU * NX; c++) HUXL[c] = 0.0;
+                    for (int c = 0; c < NUU; c++) HUUL[c] = 0.0;
                 } else if (k == N - 1 && NSELF) {
                     const double hss = HSS[k] + MISC[2];
                     double gam = GSS[k] + MISC[3];
@@ -1058,15 +1066,23 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
             // phase, so the unpack happens in R0 below)
             LANES_END
             // ---- R0: full copy of P_N
+            const bool sig = NQ && SIGW[0] != 0.0;       // (uniform; written by A2)
+            const bool brd = teq || sig;                  // border columns in play
+            // y-entry of a state index (x, y, psi, q1, q2, q3 <-> 0..5), -1: none
+            auto yix = [&](int i) -> int { return i < 3 ? i : (i >= NX - 3 ? i - (NX - 6) : -1); };
             LANES_BEGIN
             for (int e = lane; e < NX * NX; e += MMPC_WAVE) {
                 const int i = e / NX, j = e % NX;
                 PF[e] = HXX[N * NXX + (i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i)] + ((teq && i == j && i < 2) ? MMPC_RHO_EQ : 0.0);
             }
-            if (teq && lane < NX * 2) {   // p^nu_N = E^T, E = [I2 0]
-                const double v = (lane / 2 == lane % 2) ? 1.0 : 0.0;
-                PNU[lane] = v; PNUS[N * NX * 2 + lane] = v;
-            }
+            if (brd)
+                for (int e = lane; e < NX * MMPC_NBC; e += MMPC_WAVE) {   // p_N of the border columns: E^T (E = [I2 0]) and -vN
+                    const int i = e / MMPC_NBC, c = e % MMPC_NBC;
+                    double v = 0.0;
+                    if (c < 2) v = (teq && i == c) ? 1.0 : 0.0;
+                    else if (sig && yix(i) >= 0) v = -VXN[yix(i)];
+                    PNU[e] = v; PNUS[N * NX * MMPC_NBC + e] = v;
+                }
             LANES_END
             // ---- Riccati recursion (block LDL^T of the stage-wise KKT matrix)
             for (int k = N - 1; k >= 0; k--) {
@@ -1113,18 +1129,22 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                         if (j < NX) MGX[j] = v; else MGU[j - NX] = v;
                     }
                 }
-                if (teq)
-                    for (int e = lane; e < NV * 2; e += MMPC_WAVE) {   // g^nu = [A B]^T p^nu_{k+1}
-                        const int j = e / 2, c = e % 2;
+                if (brd)
+                    for (int e = lane; e < NV * MMPC_NBC; e += MMPC_WAVE) {   // g = [A B]^T p_{k+1} of the border columns (+ -v~ of this stage)
+                        const int j = e / MMPC_NBC, c = e % MMPC_NBC;
                         double v = 0.0;
-                        for (int q = 0; q < 4; q++) v += cv[TB::ccv(j, q)] * PNU[TB::crow(j, q) * 2 + c];
+                        for (int q = 0; q < 4; q++) v += cv[TB::ccv(j, q)] * PNU[TB::crow(j, q) * MMPC_NBC + c];
+                        if (c == 2 && sig && j < NX && yix(j) >= 0) {
+                            if (k == N - 1) v -= VX[(N - 1) * 6 + yix(j)];
+                            if (k == N - 2) v -= VQ[(N - 1) * 6 + yix(j)];
+                        }
                         GNU[e] = v;
                     }
                 LANES_END
                 // R3/R4: Cholesky of Hh (every solving lane redundantly, in registers), then one
                 //        right-hand side per lane: K = -Hh^{-1} G (NX columns), kf = -Hh^{-1} gu
                 LANES_BEGIN
-                if (lane <= NX + (teq ? 2 : 0)) {
+                if (lane <= NX + (brd ? MMPC_NBC : 0)) {
                     double Lc[NUU];
                     bool ok = true;
 #pragma unroll
@@ -1145,7 +1165,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                     }
                     double rhs[NU];
 #pragma unroll
-                    for (int a = 0; a < NU; a++) rhs[a] = lane < NX ? MG[a * NX + lane] : (lane == NX ? MGU[a] : GNU[(NX + a) * 2 + lane - NX - 1]);
+                    for (int a = 0; a < NU; a++) rhs[a] = lane < NX ? MG[a * NX + lane] : (lane == NX ? MGU[a] : GNU[(NX + a) * MMPC_NBC + lane - NX - 1]);
 #pragma unroll
                     for (int i = 0; i < NU; i++) {
                         double v = rhs[i];
@@ -1164,7 +1184,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                     for (int a = 0; a < NU; a++) {
                         if (lane < NX) KK[(k * NU + a) * NX + lane] = -rhs[a];
                         else if (lane == NX) KF[k * NU + a] = -rhs[a];
-                        else KFV[(k * NU + a) * 2 + lane - NX - 1] = -rhs[a];
+                        else KFV[(k * NU + a) * MMPC_NBC + lane - NX - 1] = -rhs[a];
                     }
                     if (!ok && lane == 0) MISC[0] = 1.0;
                 }
@@ -1172,12 +1192,12 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                 if (MISC[0] != 0.0) { failed = 1; break; }
                 // R5: P_k = F + G^T K,  p_k = gx + G^T kf   (overwrite the stage blocks)
                 LANES_BEGIN
-                if (teq)
-                    for (int e = lane; e < NX * 2; e += MMPC_WAVE) {   // p^nu_k = g^nu_x + G^T kf^nu
-                        const int i = e / 2, c = e % 2;
-                        double v = GNU[i * 2 + c];
-                        for (int a = 0; a < NU; a++) v += MG[a * NX + i] * KFV[(k * NU + a) * 2 + c];
-                        PNU[e] = v; PNUS[k * NX * 2 + e] = v;
+                if (brd)
+                    for (int e = lane; e < NX * MMPC_NBC; e += MMPC_WAVE) {   // p_k = g_x + G^T kf of the border columns
+                        const int i = e / MMPC_NBC, c = e % MMPC_NBC;
+                        double v = GNU[i * MMPC_NBC + c];
+                        for (int a = 0; a < NU; a++) v += MG[a * NX + i] * KFV[(k * NU + a) * MMPC_NBC + c];
+                        PNU[e] = v; PNUS[k * NX * MMPC_NBC + e] = v;
                     }
                 for (int e = lane; e < NXX + NX; e += MMPC_WAVE) {
                     if (e < NXX) {
@@ -1194,6 +1214,49 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                     }
                 }
                 LANES_END
+            }
+            if (!failed && brd) {
+                // the direction is affine in the border variables y = (nu0, nu1, dsigma): roll out the y = 0 solution and the
+                // sensitivities (same gains K; homogeneous dynamics for the sensitivities), and collect v~.d of every column
+                LANES_BEGIN
+                for (int j = lane; j < 2 * (1 + MMPC_NBC) * NX; j += MMPC_WAVE) FWV[j] = 0.0;
+                if (lane < 1 + MMPC_NBC) SIGW[4 + lane] = 0.0;
+                LANES_END
+                for (int k = 0; k < N; k++) {
+                    const double *src = FWV + (k & 1) * (1 + MMPC_NBC) * NX;
+                    double *dst = FWV + ((k + 1) & 1) * (1 + MMPC_NBC) * NX;
+                    LANES_BEGIN
+                    if (lane < (1 + MMPC_NBC) * NX) {
+                        const int c = lane / NX, i = lane % NX;
+                        const double *cv = CV + k * MMPC_NCV;
+                        const double *d = src + c * NX;
+                        double v = c == 0 ? CD[k * NX + i] : 0.0;
+                        for (int q = 0; q < 5; q++) {
+                            const int col = TB::rcol(i, q);
+                            double x;
+                            if (col < NX) x = d[col];
+                            else {
+                                const int a = col - NX;
+                                x = c == 0 ? KF[k * NU + a] : KFV[(k * NU + a) * MMPC_NBC + c - 1];
+                                for (int j = 0; j < NX; j++) x += KK[(k * NU + a) * NX + j] * d[j];
+                            }
+                            v += cv[TB::rcv(i, q)] * x;
+                        }
+                        dst[c * NX + i] = v;
+                    }
+                    LANES_END
+                    if (sig && k + 1 >= N - 2) {   // v~ . dx_{k+1}: vq on x_{N-2}, v on x_{N-1}, vN on x_N
+                        LANES_BEGIN
+                        if (lane < 1 + MMPC_NBC) {
+                            const double *vv = k + 1 == N - 2 ? VQ + (N - 1) * 6 : (k + 1 == N - 1 ? VX + (N - 1) * 6 : VXN);
+                            double t = SIGW[4 + lane];
+                            for (int a = 0; a < 6; a++) t += vv[a] * dst[lane * NX + kY[a]];
+                            SIGW[4 + lane] = t;
+                        }
+                        LANES_END
+                    }
+                }
+                if (sig && !(HSS[N - 1] - SIGW[4 + MMPC_NBC] > 0.0)) failed = 1;   // pivot of the border variable (uniform)
             }
 #ifdef MMPC_EMU_DEBUG
             if (failed) fprintf(stderr, "generic it %d: attempt %d lost a pivot (prox %g)\n", it, attempt, prox);
@@ -1217,45 +1280,36 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
 #endif
             status = 2; break; }
 
-        if (teq) {
-            // the direction is affine in the two terminal multipliers: roll out the nu = 0 solution and the two
-            // sensitivities (same gains K), solve E dx_N = e (2x2), fold nu into the feed-forward terms
-            LANES_BEGIN
-            for (int j = lane; j < 2 * 3 * NX; j += MMPC_WAVE) FWV[j] = 0.0;
-            LANES_END
-            for (int k = 0; k < N; k++) {
-                const double *src = FWV + (k & 1) * 3 * NX;
-                double *dst = FWV + ((k + 1) & 1) * 3 * NX;
-                LANES_BEGIN
-                if (lane < 3 * NX) {
-                    const int c = lane / NX, i = lane % NX;
-                    const double *cv = CV + k * MMPC_NCV;
-                    const double *d = src + c * NX;
-                    double v = c == 0 ? CD[k * NX + i] : 0.0;
-                    for (int q = 0; q < 5; q++) {
-                        const int col = TB::rcol(i, q);
-                        double x;
-                        if (col < NX) x = d[col];
-                        else {
-                            const int a = col - NX;
-                            x = c == 0 ? KF[k * NU + a] : KFV[(k * NU + a) * 2 + c - 1];
-                            for (int j = 0; j < NX; j++) x += KK[(k * NU + a) * NX + j] * d[j];
-                        }
-                        v += cv[TB::rcv(i, q)] * x;
-                    }
-                    dst[c * NX + i] = v;
+        {
+            const bool sig = NQ && SIGW[0] != 0.0, brd = teq || sig;
+            if (brd) {
+                // the small system in y = (nu0, nu1, dsigma):
+                //   E (dx_N + D y) = e                        (terminal equality; D = sensitivities of dx_N)
+                //   h dsigma - v~.(d + D y) = -g_s            (stationarity in s_{N-1})
+                // rows / columns of variables that are not in play are replaced by the identity
+                const double *fin = FWV + (N & 1) * (1 + MMPC_NBC) * NX;
+                double Ms[3][4];
+                for (int r = 0; r < 2; r++) {
+                    for (int c = 0; c < 3; c++) Ms[r][c] = fin[(1 + c) * NX + r];
+                    Ms[r][3] = XREF[N * NX + r] - X[N * NX + r] - fin[r];
                 }
-                LANES_END
-            }
-            {
-                const double *fin = FWV + (N & 1) * 3 * NX;
-                const double e0 = XREF[N * NX + 0] - X[N * NX + 0] - fin[0], e1 = XREF[N * NX + 1] - X[N * NX + 1] - fin[1];
-                const double d00 = fin[NX + 0], d10 = fin[NX + 1], d01 = fin[2 * NX + 0], d11 = fin[2 * NX + 1];
-                const double det = d00 * d11 - d01 * d10;
-                const double nu0 = (e0 * d11 - d01 * e1) / det, nu1 = (d00 * e1 - e0 * d10) / det;
+                Ms[2][0] = -SIGW[5]; Ms[2][1] = -SIGW[6]; Ms[2][2] = (sig ? HSS[N - 1] : 0.0) - SIGW[7]; Ms[2][3] = -(sig ? GSS[N - 1] : 0.0) + SIGW[4];
+                for (int r = 0; r < 3; r++) {
+                    if (r < 2 ? teq : sig) continue;
+                    for (int q = 0; q < 4; q++) Ms[r][q] = 0.0;
+                    for (int q = 0; q < 3; q++) Ms[q][r] = 0.0;
+                    Ms[r][r] = 1.0;
+                }
+                for (int pc = 0; pc < 3; pc++) {   // Gaussian elimination with row pivoting
+                    int pr = pc;
+                    for (int r = pc + 1; r < 3; r++) if (fabs(Ms[r][pc]) > fabs(Ms[pr][pc])) pr = r;
+                    if (pr != pc) for (int q = 0; q < 4; q++) { const double tq = Ms[pr][q]; Ms[pr][q] = Ms[pc][q]; Ms[pc][q] = tq; }
+                    for (int r = 0; r < 3; r++) if (r != pc) { const double f = Ms[r][pc] / Ms[pc][pc]; for (int q = pc; q < 4; q++) Ms[r][q] -= f * Ms[pc][q]; }
+                }
+                const double nu0 = Ms[0][3] / Ms[0][0], nu1 = Ms[1][3] / Ms[1][1], dsg = Ms[2][3] / Ms[2][2];
                 LANES_BEGIN
-                if (lane == 0) { NUEQ[2] = nu0; NUEQ[3] = nu1; }
-                for (int e = lane; e < N * NU; e += MMPC_WAVE) KF[e] += KFV[e * 2] * nu0 + KFV[e * 2 + 1] * nu1;
+                if (lane == 0) { NUEQ[2] = nu0; NUEQ[3] = nu1; SIGW[1] = dsg; }
+                for (int e = lane; e < N * NU; e += MMPC_WAVE) KF[e] += KFV[e * MMPC_NBC] * nu0 + KFV[e * MMPC_NBC + 1] * nu1 + KFV[e * MMPC_NBC + 2] * dsg;
                 LANES_END
             }
         }
@@ -1302,7 +1356,8 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                 double v = QX[k * NX + i];
                 for (int j = 0; j < NX; j++)
                     v += HXX[k * NXX + (i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i)] * dx[j];
-                if (teq) v += PNUS[(k * NX + i) * 2] * NUEQ[2] + PNUS[(k * NX + i) * 2 + 1] * NUEQ[3];
+                if (teq) v += PNUS[(k * NX + i) * MMPC_NBC] * NUEQ[2] + PNUS[(k * NX + i) * MMPC_NBC + 1] * NUEQ[3];
+                if (NQ && SIGW[0] != 0.0) v += PNUS[(k * NX + i) * MMPC_NBC + 2] * SIGW[1];
                 DLAM[k * NX + i] = -v - LAM[k * NX + i];
             }
             // a slack eliminated one stage earlier is not part of this stage's cost-to-go: its pull on x_k enters the multiplier of

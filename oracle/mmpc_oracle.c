@@ -235,7 +235,10 @@ typedef struct {
     double Hxx[NSM][NXM][NXM], Hux[NSM][NUM][NXM], Huu[NSM][NUM][NUM], qx[NSM][NXM], qu[NSM][NUM];
     double hss[NSM], gss[NSM], vx[NSM][NXM], vxN[NXM];
     double K[NSM][NUM][NXM], kf[NSM][NUM];
-    double pvv[NSM][NXM][2], kfv[NSM][NUM][2], nu_eq[2], nu_new[2];   /* terminal xy equality (interface_wholebody_qref.py:166-167) */
+    double pvv[NSM][NXM][3], kfv[NSM][NUM][3], nu_eq[2], nu_new[2];   /* terminal xy equality (interface_wholebody_qref.py:166-167): columns 0, 1 */
+    /* column 2: the slack s_{N-1} kept as a BORDER variable of the stage-wise system when it reaches back to x_{N-2} (NLP as
+     * written): it then touches x_{N-2}, x_{N-1} and (quirk Q1) x_N - three stages, no stage-wise elimination is exact */
+    int sig; double dsig, sig_den, dxs[NSM][NXM];
     double dX[NSM][NXM], dU[NSM][NUM], ds[NSM], lamn[NSM][NXM];
     double dt_[NSM][RMX], dz[NSM][RMX];
     double Q2[NXM][NXM], P2[NXM][NXM], RW2[NUM][NUM];
@@ -531,9 +534,13 @@ static int factor(work *w, double mu, int use_exact, double prox) {
     /* Schur complement of s_k (H_xs = -v).  s_k is tied to x_k by its own rows (v), for k = N-1 also to x_N by the terminal
      * self rows (vN, quirk Q1), and in the NLP as written to x_{k-1} by the rows whose previous-stage entry attains the max
      * (vq).  A slack that reaches back is eliminated one stage earlier, everything expressed in (x_{k-1}, u_{k-1}) through
-     * dx_k = A dx_{k-1} + B du_{k-1} + c:  a = vq + A^T v, b = B^T v, gamma = g_s - v.c.  (s_{N-1} would then touch three
-     * stages; its reach-back part keeps only the diagonal block of x_{N-2} - an inexact Newton matrix in that corner,
-     * the residuals stay exact.) */
+     * dx_k = A dx_{k-1} + B du_{k-1} + c:  a = vq + A^T v, b = B^T v, gamma = g_s - v.c.  s_{N-1} reaching back touches three
+     * stages (x_{N-2}, x_{N-1}, x_N): it is not eliminated at all but kept as a border variable sigma of the stage-wise system
+     * (w->sig): [K -v~; -v~^T h] [d; dsigma] = -[q; g_s], solved with one extra right-hand side through the same recursion
+     * (column 2 of pvv / kfv, like the two multipliers of the terminal equality).  (Round 2 kept only the diagonal block of
+     * x_{N-2}: an inexact Newton matrix whose iteration stalled at a dual residual of 1e-2..1e-6 on 2 % of the starts.) */
+    w->sig = 0;
+    if (w->nq8 && N >= 2) for (int i = 0; i < nx; i++) if (w->vq[N - 1][i] != 0.0) w->sig = 1;
     for (int k = 0; k <= N; k++) {
         int back = 0;
         if (w->nq8 && k >= 1 && k != N - 1) for (int i = 0; i < nx; i++) if (w->vq[k][i] != 0.0) back = 1;
@@ -552,6 +559,7 @@ static int factor(work *w, double mu, int use_exact, double prox) {
             }
             continue;
         }
+        if (k == N - 1 && w->sig) continue;   /* border variable: no elimination */
         double a[NXM], b[NUM], gam = w->gss[k];
         for (int i = 0; i < nx; i++) a[i] = w->vx[k][i];
         for (int i = 0; i < nu; i++) b[i] = 0;
@@ -559,8 +567,6 @@ static int factor(work *w, double mu, int use_exact, double prox) {
             for (int i = 0; i < nx; i++) for (int j = 0; j < nx; j++) a[i] += w->A[k][j][i] * w->vxN[j];
             for (int i = 0; i < nu; i++) for (int j = 0; j < nx; j++) b[i] += w->B[k][j][i] * w->vxN[j];
             for (int j = 0; j < nx; j++) gam -= w->vxN[j] * w->c[k][j];
-            if (w->nq8 && k >= 1)   /* reach-back part of s_{N-1}: diagonal block and gradient on x_{N-2} only */
-                for (int i = 0; i < nx; i++) { for (int j = 0; j < nx; j++) w->Hxx[k - 1][i][j] -= w->vq[k][i] * w->vq[k][j] * ih; w->qx[k - 1][i] += w->vq[k][i] * w->gss[k] * ih; }
         }
         for (int i = 0; i < nx; i++) { for (int j = 0; j < nx; j++) w->Hxx[k][i][j] -= a[i] * a[j] * ih; w->qx[k][i] += a[i] * gam * ih; }
         if (k == N - 1)
@@ -578,6 +584,7 @@ static int factor(work *w, double mu, int use_exact, double prox) {
         }
     memset(w->pvv[N], 0, sizeof(w->pvv[N]));
     w->pvv[N][0][0] = 1.0; w->pvv[N][1][1] = 1.0; /* E^T, E = [I2 0] */
+    if (w->sig) for (int i = 0; i < nx; i++) w->pvv[N][i][2] = -w->vxN[i];   /* "gradient" of the border column: -v~ */
     for (int k = N - 1; k >= 0; k--) {
         double (*P)[NXM] = w->Hxx[k + 1]; double *p = w->qx[k + 1];
         double PA[NXM][NXM], PB[NXM][NUM], pc[NXM];
@@ -604,8 +611,8 @@ static int factor(work *w, double mu, int use_exact, double prox) {
             for (int i = 0; i < nu; i++) w->K[k][i][j] = -col[i];
         }
         { double col[NUM]; for (int i = 0; i < nu; i++) col[i] = gu[i]; chol_solve(L, nu, col); for (int i = 0; i < nu; i++) w->kf[k][i] = -col[i]; }
-        if (c->terminal_xy_eq)
-            for (int cc = 0; cc < 2; cc++) {   /* sensitivities of the direction w.r.t. the two terminal multipliers */
+        for (int cc = 0; cc < 3; cc++) {   /* sensitivities of the direction w.r.t. the two terminal multipliers / the border slack */
+                if (cc < 2 ? !c->terminal_xy_eq : !w->sig) continue;
                 double col[NUM];
                 for (int i = 0; i < nu; i++) { double v = 0; for (int l = 0; l < nx; l++) v += w->B[k][l][i] * w->pvv[k + 1][l][cc]; col[i] = v; }
                 chol_solve(L, nu, col);
@@ -614,6 +621,8 @@ static int factor(work *w, double mu, int use_exact, double prox) {
                     double v = 0;
                     for (int l = 0; l < nx; l++) v += w->A[k][l][i] * w->pvv[k + 1][l][cc];
                     for (int l = 0; l < nu; l++) v += G[l][i] * w->kfv[k][l][cc];
+                    if (cc == 2 && k == N - 1) v -= w->vx[N - 1][i];
+                    if (cc == 2 && k == N - 2) v -= w->vq[N - 1][i];
                     w->pvv[k][i][cc] = v;
                 }
             }
@@ -623,6 +632,24 @@ static int factor(work *w, double mu, int use_exact, double prox) {
             double v = gx[i]; for (int l = 0; l < nu; l++) v += G[l][i] * w->kf[k][l]; w->qx[k][i] = v;
         }
         for (int i = 0; i < nx; i++) for (int j = 0; j < nx; j++) w->Hxx[k][i][j] = 0.5 * (Pn[i][j] + Pn[j][i]);
+    }
+    if (w->sig) {
+        /* K d1 = v~ (homogeneous dynamics): roll-out of the border column; h - v~.d1 is the pivot of the border variable */
+        memset(w->dxs, 0, sizeof(w->dxs));
+        for (int k = 0; k < N; k++) {
+            double du[NUM];
+            for (int i = 0; i < nu; i++) { double v = w->kfv[k][i][2]; for (int j = 0; j < nx; j++) v += w->K[k][i][j] * w->dxs[k][j]; du[i] = v; }
+            for (int i = 0; i < nx; i++) {
+                double v = 0;
+                for (int j = 0; j < nx; j++) v += w->A[k][i][j] * w->dxs[k][j];
+                for (int j = 0; j < nu; j++) v += w->B[k][i][j] * du[j];
+                w->dxs[k + 1][i] = v;
+            }
+        }
+        double t1 = 0;
+        for (int j = 0; j < nx; j++) t1 += w->vq[N - 1][j] * w->dxs[N - 2][j] + w->vx[N - 1][j] * w->dxs[N - 1][j] + w->vxN[j] * w->dxs[N][j];
+        w->sig_den = w->hss[N - 1] - t1;
+        if (!(w->sig_den > 0.0)) return 0;
     }
     return 1;
 }
@@ -769,29 +796,54 @@ int mmpc_oracle_solve(const oracle_cfg *cfg, const double *x_init, const double 
             }
             if (!okf) { status = 2; break; }
         }
-        w->nu_new[0] = w->nu_new[1] = 0;
-        if (cfg->terminal_xy_eq) {
-            double d0[NXM] = {0}, Dv[NXM][2], u0[NUM], Uv[NUM][2], t0[NXM], Tv[NXM][2];
-            memset(Dv, 0, sizeof(Dv));
+        w->nu_new[0] = w->nu_new[1] = 0; w->dsig = 0;
+        if (cfg->terminal_xy_eq || w->sig) {
+            /* the direction is affine in the border variables y = (nu0, nu1, dsigma): roll out the y = 0 solution and the
+             * sensitivities (same gains), then the small system
+             *   E (dx_N + D y) = e                        (terminal equality)
+             *   h dsigma - v~.(d + D y) = -g_s            (stationarity in s_{N-1}) */
+            static __thread double d0[NSM][NXM], Dv[NSM][NXM][2];
+            memset(d0, 0, sizeof(d0)); memset(Dv, 0, sizeof(Dv));
             for (int k = 0; k < N; k++) {
+                double u0[NUM], Uv[NUM][2];
                 for (int i = 0; i < nu; i++) {
                     double v = w->kf[k][i], v0 = w->kfv[k][i][0], v1 = w->kfv[k][i][1];
-                    for (int j = 0; j < nx; j++) { v += w->K[k][i][j] * d0[j]; v0 += w->K[k][i][j] * Dv[j][0]; v1 += w->K[k][i][j] * Dv[j][1]; }
+                    for (int j = 0; j < nx; j++) { v += w->K[k][i][j] * d0[k][j]; v0 += w->K[k][i][j] * Dv[k][j][0]; v1 += w->K[k][i][j] * Dv[k][j][1]; }
                     u0[i] = v; Uv[i][0] = v0; Uv[i][1] = v1;
                 }
                 for (int i = 0; i < nx; i++) {
                     double v = w->c[k][i], v0 = 0, v1 = 0;
-                    for (int j = 0; j < nx; j++) { v += w->A[k][i][j] * d0[j]; v0 += w->A[k][i][j] * Dv[j][0]; v1 += w->A[k][i][j] * Dv[j][1]; }
+                    for (int j = 0; j < nx; j++) { v += w->A[k][i][j] * d0[k][j]; v0 += w->A[k][i][j] * Dv[k][j][0]; v1 += w->A[k][i][j] * Dv[k][j][1]; }
                     for (int j = 0; j < nu; j++) { v += w->B[k][i][j] * u0[j]; v0 += w->B[k][i][j] * Uv[j][0]; v1 += w->B[k][i][j] * Uv[j][1]; }
-                    t0[i] = v; Tv[i][0] = v0; Tv[i][1] = v1;
+                    d0[k + 1][i] = v; Dv[k + 1][i][0] = v0; Dv[k + 1][i][1] = v1;
                 }
-                memcpy(d0, t0, sizeof(d0)); memcpy(Dv, Tv, sizeof(Dv));
             }
-            double e0 = w->xref[N * nx + 0] - w->X[N][0] - d0[0], e1 = w->xref[N * nx + 1] - w->X[N][1] - d0[1];
-            double det = Dv[0][0] * Dv[1][1] - Dv[0][1] * Dv[1][0];
-            w->nu_new[0] = (e0 * Dv[1][1] - Dv[0][1] * e1) / det;
-            w->nu_new[1] = (Dv[0][0] * e1 - e0 * Dv[1][0]) / det;
-            for (int k = 0; k < N; k++) for (int i = 0; i < nu; i++) w->kf[k][i] += w->kfv[k][i][0] * w->nu_new[0] + w->kfv[k][i][1] * w->nu_new[1];
+            double Ms[3][4]; int act3[3] = {cfg->terminal_xy_eq, cfg->terminal_xy_eq, w->sig};
+            memset(Ms, 0, sizeof(Ms));
+            for (int r = 0; r < 2; r++) {
+                Ms[r][0] = Dv[N][r][0]; Ms[r][1] = Dv[N][r][1]; Ms[r][2] = w->sig ? w->dxs[N][r] : 0.0;
+                Ms[r][3] = w->xref[N * nx + r] - w->X[N][r] - d0[N][r];
+            }
+            if (w->sig) {
+                double t0 = 0, tv[2] = {0, 0};
+                for (int j = 0; j < nx; j++) {
+                    t0 += w->vq[N - 1][j] * d0[N - 2][j] + w->vx[N - 1][j] * d0[N - 1][j] + w->vxN[j] * d0[N][j];
+                    for (int cc = 0; cc < 2; cc++) tv[cc] += w->vq[N - 1][j] * Dv[N - 2][j][cc] + w->vx[N - 1][j] * Dv[N - 1][j][cc] + w->vxN[j] * Dv[N][j][cc];
+                }
+                Ms[2][0] = -tv[0]; Ms[2][1] = -tv[1]; Ms[2][2] = w->sig_den; Ms[2][3] = -w->gss[N - 1] + t0;
+            }
+            for (int r = 0; r < 3; r++) if (!act3[r]) { for (int q = 0; q < 4; q++) Ms[r][q] = 0.0; for (int q = 0; q < 3; q++) Ms[q][r] = 0.0; Ms[r][r] = 1.0; }
+            for (int pcol = 0; pcol < 3; pcol++) {   /* Gaussian elimination with row pivoting (3 x 3) */
+                int pr = pcol; for (int r = pcol + 1; r < 3; r++) if (fabs(Ms[r][pcol]) > fabs(Ms[pr][pcol])) pr = r;
+                if (pr != pcol) for (int q = 0; q < 4; q++) { double tq = Ms[pr][q]; Ms[pr][q] = Ms[pcol][q]; Ms[pcol][q] = tq; }
+                for (int r = 0; r < 3; r++) if (r != pcol) { double f = Ms[r][pcol] / Ms[pcol][pcol]; for (int q = pcol; q < 4; q++) Ms[r][q] -= f * Ms[pcol][q]; }
+            }
+            double y[3]; for (int r = 0; r < 3; r++) y[r] = Ms[r][3] / Ms[r][r];
+            w->nu_new[0] = y[0]; w->nu_new[1] = y[1]; w->dsig = y[2];
+            for (int k = 0; k < N; k++) for (int i = 0; i < nu; i++) {
+                if (cfg->terminal_xy_eq) w->kf[k][i] += w->kfv[k][i][0] * y[0] + w->kfv[k][i][1] * y[1];
+                if (w->sig) w->kf[k][i] += w->kfv[k][i][2] * y[2];
+            }
         }
         for (int j = 0; j < nx; j++) w->dX[0][j] = 0;
         for (int k = 0; k < N; k++) {
@@ -806,6 +858,7 @@ int mmpc_oracle_solve(const oracle_cfg *cfg, const double *x_init, const double 
         for (int k = 1; k <= N; k++) for (int i = 0; i < nx; i++) {
             double v = w->qx[k][i]; for (int j = 0; j < nx; j++) v += w->Hxx[k][i][j] * w->dX[k][j];
             if (cfg->terminal_xy_eq) v += w->pvv[k][i][0] * w->nu_new[0] + w->pvv[k][i][1] * w->nu_new[1];
+            if (w->sig) v += w->pvv[k][i][2] * w->dsig;
             w->lamn[k][i] = -v; }
         for (int k = 0; k <= N; k++) {
             double vdx = 0; for (int j = 0; j < nx; j++) vdx += w->vx[k][j] * w->dX[k][j];

@@ -65,3 +65,23 @@ def make_batch(B, N=20, M=5, kind="wholebody", seed=20240114, config_id=3, movin
     if moving:
         out["obs_vel"] = vel
     return out
+
+
+def make_c1_starts(B=2048, N=20, nplanes=2, seed=11):
+    """Starts around the two (three) half-space obstacles of demo_wholebody_qref.py:21-33 ('the tent'): the shape of BASELINE
+    config C1 as a batch (bench.py: c1_shape_generic_kernel; tests: the NLP as written must converge on all of them)."""
+    r2 = 1 / np.sqrt(2)
+    if nplanes == 2:
+        hs = np.array([[2.5, 2, 0.35 + 0.606 + 0.333, r2, 0, r2], [2.5, 2, 0.35 + 0.606 + 0.333, -r2, 0, r2]])
+    else:
+        hs = np.array([[2.5, 2, 1.3, r2, 0, r2], [2.5, 2, 1.3, -r2, 0, r2], [2.5, 2, 1.5, 0, 0, 1.0]])
+    rng = np.random.default_rng(seed)
+    x = np.zeros((B, 9)); tr = np.zeros((B, N + 1, 9))
+    for b in range(B):
+        x0 = np.array([rng.uniform(1.4, 2.6), rng.uniform(1.6, 2.4), rng.uniform(-0.4, 0.4), rng.uniform(0, 0.8), 0, 0,
+                       rng.uniform(-0.3, 0.6), rng.uniform(-1.6, -0.6), rng.uniform(0.8, 2.2)])
+        x0[4] = x0[3] * np.sin(x0[2]); x0[3] = x0[3] * np.cos(x0[2])
+        tg = x0.copy(); tg[0] += rng.uniform(0.8, 1.8); tg[1] += rng.uniform(-0.3, 0.3); tg[3:6] = 0
+        x[b] = x0; tr[b] = np.linspace(x0, tg, 51)[:N + 1]
+    obs = np.broadcast_to(np.array([[2.5, 3.4, 0.3], [2.5, 0.6, 0.3], [6, 6, 0.1]]), (B, 3, 3)).copy()
+    return x, tr, obs, hs

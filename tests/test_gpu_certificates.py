@@ -16,13 +16,12 @@ import pytest
 
 from oracle import nlp, coracle, synth
 from cert_pool import certify
-from test_slsqp_golden import load_cases, EXCEPTIONS, TOL_X, TOL_U, TOL_COST
+from test_slsqp_golden import load_cases, check_fixture, check_summary, cert_ok, CERT_TOL
 
 pytestmark = pytest.mark.gpu
 
-# IPOPT declares convergence at E0 <= 1e-8 with ITS multipliers; the certificate's multipliers are a least-squares fit,
-# not the solver's, so its E0 is an upper bound that sits a small factor above the engine's own figure (measured 1.0-1.8x)
-CERT_TOL = 3e-8
+# (CERT_TOL = 1.5e-8 and cert_ok: tests/test_slsqp_golden.py - IPOPT declares convergence at E0 <= 1e-8 with ITS multipliers; the
+#  certificate's multipliers are fitted independently, so its E0 is an upper bound a small factor above the engine's own figure)
 
 
 def _wb(mm, N, M, B, **kw):
@@ -56,7 +55,7 @@ def test_bench_batch_passes_ipopt_termination_test_incl_tail(mm):
     cs = certify(items)
     E0 = np.array([c["E0"] for c in cs])
     worst = int(np.argmax(E0))
-    assert E0.max() <= CERT_TOL, (int(sel[worst]), int(r["iters"][sel[worst]]), cs[worst])
+    assert all(cert_ok(c) for c in cs), (int(sel[worst]), int(r["iters"][sel[worst]]), cs[worst])
     assert max(c["eq_violation"] for c in cs) <= 1e-8 and max(c["ineq_violation"] for c in cs) <= 1e-8
     cost = np.array([c["cost"] for c in cs])
     assert np.abs(cost / r["cost"][sel] - 1).max() < 1e-10       # the kernel reports the reference's cost (:317)
@@ -91,7 +90,7 @@ def test_full_bench_batch_against_cpu_oracle(mm):
     ul = np.zeros((N, 5))
     cs = certify([(nlp.Problem(par, xi[b], d["traj_ref"][b], d["u_ref"][b], ul, d["obs"][b]), r["X"][b], r["U"][b], r["s"][b]) for b in loose])
     for b, c in zip(loose, cs):
-        assert c["E0"] <= CERT_TOL, (int(b), c)
+        assert cert_ok(c), (int(b), c)
 
 
 def test_c2_base_batch_1024(mm):
@@ -108,7 +107,7 @@ def test_c2_base_batch_1024(mm):
     sel = np.concatenate([np.argsort(-r["iters"], kind="stable")[:8], np.arange(56)])
     ul = np.zeros((N, 2))
     cs = certify([(nlp.Problem(par, d["x_init"][b], d["traj_ref"][b], d["u_ref"][b], ul, d["obs"][b]), r["X"][b], r["U"][b], r["s"][b]) for b in sel])
-    assert max(c["E0"] for c in cs) <= CERT_TOL
+    assert all(cert_ok(c) for c in cs), max(c["E0"] for c in cs)
 
 
 def test_base_heading_term_across_the_pi_cut(mm):
@@ -142,7 +141,7 @@ def test_base_heading_term_across_the_pi_cut(mm):
         assert (np.abs(plain - wrapped) > 6.0).any()
         ul = np.zeros((N, 2))
         cs = certify([(nlp.Problem(pard, d["x_init"][b], d["traj_ref"][b], d["u_ref"][b], ul, d["obs"][b]), r["X"][b], r["U"][b], r["s"][b]) for b in range(16)])
-        assert max(c["E0"] for c in cs) <= CERT_TOL, generic
+        assert all(cert_ok(c) for c in cs), (generic, max(c["E0"] for c in cs))
 
 
 def _c5_batch(B):
@@ -174,7 +173,7 @@ def test_c5_shape_every_instance_certified(mm):
     ul = np.zeros((N, 5))
     cs = certify([(nlp.Problem(par, xi[b], d["traj_ref"][b], d["u_ref"][b], ul, d["obs"][b]), r["X"][b], r["U"][b], r["s"][b]) for b in sel])
     E0 = np.array([c["E0"] for c in cs])
-    assert E0.max() <= CERT_TOL, (int(sel[int(np.argmax(E0))]), E0.max())
+    assert all(cert_ok(c) for c in cs), (int(sel[int(np.argmax(E0))]), E0.max())
 
 
 def test_c5_full_size_properties(mm):
@@ -233,10 +232,14 @@ def test_c5_full_size_properties(mm):
                          xc[:, 5] + 0.1 * u0[:, 1], xc[:, 6] + 0.1 * u0[:, 2], xc[:, 7] + 0.1 * u0[:, 3], xc[:, 8] + 0.1 * u0[:, 4]], dim=1)
 
 
+_RECORD = {}
+
+
 @pytest.mark.parametrize("name,par,g", load_cases(), ids=[n for n, _, _ in load_cases()])
-def test_gpu_reaches_the_slsqp_minimiser(mm, name, par, g):
-    """HIP path vs the committed SLSQP solutions: |dX| <= 1e-4, |dU| <= 5e-4, cost 1e-6 relative (tests/test_slsqp_golden.py
-    states why); every output must pass the certificate, the three fixtures where SLSQP ended elsewhere included."""
+def test_gpu_against_the_second_source(mm, name, par, g):
+    """HIP path vs the committed SLSQP solutions (two SLSQP starts per fixture), rules of tests/test_slsqp_golden.py: every
+    output passes the certificate; one whose cost equals that of an SLSQP run is that minimiser to |dX| <= 1e-4, |dU| <= 5e-4;
+    the others are recorded as another local minimum, with whether they cost more than the second source's best run."""
     N = par.N
     obs = g["obs"]
     per_stage = obs.ndim == 3
@@ -253,12 +256,13 @@ def test_gpu_reaches_the_slsqp_minimiser(mm, name, par, g):
     assert np.abs(g["u_last"]).max() == 0.0          # cold start in every fixture
     r = ctrl.solve_batch(g["x_init"][None], g["traj_ref"][None], g["u_ref"][None], obs[None])
     assert r["status"][0] == 0
-    if name not in EXCEPTIONS:
-        assert abs(r["cost"][0] - float(g["cost"])) <= TOL_COST * abs(float(g["cost"]))
-        assert np.abs(r["X"][0] - g["X"]).max() <= TOL_X and np.abs(r["U"][0] - g["U"]).max() <= TOL_U
-    prob = nlp.Problem(par, nlp.clip_x_init(par, g["x_init"]), g["traj_ref"], g["u_ref"], g["u_last"], obs, hs)
-    c = nlp.kkt_certificate_ipopt(prob, r["X"][0], r["U"][0], r["s"][0])
-    assert c["E0"] <= CERT_TOL, c
+    check_fixture(name, par, g, r["X"][0], r["U"][0], r["s"][0], float(r["cost"][0]), _RECORD)
+
+
+def test_gpu_second_source_summary():
+    """How many of the 67 fixtures the HIP path solves to the minimiser of one of the two SLSQP runs, how many end in a
+    costlier local minimum than the second source's best run (printed with -s; bounds in tests/test_slsqp_golden.py)."""
+    check_summary(_RECORD, len(load_cases()))
 
 
 def test_failed_instances_keep_their_warm_start(mm):
@@ -425,12 +429,38 @@ def test_as_written_halfspace_rows_batch(mm, nplanes):
     ok = np.nonzero(r["status"] == 0)[0]
     cs = certify([(nlp.Problem(par, x[b], tr[b], z[b], z[b], obs[b], hs, as_written=True), r["X"][b], r["U"][b], r["s"][b]) for b in ok])
     E0 = np.array([c["E0"] for c in cs])
-    assert E0.max() <= CERT_TOL, (int(ok[int(np.argmax(E0))]), E0.max())
+    assert all(cert_ok(c) for c in cs), (int(ok[int(np.argmax(E0))]), E0.max())
     # the as-written rows matter here: solved with the intended rows only, many of these optima violate one
     loose = mm.MPCWholeBody(mm.MobileManipulator(0.1), [], oml, N=N, max_batch=B, n_obstacles=3, faithful_convex=False)
     ri = loose.solve_batch(x, tr, z, obs)
     viol = mm.controllers._q8.as_written_extra_rows(ri["X"], ri["s"], hs).reshape(B, -1).max(1)
     assert (viol > 1e-6).sum() >= 8
+
+
+def test_as_written_converges_on_2048_starts(mm):
+    """bench.py's C1-shape batch (2048 starts around the demo's two planes, oracle/synth.py:make_c1_starts) under the NLP AS
+    WRITTEN on the GPU: 100 % converged (round 2: 43 of them ran into the iteration cap - s_{N-1} reaching back to x_{N-2} was
+    eliminated with a diagonal block only; it is a border variable of the stage-wise system now), same answers as the C oracle,
+    and the certificate of the as-written NLP on the former failures and on the slowest instances."""
+    x, tr, obs, hs = synth.make_c1_starts()
+    B, N = x.shape[0], 20
+    par = nlp.WholeBodyParams()
+    z = np.zeros((B, N, 5))
+    oml = [(h[:3], h[3:].reshape(1, 3)) for h in hs]
+    ctrl = mm.MPCWholeBody(mm.MobileManipulator(0.1), [], oml, N=N, max_batch=B, n_obstacles=3)      # the NLP as written
+    r = ctrl.solve_batch(x, tr, z, obs)
+    assert (r["status"] == 0).all(), np.nonzero(r["status"])[0].tolist()
+    assert (r["q8_margin"] <= ctrl.Q8_TOL).all()
+    o = coracle.solve_batch(par, x, tr, z, z, obs, hs=hs, max_iter=2000, nthreads=16, as_written=True)
+    assert (o["status"] == 0).all()
+    same = np.abs(r["cost"] / o["cost"] - 1) < 1e-6
+    assert same.sum() >= B - 20, int(same.sum())           # (a kink of a max can send the two builds to different branches)
+    # (U is the least determined block - the arm inputs carry no R weight -: measured 2.0e-5 on one of the 2048, X 2.0e-6)
+    assert np.abs(r["X"][same] - o["X"][same]).max() < 1e-5 and np.abs(r["U"][same] - o["U"][same]).max() < 5e-5
+    sel = np.unique(np.concatenate([[66, 144, 293, 1948], np.argsort(-r["iters"], kind="stable")[:12]]))
+    cs = certify([(nlp.Problem(par, x[b], tr[b], z[b], z[b], obs[b], hs, as_written=True), r["X"][b], r["U"][b], r["s"][b]) for b in sel])
+    assert all(cert_ok(c) for c in cs), max(c["E0"] for c in cs)
+    print("as written, 2048 starts: mean %.1f iterations, max %d; %d of 2048 in the C oracle's minimum" % (r["iters"].mean(), r["iters"].max(), int(same.sum())))
 
 
 def test_non_finite_inputs_fail_per_instance(mm):

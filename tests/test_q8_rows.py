@@ -4,7 +4,7 @@ against finite differences, and a hand-made trajectory that satisfies the intend
 import numpy as np
 
 import mmpc_loader
-from oracle import nlp
+from oracle import synth, nlp, coracle
 
 R2 = 1 / np.sqrt(2)
 HS2 = np.array([[2.5, 2, 0.35 + 0.606 + 0.333, R2, 0, R2], [2.5, 2, 0.35 + 0.606 + 0.333, -R2, 0, R2]])    # demo scenario 2 (:30-33)
@@ -121,3 +121,21 @@ def test_as_written_tick_with_two_slacks_folded_into_the_last_stage():
     prob = nlp.Problem(par, z["x"][0], z["t"][0], z["u"][0], z["ul"][0], z["o"][0], HS2, as_written=True)
     c = nlp.kkt_certificate_ipopt(prob, e["X"][0], e["U"][0], e["s"][0])
     assert c["E0"] <= 3e-8, c
+
+
+def test_as_written_converges_on_2048_starts():
+    """The 2048 starts of bench.py's C1-shape line (oracle/synth.py:make_c1_starts) under the NLP AS WRITTEN: every one converges
+    (round 2: 52 ran into the iteration cap on the CPU oracle, 43 on the GPU - the slack s_{N-1} reaches back to x_{N-2} there and
+    its elimination kept only a diagonal block; it is now a border variable of the stage-wise system), and the outputs of the
+    former failures are KKT points of the as-written NLP."""
+    x, tr, obs, hs = synth.make_c1_starts()
+    B, N = x.shape[0], 20
+    par = nlp.WholeBodyParams()
+    z = np.zeros((B, N, 5))
+    o = coracle.solve_batch(par, x, tr, z, z, obs, nthreads=4, hs=hs, as_written=True, max_iter=2000)
+    assert (o["status"] == 0).all(), np.nonzero(o["status"])[0].tolist()
+    assert o["iters"].max() <= 400 and o["iters"].mean() < 40, (o["iters"].max(), o["iters"].mean())
+    for b in (66, 144, 293, 1948):          # four of round 2's failures
+        prob = nlp.Problem(par, x[b], tr[b], z[b], z[b], obs[b], hs, as_written=True)
+        c = nlp.kkt_certificate_ipopt(prob, o["X"][b], o["U"][b], o["s"][b])
+        assert c["E0"] <= 1.5e-8 or c["E0_sd"] <= 1.5e-8, (b, c)

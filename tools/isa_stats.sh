@@ -2,7 +2,7 @@
 # per-phase static instruction / LDS / scratch / AGPR-move / s_waitcnt counts of the (0,20,5) fast kernel (by source line ranges)
 cd "$(dirname "$0")/../mobile-manipulator-mpc_amd/csrc"
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -gline-tables-only -S -o /tmp/mmpc3.s --cuda-device-only mmpc_hip.hip 2>/dev/null
-awk '/^_Z16mmpc_fast_kernelILi0ELi20ELi5ELi1ELb0ELi0E/,/s_endpgm/' /tmp/mmpc3.s > /tmp/kf3.s
+python3 ../../tools/kernel_asm.py /tmp/mmpc3.s _Z16mmpc_fast_kernelILi0ELi20ELi5ELi1ELb0ELi0E /tmp/kf3.s
 python3 - <<'PY'
 import re,collections,bisect
 files={}
