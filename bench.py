@@ -56,10 +56,13 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=8192, help="instances timed on the host cores (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--seed-base", type=int, default=SEED_BASE, help="weak scaling: rank r solves the C4 seed SEED_BASE + r")
-    ap.add_argument("--budget", type=int, default=None,
-                    help="iterations per launch (mmpc_set_iteration_budget); instances that need more are finished by a continuation "
-                         "launch on a side stream while the next batches run (--handles handles in rotation).  Default: 0 (off) on one "
-                         "GPU - the headline -, 64 in multi-rank runs, where one rank's 450-iteration straggler would hold the job")
+    ap.add_argument("--budget", type=int, default=0,
+                    help="iterations per launch of the TIMED steps (mmpc_set_iteration_budget); instances that need more are finished by a "
+                         "continuation launch on a side stream while the next batches run (--handles handles in rotation).  Default 0 "
+                         "(off) at every N: one launch per batch on the plain kernel - the same mode on one GPU and on eight.  The "
+                         "pipelined mode is measured beside it on the same batches (extra `pipelined_budget`, --pipelined-budget)")
+    ap.add_argument("--pipelined-budget", type=int, default=64, help="iteration budget of the `pipelined_budget` extra")
+    ap.add_argument("--no-extras", action="store_true", help="headline only (no collective extras, no rank-0 extras)")
     ap.add_argument("--handles", type=int, default=8, help="handles in rotation when --budget > 0")
     ap.add_argument("--side-streams", type=int, default=6, help="streams the continuation launches rotate over when --budget > 0")
     ap.add_argument("--gather", default="full", choices=["full", "u0"],
@@ -71,11 +74,12 @@ def main():
     args = ap.parse_args()
     if args.config == "c5":
         return main_c5(args)
+    if args.budget < 0 or args.pipelined_budget < 1:
+        raise SystemExit("--budget must be >= 0, --pipelined-budget >= 1")
 
     # Pipelined continuation (see --budget): the launch stream plus the side streams of the continuations must not share a
     # hardware queue - a queue runs its kernels one after the other, the next batch would wait behind a 20 ms continuation.
     # ROCm's default is 4 queues per process; read at runtime initialisation, hence before torch is imported.
-    _budget = args.budget if args.budget is not None else (64 if int(os.environ.get("WORLD_SIZE", "1")) > 1 else 0)
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")       # (also for the one-GPU run: its extras time the same pattern)
 
     import torch
@@ -105,144 +109,202 @@ def main():
             dist.init_process_group(backend)
 
     N, M = args.horizon, args.obstacles
-    Bg = args.batch * (world if args.scaling == "weak" else 1)       # global number of instances
     nx, nu = 9, 5
     from mmpc_amd import sharding
-    lo, hi = sharding.shard_bounds(Bg, world, rank)
-    Bl = hi - lo
-    if args.scaling == "weak":
-        # every rank generates its own seeded batch (rank 0 = the N=1 workload); instance b of rank r is global b + r*batch.
-        # Consecutive seeds, nothing filtered: what the slowest instance of a rank's batch costs shows in per_rank below
-        seed = args.seed_base + rank
-        d = synth.make_batch(args.batch, N=N, M=M, config_id=seed)
-        sl = slice(0, Bl)
-    else:
-        # identical seeded inputs on every rank; each rank keeps its contiguous slice
-        d = synth.make_batch(Bg, N=N, M=M, config_id=args.seed_base)
-        sl = slice(lo, hi)
     robot = mm.MobileManipulator(0.1)
-    ctrl = mm.MPCWholeBody(robot, [], [], N=N, max_batch=Bl, device=local_dev, n_obstacles=M)
-    eng = ctrl._engine
-    # The headline uses NO information from earlier solves: the timed steps re-solve one resident batch, and a launch order
-    # taken from the previous solve of the identical problems is knowledge no first solve of a batch has.  Mode 2 = the
-    # engine orders the workgroups by an a-priori difficulty key computed from this batch's own data inside every call
-    # (mmpc_set_schedule_hint; the key kernel and the sort are part of the timed launch)
-    eng.set_schedule_hint(2)
-    t = lambda a: torch.from_numpy(np.ascontiguousarray(a[sl])).to(dev)
-    x_init = t(np.clip(d["x_init"], ctrl.xlim[0], ctrl.xlim[1]))
-    traj, uref, obs = t(d["traj_ref"]), t(d["u_ref"]), t(d["obs"])
-    ulast = torch.zeros((Bl, N, nu), dtype=torch.float64, device=dev)   # cold start: u_latest = 0 (:298-299)
-    out = eng.solve_batch_device(x_init, traj, uref, ulast, obs)
-    # Iteration budget + continuation (multi-rank default): a launch gives every instance at most `budget` iterations; the few
-    # that need more park their state and are finished by a continuation launch on a side stream while the next batches run.
-    # The handle's state (save area, launch lists) belongs to one batch in flight, so NH handles take turns; a handle's next
-    # launch is ordered after its continuation by the engine itself (event across streams).  Results are bitwise those of one
-    # uninterrupted solve.  A batch takes as long as its slowest instance - a 450-iteration straggler is 16 ms against 6.5 ms -
-    # but the throughput of a stream of batches no longer does.
-    budget = _budget
-    NH = args.handles if budget > 0 else 1
-    engs, outs, sides = [eng], [out], [None]
-    if budget > 0:
-        for _ in range(NH - 1):
-            c_ = mm.MPCWholeBody(robot, [], [], N=N, max_batch=Bl, device=local_dev, n_obstacles=M)
-            c_._engine.set_schedule_hint(2)
-            engs.append(c_._engine); outs.append(None)
-        # (fewer side streams than hardware queues, see GPU_MAX_HW_QUEUES above; continuations on one stream run one after the other)
-        sides = [torch.cuda.Stream(device=dev) for _ in range(min(NH, args.side_streams))]
-        for h in range(NH):
-            engs[h].set_iteration_budget(budget)
-    packed = gathered = None
-    pending = [None] * max(2, NH)
-    rec = sharding.record_len(N, nx, nu) if args.gather == "full" else nu
-    if world > 1:
-        packed = [torch.empty((Bl, rec), dtype=torch.float64, device=dev) for _ in range(max(2, NH))]
-        gathered = [torch.empty((Bg, rec), dtype=torch.float64, device=dev) for _ in range(max(2, NH))]
 
-    def solve_step(i):
-        # one pass of the hot path over the resident batch; returns the output set it writes and the stream its last launch is on
-        if budget == 0:
-            eng.solve_batch_device(x_init, traj, uref, ulast, obs, out=out)
-            return out, None
-        h = i % NH
-        outs[h] = engs[h].solve_batch_device(x_init, traj, uref, ulast, obs, out=outs[h])
-        side = sides[i % len(sides)]
-        engs[h].resume_batch_device(x_init, traj, uref, ulast, obs, outs[h], stream=side.cuda_stream)
-        return outs[h], side
+    def run_config(scaling, budget, steps, warmup):
+        """Warm-up + `steps` timed passes of the hot path in one mode: `scaling` weak (every rank its own seeded batch) or strong
+        (one seeded batch of --batch instances, contiguous slices), `budget` 0 (one launch per batch, the plain kernel) or > 0
+        (at most `budget` iterations per launch, the rest by continuation launches on side streams while the next batches run).
+        Collective: every rank calls it with the same arguments.  Timing per the contract: barrier + synchronize on both sides,
+        max over ranks."""
+        Bg = args.batch * (world if scaling == "weak" else 1)       # global number of instances
+        lo, hi = sharding.shard_bounds(Bg, world, rank)
+        Bl = hi - lo
+        if scaling == "weak":
+            # every rank generates its own seeded batch (rank 0 = the N=1 workload); instance b of rank r is global b + r*batch.
+            # Consecutive seeds, nothing filtered: what the slowest instance of a rank's batch costs shows in per_rank below
+            d = synth.make_batch(args.batch, N=N, M=M, config_id=args.seed_base + rank)
+            sl = slice(0, Bl)
+        else:
+            # identical seeded inputs on every rank; each rank keeps its contiguous slice (SURVEY 8e)
+            d = synth.make_batch(Bg, N=N, M=M, config_id=args.seed_base)
+            sl = slice(lo, hi)
+        ctrl = mm.MPCWholeBody(robot, [], [], N=N, max_batch=max(Bl, 1), device=local_dev, n_obstacles=M)
+        eng = ctrl._engine
+        # The headline uses NO information from earlier solves: the timed steps re-solve one resident batch, and a launch order
+        # taken from the previous solve of the identical problems is knowledge no first solve of a batch has.  Mode 2 = the
+        # engine orders the workgroups by an a-priori difficulty key computed from this batch's own data inside every call
+        # (mmpc_set_schedule_hint; the key kernel and the sort are part of the timed launch)
+        eng.set_schedule_hint(2)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a[sl])).to(dev)
+        x_init = t(np.clip(d["x_init"], ctrl.xlim[0], ctrl.xlim[1]))
+        traj, uref, obs = t(d["traj_ref"]), t(d["u_ref"]), t(d["obs"])
+        ulast = torch.zeros((Bl, N, nu), dtype=torch.float64, device=dev)   # cold start: u_latest = 0 (:298-299)
+        out = eng.solve_batch_device(x_init, traj, uref, ulast, obs)
+        # Iteration budget + continuation: a launch gives every instance at most `budget` iterations; the few that need more park
+        # their state and are finished by a continuation launch on a side stream while the next batches run.  The handle's state
+        # (save area, launch lists) belongs to one batch in flight, so NH handles take turns; a handle's next launch is ordered
+        # after its continuation by the engine itself (event across streams).  Results are bitwise those of one uninterrupted
+        # solve.  A batch takes as long as its slowest instance - a 450-iteration straggler is 16 ms against 6.5 ms - but the
+        # throughput of a stream of batches no longer does.
+        NH = args.handles if budget > 0 else 1
+        engs, outs, sides, keep = [eng], [out], [None], [ctrl]
+        if budget > 0:
+            for _ in range(NH - 1):
+                c_ = mm.MPCWholeBody(robot, [], [], N=N, max_batch=max(Bl, 1), device=local_dev, n_obstacles=M)
+                c_._engine.set_schedule_hint(2)
+                engs.append(c_._engine); outs.append(None); keep.append(c_)
+            # (fewer side streams than hardware queues, see GPU_MAX_HW_QUEUES above; continuations on one stream run one after the other)
+            sides = [torch.cuda.Stream(device=dev) for _ in range(min(NH, args.side_streams))]
+            for h in range(NH):
+                engs[h].set_iteration_budget(budget)
+        packed = gathered = None
+        pending = [None] * max(2, NH)
+        rec = sharding.record_len(N, nx, nu) if args.gather == "full" else nu
+        if world > 1:
+            packed = [torch.empty((Bl, rec), dtype=torch.float64, device=dev) for _ in range(max(2, NH))]
+            gathered = [torch.empty((Bg, rec), dtype=torch.float64, device=dev) for _ in range(max(2, NH))]
 
-    def gather(i, o, side):
-        # the one collective of the path: all-gather of the solved (X,U,s) - or of u0 only - over xGMI (RCCL), inside the
-        # timed region.  Multi-buffered and asynchronous: the gather of step i travels on RCCL's stream while step i+1 is
-        # solved; a buffer set is reused only after its previous gather has completed, and drain() waits for the last ones.
-        # With a continuation in flight the packing and the gather are issued on that continuation's stream (behind it).
-        b = i % len(pending)
-        if pending[b] is not None:
-            pending[b].wait()
-            pending[b] = None
-        with torch.cuda.stream(side) if side is not None else _nullcontext():
-            if args.gather == "full":
-                sharding.pack_solution(o["X"], o["U"], o["s"], out=packed[b])
-            else:
-                packed[b].copy_(o["U"][:, 0, :])
-            _, pending[b] = sharding.allgather_solutions(packed[b], Bg, dist, gathered=gathered[b], async_op=True)
+        def solve_step(i):
+            # one pass of the hot path over the resident batch; returns the output set it writes and the stream its last launch is on
+            if budget == 0:
+                eng.solve_batch_device(x_init, traj, uref, ulast, obs, out=out)
+                return out, None
+            h = i % NH
+            # the output set of this handle is still being packed / gathered from its previous turn (on a side stream, behind the
+            # continuation): the launch that overwrites it is ordered after that gather
+            if pending[h % len(pending)] is not None:
+                pending[h % len(pending)].wait()
+                pending[h % len(pending)] = None
+            outs[h] = engs[h].solve_batch_device(x_init, traj, uref, ulast, obs, out=outs[h])
+            side = sides[i % len(sides)]
+            engs[h].resume_batch_device(x_init, traj, uref, ulast, obs, outs[h], stream=side.cuda_stream)
+            return outs[h], side
 
-    def drain():
-        for b in range(len(pending)):
+        def gather(i, o, side):
+            # the one collective of the path: all-gather of the solved (X,U,s) - or of u0 only - over xGMI (RCCL), inside the
+            # timed region.  Multi-buffered and asynchronous: the gather of step i travels on RCCL's stream while step i+1 is
+            # solved; a buffer set is reused only after its previous gather has completed, and drain() waits for the last ones.
+            # With a continuation in flight the packing and the gather are issued on that continuation's stream (behind it).
+            b = i % len(pending)
             if pending[b] is not None:
                 pending[b].wait()
                 pending[b] = None
+            with torch.cuda.stream(side) if side is not None else _nullcontext():
+                if args.gather == "full":
+                    sharding.pack_solution(o["X"], o["U"], o["s"], out=packed[b])
+                else:
+                    packed[b].copy_(o["U"][:, 0, :])
+                _, pending[b] = sharding.allgather_solutions(packed[b], Bg, dist, gathered=gathered[b], async_op=True)
 
-    for i in range(max(args.warmup, NH if budget > 0 else 0)):
-        o_, side_ = solve_step(i)
+        def drain():
+            for b in range(len(pending)):
+                if pending[b] is not None:
+                    pending[b].wait()
+                    pending[b] = None
+
+        for i in range(max(warmup, NH if budget > 0 else 0)):
+            o_, side_ = solve_step(i)
+            if world > 1:
+                gather(i, o_, side_)
         if world > 1:
-            gather(i, o_, side_)
-    if world > 1:
-        drain()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        evs[i][0].record()
-        o_, side_ = solve_step(i)
-        evs[i][1].record()
+            drain()
+        torch.cuda.synchronize()
         if world > 1:
-            gather(i, o_, side_)
-    if world > 1:
-        drain()
-    torch.cuda.synchronize()
-    out = o_                                               # (every output set holds the same batch's solution)
-    t_rank = time.perf_counter() - t0                      # this rank's own time for its K steps (before the barrier)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([el], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        el = float(tt.item())
-    step_ms = sorted(e0.elapsed_time(e1) for e0, e1 in evs)     # solve kernel per step, HIP events on the launch stream
-    status = out["status"].cpu().numpy()
-    iters = out["iters"].cpu().numpy()
-    err = out["err"].cpu().numpy()
-    stats = torch.tensor([float((status == 0).sum()), float(iters.sum()), float(iters.max()), float(err.max()),
-                          t_rank / args.steps * 1e3, step_ms[len(step_ms) // 2], float(Bl)], dtype=torch.float64, device=dev)
-    if world > 1:
-        parts = [torch.zeros_like(stats) for _ in range(world)]
-        dist.all_gather(parts, stats)
-        parts = [p.tolist() for p in parts]
-    else:
-        parts = [stats.tolist()]
+            dist.barrier()
+        torch.cuda.synchronize()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        t0 = time.perf_counter()
+        for i in range(steps):
+            evs[i][0].record()
+            o_, side_ = solve_step(i)
+            evs[i][1].record()
+            if world > 1:
+                gather(i, o_, side_)
+        if world > 1:
+            drain()
+        torch.cuda.synchronize()
+        out = o_                                               # (every output set holds the same batch's solution)
+        t_rank = time.perf_counter() - t0                      # this rank's own time for its K steps (before the barrier)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        # the gathered table of the last step against this rank's own solution (outside the timed region): every rank's slice of
+        # the table must be its packed records, bit for bit
+        gather_ok = None
+        if world > 1:
+            bl = (steps - 1) % len(pending)
+            mine = sharding.pack_solution(out["X"], out["U"], out["s"]) if args.gather == "full" else out["U"][:, 0, :]
+            ok = torch.equal(gathered[bl][lo:hi] if scaling == "strong" else gathered[bl][rank * Bl:(rank + 1) * Bl], mine) and bool(torch.isfinite(gathered[bl]).all())
+            flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            gather_ok = bool(flag.item() == 1.0)
+        step_ms = sorted(e0.elapsed_time(e1) for e0, e1 in evs)     # solve kernel per step, HIP events on the launch stream
+        status = out["status"].cpu().numpy()
+        iters = out["iters"].cpu().numpy()
+        err = out["err"].cpu().numpy()
+        stats = torch.tensor([float((status == 0).sum()), float(iters.sum()), float(iters.max()) if Bl else 0.0, float(err.max()) if Bl else 0.0,
+                              t_rank / steps * 1e3, step_ms[len(step_ms) // 2], float(Bl)], dtype=torch.float64, device=dev)
+        if world > 1:
+            parts = [torch.zeros_like(stats) for _ in range(world)]
+            dist.all_gather(parts, stats)
+            parts = [p.tolist() for p in parts]
+        else:
+            parts = [stats.tolist()]
+        if budget > 0:
+            for e_ in engs:
+                e_.set_iteration_budget(0)
+        return dict(Bg=Bg, Bl=Bl, el=el, steps=steps, value=Bg * steps / el, ms_per_step=el / steps * 1e3, step_ms=step_ms, parts=parts, out=out,
+                    iters=iters, eng=eng, ctrl=ctrl, d=d, x_init=x_init, traj=traj, uref=uref, obs=obs, ulast=ulast, evs=evs, NH=NH,
+                    gather_ok=gather_ok, keep=keep)
+
+    # ---- the headline: one launch per batch on the plain kernel, at every N (the same mode on one GPU and on eight)
+    budget = args.budget
+    R = run_config(args.scaling, budget, args.steps, args.warmup)
+    Bg, Bl, el, step_ms, parts, out, iters = R["Bg"], R["Bl"], R["el"], R["step_ms"], R["parts"], R["out"], R["iters"]
+    eng, ctrl, d, x_init, traj, uref, obs, ulast, evs, NH = (R[k] for k in ("eng", "ctrl", "d", "x_init", "traj", "uref", "obs", "ulast", "evs", "NH"))
     n_conv = sum(p[0] for p in parts); it_sum = sum(p[1] for p in parts)
     it_max = max(p[2] for p in parts); err_max = max(p[3] for p in parts)
+    # ---- collective extras (every rank takes part): the pipelined-budget mode on the same batches, and - in a weak-scaling
+    #      multi-rank run - config C4 read literally (global batch 8192, 1024 per GPU at N = 8)
+    extras = {}
+    if not args.no_extras and (world > 1 or not args.no_cpu):
+        if budget == 0:
+            P = run_config(args.scaling, args.pipelined_budget, args.steps, max(args.warmup, 2))
+            extras["pipelined_budget"] = {"iteration_budget": args.pipelined_budget, "handles": P["NH"], "value": P["value"], "unit": "solves/s",
+                                          "ms_per_step": P["ms_per_step"], "converged_frac": sum(p[0] for p in P["parts"]) / P["Bg"],
+                                          "gather_checked": P["gather_ok"],
+                                          "per_rank_ms_per_step": [p[4] for p in P["parts"]],
+                                          "note": "same batches, same results: at most %d iterations per launch, the instances that need more are "
+                                                  "finished by continuation launches on side streams while the next batches run (%d handles in "
+                                                  "rotation) - the throughput of a stream of batches does not wait for a batch's slowest instance; "
+                                                  "no roofline figure for this mode (the continuation runs beside the next launch)" % (args.pipelined_budget, P["NH"])}
+            del P
+        if world > 1 and args.scaling == "weak":
+            S = run_config("strong", 0, args.steps, max(args.warmup, 2))
+            extras["strong_scaling"] = {"value": S["value"], "unit": "solves/s", "ms_per_step": S["ms_per_step"], "global_batch": S["Bg"],
+                                        "batch_per_gpu": [int(p[6]) for p in S["parts"]], "max_iters_per_rank": [int(p[2]) for p in S["parts"]],
+                                        "converged_frac": sum(p[0] for p in S["parts"]) / S["Bg"], "gather_checked": S["gather_ok"],
+                                        "note": "BASELINE config C4 read literally: ONE seeded batch of %d instances sharded over the ranks "
+                                                "(contiguous slices) + the all-gather; a rank's time is its slowest instance" % S["Bg"]}
+            del S
 
     if rank == 0:
         ms_per_step = el / args.steps * 1e3
         value = Bg * args.steps / el
         mean_iters = it_sum / Bg
         k_ms = sum(step_ms) / len(step_ms)                 # this rank's solve kernel, average launch duration
-        fl = riccati_flops_per_iter(N, nx, nu, M, 4) * (float(iters.sum()) / Bl) * Bl
+        # (with --budget > 0 the timed launches execute at most `budget` iterations per instance; the rest runs in the
+        #  continuation launches beside the next step and is not part of this kernel's duration)
+        it_kernel = float(np.minimum(iters, budget).sum()) if budget > 0 else float(iters.sum())
+        fl = riccati_flops_per_iter(N, nx, nu, M, 4) * it_kernel
         achieved_tf = fl / (k_ms * 1e-3) / 1e12
         by = algorithmic_bytes_per_solve(N, nx, nu, M) * Bl
         traffic = None
@@ -292,8 +354,11 @@ def main():
                          "flops_per_iter": riccati_flops_per_iter(N, nx, nu, M, 4),
                          "hbm_achieved_GBs": by / (k_ms * 1e-3) / 1e9, "hbm_frac": by / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
+        res.update(extras)
+        if world > 1:
+            res["gather_checked"] = R["gather_ok"]        # every rank found its own records, bit for bit, in the gathered table
         ev0, ev1 = evs[0]
-        if world == 1 and not args.no_cpu:   # (--no-cpu = the profiler passes: they see the warm-up and timed launches only)
+        if world == 1 and not args.no_cpu and not args.no_extras:   # (--no-cpu = the profiler passes: they see the warm-up and timed launches only)
             # Extras, outside the timed region.  (1) the same launches in plain batch order (mode 0) and WITH the history hint
             # (mode 1, the engine's default): workgroups start longest-first by the iteration counts of the handle's previous
             # solve - exact here because the batch is re-solved, correlated in a receding-horizon loop.
@@ -424,6 +489,13 @@ def main():
                     res["stream_of_batches"] = stream_of_batches_extra(mm, robot, dev, local_dev, args.seed_base, N, M, Bl, nu, ctrl.xlim)
                 except Exception as e:
                     res["stream_of_batches"] = {"error": repr(e)}
+            # (7) config C5 (N = 30, 8 moving obstacles, warm-started receding horizon) in short form: `python bench.py --config c5`
+            # prints the full line
+            try:
+                res["c5"] = run_c5(args, torch, mm, None, 0, 1, dev, local_dev, steps=2, warmup=2, cpu_instances=256, compact=True)
+            except Exception as e:
+                res["c5"] = {"error": repr(e)}
+        if world == 1 and not args.no_cpu:
             res["cpu_baseline"] = cpu_baseline(d, N, M, min(args.cpu_sample, Bl), out["X"])
         print(json.dumps(res))
     if world > 1:
@@ -497,7 +569,7 @@ def c1_shape_extra(mm, robot, dev, B=2048, N=20):
     return out
 
 
-def cpu_baseline(d, N, M, ns, gpu_X, obs=None, u_last=None, x_init=None, traj=None):
+def cpu_baseline(d, N, M, ns, gpu_X, obs=None, u_last=None, x_init=None, traj=None, seconds=10.0):
     """The CPU restatement (oracle/mmpc_oracle.c, OpenMP over the batch) timed on the GPU box's host cores on a bounded
     sample of the same workload; `kind` is "port": the reference's own solver (CasADi/IPOPT) cannot be installed here."""
     from oracle import coracle, nlp
@@ -511,7 +583,7 @@ def cpu_baseline(d, N, M, ns, gpu_X, obs=None, u_last=None, x_init=None, traj=No
     coracle.lib()
     # bounded sample: passes over the sample until about 10 s of wall time on the host cores (at most 24 passes)
     c0 = time.perf_counter(); passes = 0
-    while passes < 24 and (passes == 0 or time.perf_counter() - c0 < 10.0):
+    while passes < 24 and (passes == 0 or time.perf_counter() - c0 < seconds):
         o = coracle.solve_batch(par, xi, tr, d["u_ref"][:ns], ul, ob, nthreads=cores, max_iter=2000)
         passes += 1
     ct = (time.perf_counter() - c0) / passes
@@ -528,27 +600,65 @@ def cpu_baseline(d, N, M, ns, gpu_X, obs=None, u_last=None, x_init=None, traj=No
 
 
 def main_c5(args):
-    """Config C5 (BASELINE.json configs[4]) on one GPU: N=30, M=8 moving obstacles (centre c + v (tick+k) dt at stage k:
-    the build's definition, no reference code exists), `--ticks` receding-horizon ticks, tick 0 cold, later ticks
-    warm-started per mpc_wholebody_qref.py:303,310 (U init = U_last = previous optimum, X init = tile(x_init)).
-    Plant step and local-reference window (interface_wholebody_qref.py:143,353-396) run as torch ops on the device.
-    One 'step' = all ticks; value = B*ticks / time."""
+    """`--config c5`: BASELINE.json configs[4] as its own bench line, on one GPU or - under torchrun - on N (one rank per GPU)."""
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     import mmpc_loader
     mm = mmpc_loader.load()
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    backend = os.environ.get("MMPC_BENCH_BACKEND", "nccl")
+    local_dev = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    res = run_c5(args, torch, mm, dist, rank, world, dev, local_dev, steps=args.steps, warmup=args.warmup,
+                 cpu_instances=0 if (args.no_cpu or world > 1) else 1024, compact=False)
+    if rank == 0:
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def run_c5(args, torch, mm, dist, rank, world, dev, local_dev, steps, warmup, cpu_instances, compact):
+    """Config C5 (BASELINE.json configs[4]): N=30, M=8 moving obstacles (centre c + v (tick+k) dt at stage k: the build's
+    definition, no reference code exists), `--ticks` receding-horizon ticks, tick 0 cold, later ticks warm-started per
+    mpc_wholebody_qref.py:303,310 (U init = U_last = previous optimum, X init = tile(x_init)).  Plant step and local-reference
+    window (interface_wholebody_qref.py:143,353-396) run as torch ops on the device.  One 'step' = all ticks;
+    value = robots x ticks / time.
+    N ranks: the robots are sharded like the instances of C4 - weak (default): every rank simulates its own `--batch` robots
+    (seed 5 + rank), strong: one population of `--batch` robots in contiguous slices -, every rank keeps its slice of u_latest
+    and of the robots' states resident, and the one exchange per tick is the all-gather of the first inputs u0 the closed loop
+    applies (5 doubles per robot), asynchronous: it travels while the next tick is solved."""
     from oracle import synth
-    dev = torch.device("cuda", 0)
-    torch.cuda.set_device(0)
-    N, M, B, T = 30, 8, args.batch, args.ticks
-    d = synth.make_batch(B, N=N, M=M, config_id=5, moving=True)
-    ctrl = mm.MPCWholeBody(mm.MobileManipulator(0.1), [], [], N=N, max_batch=B, n_obstacles=M, obs_per_stage=True)
+    from mmpc_amd import sharding
+    N, M, T = 30, 8, args.ticks
+    Bg = args.batch * (world if args.scaling == "weak" else 1)
+    lo, hi = sharding.shard_bounds(Bg, world, rank)
+    B = hi - lo
+    if args.scaling == "weak":
+        d = synth.make_batch(args.batch, N=N, M=M, config_id=5 + rank, moving=True)
+        sl = slice(0, B)
+    else:
+        d = synth.make_batch(Bg, N=N, M=M, config_id=5, moving=True)
+        sl = slice(lo, hi)
+    ctrl = mm.MPCWholeBody(mm.MobileManipulator(0.1), [], [], N=N, max_batch=max(B, 1), device=local_dev, n_obstacles=M, obs_per_stage=True)
     eng = ctrl._engine
     f64 = dict(dtype=torch.float64, device=dev)
-    x0 = torch.from_numpy(np.clip(d["x_init"], ctrl.xlim[0], ctrl.xlim[1])).to(dev)
-    glob = torch.from_numpy(d["traj_ref"]).to(dev)                       # first N+1=31 rows of the 51-row global plan
+    x0 = torch.from_numpy(np.clip(d["x_init"][sl], ctrl.xlim[0], ctrl.xlim[1])).to(dev)
+    glob = torch.from_numpy(np.ascontiguousarray(d["traj_ref"][sl])).to(dev)     # first N+1=31 rows of the 51-row global plan
     step = (glob[:, N] - glob[:, 0]) / N
     glob = glob[:, :1] + step[:, None, :] * torch.arange(51, **f64)[None, :, None]   # full 51-row straight-line plan
-    obs0 = torch.from_numpy(d["obs"]).to(dev); vel = torch.from_numpy(d["obs_vel"]).to(dev)
+    obs0 = torch.from_numpy(np.ascontiguousarray(d["obs"][sl])).to(dev); vel = torch.from_numpy(np.ascontiguousarray(d["obs_vel"][sl])).to(dev)
     uref = torch.zeros((B, N, 5), **f64)
     xlo = torch.from_numpy(ctrl.xlim[0]).to(dev); xhi = torch.from_numpy(ctrl.xlim[1]).to(dev)
     karr = torch.arange(N + 1, **f64)
@@ -561,11 +671,15 @@ def main_c5(args):
                             xc[:, 6] + 0.1 * u[:, 2], xc[:, 7] + 0.1 * u[:, 3], xc[:, 8] + 0.1 * u[:, 4]], dim=1)
 
     ug_buf = torch.zeros((B, N, 5), **f64); xg_buf = torch.zeros((B, N + 1, 9), **f64)
-
     evp = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(T)]
     cap = {}
+    # u0 of every robot of the job, gathered per tick (two buffer sets: the gather of tick t travels while tick t+1 is solved)
+    u0_loc = [torch.empty((B, 5), **f64) for _ in range(2)]
+    u0_all = [torch.empty((Bg, 5), **f64) for _ in range(2)]
+    pend = [None, None]
+    gather_ok = [True]
 
-    def run_all(shifted=False, timed=False):
+    def run_all(shifted=False, timed=False, check=False):
         """shifted=False: the reference's protocol (U starts at the previous optimum unshifted = U_last, X at tile(x_init),
         cold barrier parameter).  shifted=True: the engine's opt-in warm start (mmpc_set_warm_start) from tick 1 on - U starts
         at the previous optimum shifted by one stage, X at its roll-out, mu at 0.1; U_last, and with it the NLP, is unchanged."""
@@ -574,8 +688,8 @@ def main_c5(args):
         eng.set_warm_start(None, 1.0)
         eng.reset()      # forget the schedule hint of the previous pass: tick 0 is a first solve, later ticks are hinted by the tick before
         for t in range(T):
-            dist = torch.linalg.norm(x[:, None, :2] - glob[:, :, :2], dim=2)
-            start = torch.argmin(dist, dim=1)
+            dist_ = torch.linalg.norm(x[:, None, :2] - glob[:, :, :2], dim=2)
+            start = torch.argmin(dist_, dim=1)
             idx = torch.clamp(start[:, None] + torch.arange(N + 1, device=dev)[None, :], max=50)
             loc = torch.gather(glob, 1, idx[:, :, None].expand(B, N + 1, 9)).contiguous()
             obs = obs0[:, None, :, :].repeat(1, N + 1, 1, 1)
@@ -601,20 +715,46 @@ def main_c5(args):
                 cap["X%d" % t] = out["X"].clone()
             ul = out["U"].clone()
             u0 = out["U"][:, 0]
+            if world > 1:
+                b = t & 1
+                if pend[b] is not None:
+                    pend[b].wait(); pend[b] = None
+                u0_loc[b].copy_(u0)
+                _, pend[b] = sharding.allgather_solutions(u0_loc[b], Bg, dist, gathered=u0_all[b], async_op=True)
+                if check and t == T - 1:
+                    pend[b].wait(); pend[b] = None
+                    gather_ok[0] = gather_ok[0] and torch.equal(u0_all[b][lo:hi], u0_loc[b]) and bool(torch.isfinite(u0_all[b]).all())
             x = f_batch(torch.minimum(torch.maximum(x, xlo), xhi), u0)
-            its.append((out["iters"].double().mean(), (out["status"] == 0).double().mean(), out["iters"].max()))
+            its.append((out["iters"].double().mean() if B else torch.zeros((), **f64), (out["status"] == 0).double().sum(), out["iters"].max() if B else torch.zeros((), **f64)))
+        for b in range(2):
+            if pend[b] is not None:
+                pend[b].wait(); pend[b] = None
         return its
 
-    for _ in range(max(1, args.warmup // 2)):
-        run_all()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        its = run_all()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
+    def timed_passes(shifted):
+        for _ in range(max(1, warmup // 2)):
+            run_all(shifted=shifted)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            its = run_all(shifted=shifted)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([el], **f64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        return el, its
+
+    el, its = timed_passes(False)
     # kernel time and iteration totals of one more pass (HIP events around every tick's solve launch, on its stream)
-    its_k = run_all(timed=True)
+    its_k = run_all(timed=True, check=True)
     torch.cuda.synchronize()
     k_ms = [e0.elapsed_time(e1) for e0, e1 in evp]
     tot_iters = sum(float(a) for a, _, _ in its_k) * B
@@ -622,44 +762,63 @@ def main_c5(args):
     ach = fl_iter * tot_iters / (sum(k_ms) * 1e-3) / 1e12
     by = 8 * (9 + 9 * (N + 1) + 5 * N + 5 * N + 3 * M * (N + 1)) + 8 * (9 * (N + 1) + 5 * N + (N + 1))   # per solve, per-stage obstacle table
     # the opt-in warm start, timed the same way (reported beside the figure of the reference's protocol)
-    run_all(shifted=True)
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    for _ in range(args.steps):
-        its_w = run_all(shifted=True)
-    torch.cuda.synchronize()
-    el_w = time.perf_counter() - t1
+    el_w, its_w = timed_passes(True)
     eng.set_warm_start(None, 1.0)
-    res = {"metric": "MPC solves/sec, whole-body N=30 batch=%d, %d warm-started receding-horizon ticks, 8 moving obstacles" % (B, T),
-           "value": B * T * args.steps / el, "unit": "solves/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+    # per-rank summary (converged solves, slowest instance per tick)
+    conv_loc = torch.tensor([sum(float(b_) for _, b_, _ in its), float(B * T), max(float(c_) for _, _, c_ in its), sum(k_ms)], **f64)
+    if world > 1:
+        allp = [torch.zeros_like(conv_loc) for _ in range(world)]
+        dist.all_gather(allp, conv_loc)
+        allp = [p.tolist() for p in allp]
+        flag = torch.tensor([1.0 if gather_ok[0] else 0.0], **f64)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        gok = bool(flag.item() == 1.0)
+    else:
+        allp = [conv_loc.tolist()]
+        gok = None
+    res = {"metric": "MPC solves/sec, whole-body N=30 batch=%d, %d warm-started receding-horizon ticks, 8 moving obstacles" % (args.batch, T),
+           "value": Bg * T * steps / el, "unit": "solves/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+           "ms_per_step": el / steps * 1e3, "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None,
            "dtype": "f64", "data": "synthetic",
-           "config": {"workload": "C5: whole-body N=30, M=8 moving circle obstacles, batch %d, %d ticks (tick 0 cold; the launch "
-                                  "order of a tick is hinted by the iteration counts of the tick before)" % (B, T)},
+           "config": {"workload": "C5: whole-body N=30, M=8 moving circle obstacles, %d robots per GPU (global %d), %d ticks (tick 0 cold; the "
+                                  "launch order of a tick is hinted by the iteration counts of the tick before)" % (B, Bg, T),
+                      "batch_per_gpu": B, "parallelism": "robots sharded x%d%s" % (world, " + all-gather(u0) per tick" if world > 1 else "")},
            "roofline": {"bound": "mfma", "kernel": "mmpc_fast_kernel<0,30,8>", "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": ach / FP64_PEAK_TFLOPS, "traffic": _c5_traffic(), "kernel_ms_per_tick": k_ms, "flops_per_iter": fl_iter,
+                        "frac": ach / FP64_PEAK_TFLOPS, "traffic": _c5_traffic() if (world == 1 and B == 8192) else None, "kernel_ms_per_tick": k_ms, "flops_per_iter": fl_iter,
                         "hbm_achieved_GBs": by * B * T / (sum(k_ms) * 1e-3) / 1e9, "hbm_frac": by * B * T / (sum(k_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS},
-           "solver": {"mean_iters_per_tick": [float(a) for a, _, _ in its], "converged_frac_per_tick": [float(b) for _, b, _ in its],
+           "solver": {"mean_iters_per_tick": [float(a) for a, _, _ in its], "converged_frac": sum(p[0] for p in allp) / max(sum(p[1] for p in allp), 1.0),
                       "max_iters_per_tick": [int(c) for _, _, c in its],
                       "lds_bytes_per_problem": eng.lds_bytes, "problems_per_cu": eng.problems_per_cu},
-           "shifted_warm_start": {"value": B * T * args.steps / el_w, "unit": "solves/s", "ms_per_step": el_w / args.steps * 1e3,
+           "shifted_warm_start": {"value": Bg * T * steps / el_w, "unit": "solves/s", "ms_per_step": el_w / steps * 1e3,
                                   "mean_iters_per_tick": [float(a) for a, _, _ in its_w],
-                                  "converged_frac_per_tick": [float(b) for _, b, _ in its_w],
                                   "max_iters_per_tick": [int(c) for _, _, c in its_w],
                                   "note": "opt-in mmpc_set_warm_start: U guess = previous optimum shifted one stage, X guess = its "
                                           "roll-out (torch ops, inside the timed region), mu_init 0.1; same NLP, not the reference's protocol"}}
-    if not args.no_cpu:
-        # CPU leg: the same two captured ticks (the cold one and the last warm one), first 1024 instances, C oracle on the host cores
-        ns = min(1024, B)
+    if world > 1:
+        res["per_rank"] = [{"rank": r, "converged": int(p[0]), "solves": int(p[1]), "max_iters": int(p[2]), "kernel_ms_per_pass": p[3]} for r, p in enumerate(allp)]
+        res["gather_checked"] = gok
+    if cpu_instances > 0 and rank == 0:
+        # CPU leg: the same two captured ticks (the cold one and the last warm one), first instances, C oracle on the host cores
+        ns = min(cpu_instances, B)
         legs = []
         for t in (0, T - 1):
             dd = {"x_init": cap["x%d" % t].cpu().numpy(), "traj_ref": cap["loc%d" % t].cpu().numpy(), "u_ref": np.zeros((B, N, 5)),
                   "obs": cap["obs%d" % t].cpu().numpy()}
-            legs.append(cpu_baseline(dd, N, M, ns, cap["X%d" % t], u_last=cap["ul%d" % t].cpu().numpy()))
+            legs.append(cpu_baseline(dd, N, M, ns, cap["X%d" % t], u_last=cap["ul%d" % t].cpu().numpy(), seconds=4.0 if compact else 10.0))
         res["cpu_baseline"] = {"value": 2.0 / (1.0 / legs[0]["value"] + 1.0 / legs[1]["value"]), "unit": "solves/s", "cores": legs[0]["cores"],
                                "kind": "port", "sample": "ticks 0 and %d of the timed loop, first %d instances each: " % (T - 1, ns) + legs[0]["sample"],
                                "per_tick": legs, "casadi": legs[0]["casadi"]}
-    print(json.dumps(res))
+    if compact:
+        keep = ("value", "unit", "ms_per_step", "steps", "roofline", "cpu_baseline")
+        out = {k: res[k] for k in keep if k in res}
+        out["workload"] = res["config"]["workload"]
+        out["max_iters_per_tick"] = res["solver"]["max_iters_per_tick"]; out["mean_iters_per_tick"] = res["solver"]["mean_iters_per_tick"]
+        out["converged_frac"] = res["solver"]["converged_frac"]
+        out["shifted_warm_start_value"] = res["shifted_warm_start"]["value"]
+        if "cpu_baseline" in out:
+            out["cpu_baseline"] = {k: v for k, v in out["cpu_baseline"].items() if k != "per_tick"}
+        return out
+    return res
 
 
 def _c5_traffic():
