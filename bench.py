@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--config", default="c4", choices=["c4", "c5"],
                     help="c4: BASELINE metric (default). c5: N=30, 8 moving obstacles, warm-started receding horizon (1 GPU)")
     ap.add_argument("--ticks", type=int, default=10)
+    ap.add_argument("--async-budget", type=int, default=192, help="--config c5: iterations per launch of the asynchronous receding-horizon extra")
     args = ap.parse_args()
     if args.config == "c5":
         return main_c5(args)
@@ -564,7 +565,37 @@ def c1_shape_extra(mm, robot, dev, B=2048, N=20):
         e0.record(); o = eng.solve_batch_device(xi, trd, z, z, ob, out=o); e1.record(); e1.synchronize()
         ms = e0.elapsed_time(e1)
         out[name] = {"ms": ms, "value": B / (ms * 1e-3), "converged_frac": float((o["status"] == 0).double().mean()),
-                     "mean_iters": float(o["iters"].double().mean()), "lds_bytes_per_problem": eng.lds_bytes, "problems_per_cu": eng.problems_per_cu}
+                     "mean_iters": float(o["iters"].double().mean()), "max_iters": int(o["iters"].max()),
+                     "lds_bytes_per_problem": eng.lds_bytes, "problems_per_cu": eng.problems_per_cu}
+        if fc is None:
+            # the CPU port on the same shape (NLP as written), and the latency of ONE solve through the reference's own call
+            from oracle import coracle, nlp
+            avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            cores = min(avail, 16)
+            par = nlp.WholeBodyParams(N=N)
+            zc = np.zeros((B, N, 5))
+            c0 = time.perf_counter()
+            oc = coracle.solve_batch(par, x, tr, zc, zc, obs, hs=hs, as_written=True, nthreads=cores, max_iter=2000)
+            ct = time.perf_counter() - c0
+            gX = o["X"].cpu().numpy()
+            same = np.abs(oc["cost"] / o["cost"].cpu().numpy() - 1) < 1e-6
+            out["cpu_baseline"] = {"value": B / ct, "unit": "solves/s", "cores": cores, "kind": "port",
+                                   "sample": "the same %d starts, NLP as written, oracle/mmpc_oracle.c (OpenMP), one pass, %.1f s" % (B, ct),
+                                   "converged_frac": float((oc["status"] == 0).mean()), "same_minimum_as_gpu": int(same.sum()),
+                                   "max_abs_dX_vs_gpu_same_minimum": float(np.abs(gX[same] - oc["X"][same]).max())}
+            import contextlib, io
+            obst = [mm.Obstacles(*obs[0, m]) for m in range(3)]
+            one = mm.MPCWholeBody(robot, obst, oml, N=N)
+            lat = []
+            with contextlib.redirect_stdout(io.StringIO()):
+                for b in range(12):
+                    one.reset()
+                    l0 = time.perf_counter()
+                    one.solve(x[b].copy(), tr[b], np.zeros((N, 5)))
+                    lat.append(time.perf_counter() - l0)
+            out["single_solve_latency_ms"] = {"median": 1e3 * float(np.median(lat[2:])), "max": 1e3 * float(np.max(lat[2:])),
+                                              "note": "MPCWholeBody.solve() of the demo's controller (two planes, NLP as written) for one start: "
+                                                      "host arrays in, u0 out (10 solves, generic kernel)"}
         del ctrl, o
     return out
 
@@ -797,6 +828,33 @@ def run_c5(args, torch, mm, dist, rank, world, dev, local_dev, steps, warmup, cp
     if world > 1:
         res["per_rank"] = [{"rank": r, "converged": int(p[0]), "solves": int(p[1]), "max_iters": int(p[2]), "kernel_ms_per_pass": p[3]} for r, p in enumerate(allp)]
         res["gather_checked"] = gok
+    else:
+        # the same fleet driven asynchronously (mmpc_amd.fleet.DeviceFleet.run_async: iteration budget per launch, the robots that
+        # converge move on, the suspended ones are continued on a side stream and rejoin later), against the same class's lock step
+        try:
+            del ctrl, eng
+            fleet = mm.DeviceFleet(mm, x0, glob, obs0, vel, N=N, device=local_dev)
+            fa = {}
+            for mode in ("lockstep", "async"):
+                fn = (lambda: fleet.run_lockstep(T)) if mode == "lockstep" else (lambda: fleet.run_async(T, budget=args.async_budget))
+                fn(); torch.cuda.synchronize()
+                f0 = time.perf_counter()
+                for _ in range(steps):
+                    r_ = fn()
+                torch.cuda.synchronize()
+                fa[mode] = (time.perf_counter() - f0, r_)
+            same = bool(torch.equal(fa["lockstep"][1]["u0"], fa["async"][1]["u0"]) and torch.equal(fa["lockstep"][1]["x"], fa["async"][1]["x"]))
+            res["async_receding_horizon"] = {
+                "value": B * T * steps / fa["async"][0], "unit": "solves/s", "ms_per_step": fa["async"][0] / steps * 1e3,
+                "lockstep_value": B * T * steps / fa["lockstep"][0], "lockstep_ms_per_step": fa["lockstep"][0] / steps * 1e3,
+                "iteration_budget": args.async_budget, "rounds": fa["async"][1]["rounds"], "suspended_solves": int(fa["async"][1]["suspended"]),
+                "all_converged": bool(fa["async"][1]["all_converged"]), "bitwise_equal_to_lockstep": same,
+                "note": "same robots, same per-robot results: a launch gives a robot at most %d iterations; robots that converge take "
+                        "their plant step and are launched again in the next round (device-side list, mmpc_solve_list_device), suspended "
+                        "ones are continued on a side stream and rejoin two rounds later; the reference's warm-start protocol" % args.async_budget}
+            del fleet, fa
+        except Exception as e:
+            res["async_receding_horizon"] = {"error": repr(e)}
     if cpu_instances > 0 and rank == 0:
         # CPU leg: the same two captured ticks (the cold one and the last warm one), first instances, C oracle on the host cores
         ns = min(cpu_instances, B)
@@ -809,7 +867,7 @@ def run_c5(args, torch, mm, dist, rank, world, dev, local_dev, steps, warmup, cp
                                "kind": "port", "sample": "ticks 0 and %d of the timed loop, first %d instances each: " % (T - 1, ns) + legs[0]["sample"],
                                "per_tick": legs, "casadi": legs[0]["casadi"]}
     if compact:
-        keep = ("value", "unit", "ms_per_step", "steps", "roofline", "cpu_baseline")
+        keep = ("value", "unit", "ms_per_step", "steps", "roofline", "cpu_baseline", "async_receding_horizon")
         out = {k: res[k] for k in keep if k in res}
         out["workload"] = res["config"]["workload"]
         out["max_iters_per_tick"] = res["solver"]["max_iters_per_tick"]; out["mean_iters_per_tick"] = res["solver"]["mean_iters_per_tick"]

@@ -112,6 +112,19 @@ int mmpc_solve_batch_device(mmpc_handle h, int B, const double *d_x_init, const 
                             const double *d_obs, double *d_X, double *d_U, double *d_s, int *d_status, int *d_iters,
                             double *d_cost, double *d_err, void *stream);
 
+/* List launch (specialised kernels; no reference counterpart): the same solve for the instances d_list[0 .. *d_count - 1] only -
+ * row indices into the B-row arrays, every index at most once; list and count live in DEVICE memory (the count is read by the
+ * kernel: a caller that builds the list on the device never has to synchronise), `capacity` (<= B) bounds the count and is the
+ * size of the grid.  Rows that are not listed are neither read nor written.  Instances start in list order (put the ones that
+ * are expected to take longest first); the handle's schedule hint is not used and not updated.  With an iteration budget set the
+ * listed instances that need more are suspended as in mmpc_solve_batch_device and mmpc_resume_batch_device (same B) continues
+ * exactly them.  What it is for: a receding-horizon loop over many robots in which the robots whose solve is finished advance
+ * to their next tick while the few suspended ones are still being continued on another stream (bench.py --config c5). */
+int mmpc_solve_list_device(mmpc_handle h, int B, const int *d_list, const int *d_count, int capacity, const double *d_x_init,
+                           const double *d_traj_ref, const double *d_u_ref, const double *d_u_last, const double *d_x_guess,
+                           const double *d_obs, double *d_X, double *d_U, double *d_s, int *d_status, int *d_iters,
+                           double *d_cost, double *d_err, void *stream);
+
 /* warm start access (self.u_latest, mpc_wholebody_qref.py:165,330): host <-> device copies */
 int mmpc_get_u_latest(mmpc_handle h, int B, double *u_latest);
 int mmpc_set_u_latest(mmpc_handle h, int B, const double *u_latest);

@@ -20,7 +20,8 @@ from .controllers.mpc_wholebody import MPCWholeBody as MPCWholeBodyPoseRef
 from . import _capi
 from . import interface_wholebody_qref
 from .interface_wholebody_qref import BatchedRecedingHorizon, Interface
+from .fleet import DeviceFleet
 from .build import build_extension
 
 __all__ = ["Obstacles", "Base", "ManipulatorPanda3DoF", "MobileManipulator", "MPCWholeBody", "MPCBase", "MPCWholeBodyPoseRef",
-           "build_extension", "_capi", "BatchedRecedingHorizon", "Interface", "interface_wholebody_qref"]
+           "build_extension", "_capi", "BatchedRecedingHorizon", "Interface", "interface_wholebody_qref", "DeviceFleet"]

@@ -23,7 +23,7 @@ class MmpcConfig(C.Structure):
 
 EXPORTS = ["mmpc_create", "mmpc_destroy", "mmpc_set_weights", "mmpc_set_terminal_xy_equality", "mmpc_reset",
            "mmpc_solve_batch", "mmpc_solve_batch_device", "mmpc_get_u_latest", "mmpc_set_u_latest",
-           "mmpc_lds_bytes", "mmpc_problems_per_cu", "mmpc_set_warm_start", "mmpc_set_schedule_hint", "mmpc_set_iteration_budget", "mmpc_resume_batch_device", "mmpc_suspended_count", "mmpc_last_error", "mmpc_version", "mmpc_ik_batch", "mmpc_ik_batch_device"]
+           "mmpc_lds_bytes", "mmpc_problems_per_cu", "mmpc_set_warm_start", "mmpc_set_schedule_hint", "mmpc_set_iteration_budget", "mmpc_resume_batch_device", "mmpc_solve_list_device", "mmpc_suspended_count", "mmpc_last_error", "mmpc_version", "mmpc_ik_batch", "mmpc_ik_batch_device"]
 
 _lib = None
 _dp = C.POINTER(C.c_double)
@@ -61,6 +61,7 @@ def lib():
         L.mmpc_set_schedule_hint.argtypes = [C.c_void_p, C.c_int]
         L.mmpc_set_iteration_budget.argtypes = [C.c_void_p, C.c_int]
         L.mmpc_resume_batch_device.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 13 + [C.c_void_p]
+        L.mmpc_solve_list_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 13 + [C.c_void_p]
         L.mmpc_suspended_count.argtypes = [C.c_void_p, _ip]
         L.mmpc_last_error.argtypes = [C.c_void_p]
         L.mmpc_last_error.restype = C.c_char_p
@@ -233,10 +234,14 @@ class Engine:
         u = np.ascontiguousarray(u, float)
         self._chk(lib().mmpc_set_u_latest(self._h, u.shape[0], _d(u)), "mmpc_set_u_latest")
 
-    def solve_batch_device(self, x_init, traj_ref, u_ref, u_last, obs, x_guess=None, out=None, stream=None, resume=False):
+    def solve_batch_device(self, x_init, traj_ref, u_ref, u_last, obs, x_guess=None, out=None, stream=None, resume=False, rows=None):
         """torch CUDA float64 tensors in / out, asynchronous on torch's current stream (or `stream`).
-        PyTorch is only the owner of the device memory and of the stream here."""
+        PyTorch is only the owner of the device memory and of the stream here.
+        rows = (list, count): mmpc_solve_list_device - only the instances list[0 .. count[0]-1] (int32 cuda tensors: a list of
+        row indices and a one-element count, both read on the device) are solved, in list order; the other rows are not touched."""
         import torch
+        if rows is not None and (out is None or resume):
+            raise ValueError("a list launch needs the output set of the whole batch (out=...) and is not a continuation")
         N, nx, nu = self.N, self.nx, self.nu
         B = x_init.shape[0]
         for t_, shp in ((x_init, (B, nx)), (traj_ref, (B, N + 1, self.nref)), (u_ref, (B, N, nu)), (u_last, (B, N, nu))):
@@ -263,6 +268,15 @@ class Engine:
                        err=torch.empty(B, dtype=torch.float64, device=dev))
         st = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
         p = lambda t_: C.c_void_p(t_.data_ptr()) if t_ is not None else None
+        if rows is not None:
+            lst, cnt = rows
+            for t_ in (lst, cnt):
+                if t_.dtype != torch.int32 or not t_.is_cuda or not t_.is_contiguous() or t_.device != dev:
+                    raise ValueError("rows = (list, count): contiguous int32 tensors on %s" % dev)
+            self._chk(lib().mmpc_solve_list_device(self._h, B, p(lst), p(cnt), int(min(lst.numel(), B)), p(x_init), p(traj_ref), p(u_ref), p(u_last),
+                                                   p(x_guess), p(obs), p(out["X"]), p(out["U"]), p(out["s"]), p(out["status"]),
+                                                   p(out["iters"]), p(out["cost"]), p(out["err"]), C.c_void_p(st)), "mmpc_solve_list_device")
+            return out
         fn = lib().mmpc_resume_batch_device if resume else lib().mmpc_solve_batch_device
         self._chk(fn(self._h, B, p(x_init), p(traj_ref), p(u_ref), p(u_last), p(x_guess),
                      p(obs), p(out["X"]), p(out["U"]), p(out["s"]), p(out["status"]),

@@ -96,14 +96,17 @@ __global__ __launch_bounds__(MMPC_WAVE, WPE) void mmpc_fast_kernel(
     const double *__restrict__ u_ref, const double *__restrict__ u_last, const double *__restrict__ x_guess,
     const double *__restrict__ obs, double *__restrict__ X, double *__restrict__ U, double *__restrict__ s,
     int *__restrict__ status, int *__restrict__ iters, double *__restrict__ cost, double *__restrict__ err,
-    const int *__restrict__ order, int budget, double *__restrict__ state, int state_stride, const int *__restrict__ resume_count) {
+    const int *__restrict__ order, int budget, double *__restrict__ state, int state_stride, const int *__restrict__ resume_count,
+    const int *__restrict__ list_count) {
     __shared__ double lds[mmpc_fast_layout<KIND, N>(MC, OPS).total];
     typedef MmpcDims<KIND> D;
     // A continuation launch (resume_count != null): `order` is the compacted list of the suspended instances, *resume_count its
     // length, and the grid is SMALL (MMPC_RESUME_GRID workgroups that stride over the list): a handful of instances is left,
     // and a grid of B workgroups that almost all exit at once would still have to be dispatched one by one - in a stream of
     // batches that competes with the next batch's launch.
-    const int limit = resume_count ? *resume_count : B;
+    // A list launch (list_count != null, mmpc_solve_list_device): `order` is the caller's list of instances, *list_count its length
+    // (read on the device: the caller need not know it), the grid is the list's capacity.
+    const int limit = resume_count ? *resume_count : (list_count ? *list_count : B);
     for (int w = (int)blockIdx.x; w < limit; w += (int)gridDim.x) {
         // launch order: workgroup i solves instance order[i] (a permutation / a list; results do not depend on it)
         const int b = order ? order[w] : w;
@@ -160,6 +163,13 @@ __global__ __launch_bounds__(256) void mmpc_collect_suspended(int B, const int *
                                                              int *__restrict__ count) {
     const int b = blockIdx.x * 256 + threadIdx.x;
     if (b < B && status[b] == MMPC_STATUS_SUSPENDED) list[atomicAdd(count, 1)] = b;
+}
+
+// the same over a list of instances (list launches): only the listed ones can have been suspended by the launch before
+__global__ __launch_bounds__(256) void mmpc_collect_suspended_list(const int *__restrict__ in_list, const int *__restrict__ in_count,
+                                                                  const int *__restrict__ status, int *__restrict__ list, int *__restrict__ count) {
+    const int w = blockIdx.x * 256 + threadIdx.x;
+    if (w < *in_count) { const int b = in_list[w]; if (status[b] == MMPC_STATUS_SUSPENDED) list[atomicAdd(count, 1)] = b; }
 }
 
 // A-priori difficulty of an instance, from its data alone: how close the reference path comes to (or how deep it cuts
@@ -481,7 +491,8 @@ extern "C" int mmpc_reset(mmpc_handle h) {
 
 static int launch(mmpc_handle h, int B, const double *x_init, const double *traj, const double *uref, const double *ulast,
                   const double *xguess, const double *obs, double *X, double *U, double *s, int *status, int *iters,
-                  double *cost, double *err, hipStream_t st, bool resume = false) {
+                  double *cost, double *err, hipStream_t st, bool resume = false, const int *ulist = nullptr, const int *ucount = nullptr,
+                  int ucap = 0) {
     // (the X guess is a launch argument: null = tile(x_init); nothing in the device parameter block changes per launch)
     // a launch on another stream than the previous one waits for it: both touch the handle's schedule hint
     if (h->ev_valid && st != h->last_stream) HIPCHK(h, hipStreamWaitEvent(st, h->ev, 0));
@@ -493,24 +504,27 @@ static int launch(mmpc_handle h, int B, const double *x_init, const double *traj
     h->resume_B = 0;
     // launch order of the workgroups (results do not depend on it): the iteration counts of the handle's previous launch of
     // this batch size when there are any and the mode allows them, else the a-priori difficulty key of THIS batch's data
-    const bool lpt = !resume && h->hint_on && !h->no_lpt_env && B <= h->cfg.max_batch && B > 256;
+    if (ulist && !use_fast) return fail(h, MMPC_E_UNSUPPORTED, "%s%s", "list launches need a specialised kernel (this (kind, N, M, weights) runs the generic one)");
+    const bool lpt = !resume && !ulist && h->hint_on && !h->no_lpt_env && B <= h->cfg.max_batch && B > 256;
     const bool history = lpt && h->hint_on == 1 && h->order_B == B;
     if (lpt && !history && h->cfg.M > 0) {
         hipLaunchKernelGGL(mmpc_difficulty_key, dim3((B + 63) / 64), dim3(64), 0, st, B, h->cfg.N, h->cfg.M, h->nref,
                            h->hp.obs_per_stage, traj, obs, h->d_key);
         hipLaunchKernelGGL(mmpc_lpt_order, dim3(1), dim3(1024), 0, st, B, h->d_key, h->d_order);
     }
-    const int *order = (history || (lpt && h->cfg.M > 0)) ? h->d_order : nullptr;
+    const int *order = ulist ? ulist : ((history || (lpt && h->cfg.M > 0)) ? h->d_order : nullptr);
+    const int grid = ulist ? ucap : B;
     if (use_fast) {
 #define MMPC_LAUNCH_FAST(K, NN, MM, WW, OPS)                                                                              \
             if (resume || h->budget > 0)                                                                                               \
-                hipLaunchKernelGGL((mmpc_fast_kernel<K, NN, MM, WW, true, OPS>), dim3(resume ? (B < MMPC_RESUME_GRID ? B : MMPC_RESUME_GRID) : B), dim3(MMPC_WAVE), 0, st, h->dp, B, \
+                hipLaunchKernelGGL((mmpc_fast_kernel<K, NN, MM, WW, true, OPS>), dim3(resume ? (B < MMPC_RESUME_GRID ? B : MMPC_RESUME_GRID) : grid), dim3(MMPC_WAVE), 0, st, h->dp, B, \
                                    x_init, traj, uref, ulast, xguess, obs, X, U, s, status, iters, cost, err, resume ? h->d_list : order, \
-                                   resume ? 0 : h->budget, h->d_state, h->state_doubles, resume ? h->d_count : (const int *)nullptr);   \
+                                   resume ? 0 : h->budget, h->d_state, h->state_doubles, resume ? h->d_count : (const int *)nullptr,      \
+                                   resume ? (const int *)nullptr : ucount);                                                               \
             else                                                                                                                       \
-                hipLaunchKernelGGL((mmpc_fast_kernel<K, NN, MM, WW, false, OPS>), dim3(B), dim3(MMPC_WAVE), 0, st, h->dp, B,              \
+                hipLaunchKernelGGL((mmpc_fast_kernel<K, NN, MM, WW, false, OPS>), dim3(grid), dim3(MMPC_WAVE), 0, st, h->dp, B,           \
                                    x_init, traj, uref, ulast, xguess, obs, X, U, s, status, iters, cost, err, order, 0,                  \
-                                   (double *)nullptr, 0, (const int *)nullptr);
+                                   (double *)nullptr, 0, (const int *)nullptr, ucount);
 #define MMPC_X(K, NN, MM, WW)                                                                                          \
         if (h->cfg.kind == K && h->cfg.N == NN && h->cfg.M == MM) {                                                   \
             if (h->cfg.obs_per_stage) { MMPC_LAUNCH_FAST(K, NN, MM, WW, 1) } else { MMPC_LAUNCH_FAST(K, NN, MM, WW, 0) }   \
@@ -538,7 +552,8 @@ static int launch(mmpc_handle h, int B, const double *x_init, const double *traj
     if (use_fast && h->budget > 0 && !resume) {
         // who is suspended: compacted list for mmpc_resume_batch_device
         HIPCHK(h, hipMemsetAsync(h->d_count, 0, 4, st));
-        hipLaunchKernelGGL(mmpc_collect_suspended, dim3((B + 255) / 256), dim3(256), 0, st, B, status, h->d_list, h->d_count);
+        if (ulist) hipLaunchKernelGGL(mmpc_collect_suspended_list, dim3((ucap + 255) / 256), dim3(256), 0, st, ulist, ucount, status, h->d_list, h->d_count);
+        else hipLaunchKernelGGL(mmpc_collect_suspended, dim3((B + 255) / 256), dim3(256), 0, st, B, status, h->d_list, h->d_count);
         h->resume_B = B;
     }
     if (lpt && h->hint_on == 1) {
@@ -620,6 +635,18 @@ extern "C" int mmpc_solve_batch_device(mmpc_handle h, int B, const double *d_x_i
     HIPCHK(h, hipSetDevice(h->cfg.device));
     return launch(h, B, d_x_init, d_traj_ref, d_u_ref, d_u_last, d_x_guess, d_obs ? d_obs : h->d_obs, d_X, d_U, d_s,
                   d_status, d_iters, d_cost, d_err, (hipStream_t)stream);
+}
+
+extern "C" int mmpc_solve_list_device(mmpc_handle h, int B, const int *d_list, const int *d_count, int capacity, const double *d_x_init,
+                                      const double *d_traj_ref, const double *d_u_ref, const double *d_u_last, const double *d_x_guess,
+                                      const double *d_obs, double *d_X, double *d_U, double *d_s, int *d_status, int *d_iters,
+                                      double *d_cost, double *d_err, void *stream) {
+    if (!h || B < 1 || B > h->cfg.max_batch || !d_list || !d_count || capacity < 1 || capacity > B || !d_x_init || !d_traj_ref || !d_u_ref ||
+        !d_u_last || !d_X || !d_U || !d_s || !d_status || !d_iters || !d_cost || !d_err || (h->cfg.M > 0 && !d_obs))
+        return fail(h, MMPC_E_ARG, "mmpc_solve_list_device: %s%s", "bad argument (B in 1..max_batch, 1 <= capacity <= B)");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    return launch(h, B, d_x_init, d_traj_ref, d_u_ref, d_u_last, d_x_guess, d_obs ? d_obs : h->d_obs, d_X, d_U, d_s,
+                  d_status, d_iters, d_cost, d_err, (hipStream_t)stream, false, d_list, d_count, capacity);
 }
 
 extern "C" int mmpc_solve_batch(mmpc_handle h, int B, const double *x_init, const double *traj_ref, const double *u_ref,

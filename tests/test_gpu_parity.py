@@ -394,3 +394,30 @@ def test_empty_single_and_ragged_batches(mm):
         ctrl.reset()
         r = ctrl.solve_batch(xi[sl], d["traj_ref"][sl], d["u_ref"][sl], d["obs"][sl])
         assert np.array_equal(r["X"], r9["X"][sl]) and np.array_equal(r["U"], r9["U"][sl]) and np.array_equal(r["iters"], r9["iters"][sl])
+
+
+@pytest.mark.gpu
+def test_asynchronous_receding_horizon_equals_lock_step(mm):
+    """C5's fleet (N = 30, 8 moving obstacles, warm start per mpc_wholebody_qref.py:301-310) driven two ways by
+    mmpc_amd.fleet.DeviceFleet: all robots tick by tick, and asynchronously - every launch gives a robot at most 24 iterations
+    (mmpc_set_iteration_budget), the robots that converge move on to their next tick at once (mmpc_solve_list_device), the
+    suspended ones are continued on a side stream (mmpc_resume_batch_device) and rejoin later.  Every robot's sequence of
+    first inputs, its iteration counts and its final state are bitwise the same."""
+    import torch
+    B, N, M, T = 1024, 30, 8, 6
+    d = synth.make_batch(B, N=N, M=M, config_id=5, moving=True)
+    par = nlp.WholeBodyParams(N=N)
+    dev = torch.device("cuda", 0)
+    glob = torch.from_numpy(d["traj_ref"]).to(dev)
+    step = (glob[:, N] - glob[:, 0]) / N
+    glob = glob[:, :1] + step[:, None, :] * torch.arange(51, dtype=torch.float64, device=dev)[None, :, None]
+    fleet = mm.DeviceFleet(mm, np.clip(d["x_init"], par.xlim[0], par.xlim[1]), glob, d["obs"], d["obs_vel"], N=N)
+    a = fleet.run_lockstep(T)
+    b = fleet.run_async(T, budget=24)
+    torch.cuda.synchronize()
+    assert bool(a["all_converged"]) and bool(b["all_converged"])
+    assert int(b["suspended"]) > 0 and b["rounds"] > T            # some robots were suspended and fell a round behind
+    assert torch.equal(a["u0"], b["u0"]) and torch.equal(a["x"], b["x"]) and torch.equal(a["iters"], b["iters"])
+    # and once more with another budget: the split of a solve into launches does not matter
+    c = fleet.run_async(T, budget=40)
+    assert bool(c["all_converged"]) and torch.equal(a["u0"], c["u0"]) and torch.equal(a["x"], c["x"])
