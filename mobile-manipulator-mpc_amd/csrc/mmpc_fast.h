@@ -320,6 +320,9 @@ struct MmpcLaneState {
                                                      // (set once per roll-out: the lane id is opaque to the compiler in every phase)
 };
 
+#ifndef MMPC_RED_DPP
+#define MMPC_RED_DPP 1   // wave reductions through DPP / permlane swaps (steps 1..32) instead of ds_bpermute butterflies (steps 32..1)
+#endif
 #ifndef MMPC_EMU
 // broadcast of lane j's value to the whole wave through scalar registers (v_readlane_b32 x 2; j is a constant)
 MMPC_DEV double mmpc_readlane_f64(double v, int j) {
@@ -335,6 +338,39 @@ MMPC_DEV double mmpc_xor16_f64(double v, int lane) {
     const bool odd = (lane >> 4) & 1;
     return __hiloint2double(odd ? b[0] : b[1], odd ? a[0] : a[1]);
 }
+// Wave-wide reductions as a butterfly over the steps 1, 2, 4, 8, 16, 32 without the LDS crossbar (ds_bpermute: 57 cycles per
+// step, tools/lat_probe.hip): the partner's value comes through DPP inside a row of 16 lanes (quad permutes for 1 and 2;
+// for 4 and 8 the half-row / row MIRROR - lane 7-i resp. 15-i holds the same value as lane i^4 resp. i^8 at that point, the
+// lanes of a reduced group being bitwise equal) and through v_permlane16_swap / v_permlane32_swap across rows.  Every lane
+// ends with the same bits (the combine is commutative), which the host emulation reproduces (mmpc_emu_red).
+#if MMPC_RED_DPP
+template <int CTRL>
+MMPC_DEV double mmpc_dpp_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+MMPC_DEV double mmpc_xor32_f64(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    const bool up = (mmpc_lane_id() >> 5) & 1;
+    return __hiloint2double(up ? b[0] : b[1], up ? a[0] : a[1]);
+}
+#define MMPC_WAVE_RED(NAME, OP)                                                                              \
+MMPC_DEV double NAME(double v) {                                                                             \
+    v = OP(v, mmpc_dpp_f64<0xB1>(v));    /* quad_perm [1,0,3,2]: lane ^ 1 */                                  \
+    v = OP(v, mmpc_dpp_f64<0x4E>(v));    /* quad_perm [2,3,0,1]: lane ^ 2 */                                  \
+    v = OP(v, mmpc_dpp_f64<0x141>(v));   /* row_half_mirror: the other quad of the 8 */                       \
+    v = OP(v, mmpc_dpp_f64<0x140>(v));   /* row_mirror: the other half of the row */                          \
+    v = OP(v, mmpc_xor16_f64(v, mmpc_lane_id()));                                                             \
+    v = OP(v, mmpc_xor32_f64(v));                                                                             \
+    return v; }
+MMPC_DEV double mmpc_op_add(double a, double b) { return a + b; }
+MMPC_WAVE_RED(mmpc_wave_sum, mmpc_op_add)
+MMPC_WAVE_RED(mmpc_wave_max, mmpc_vmax)
+MMPC_WAVE_RED(mmpc_wave_min, mmpc_vmin)
+#else
 MMPC_DEV double mmpc_wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -350,6 +386,7 @@ MMPC_DEV double mmpc_wave_min(double v) {
     for (int o = 32; o > 0; o >>= 1) v = mmpc_vmin(v, __shfl_xor(v, o));
     return v;
 }
+#endif
 #define MMPC_RED_SUM(i) mmpc_wave_sum(wr_one[i])
 #define MMPC_RED_MAX(i) mmpc_wave_max(wr_one[i])
 #define MMPC_RED_MIN(i) mmpc_wave_min(wr_one[i])
@@ -359,9 +396,12 @@ MMPC_DEV double mmpc_wave_min(double v) {
 static inline double mmpc_emu_red(double (*wr)[8], int i, int op) {
     double v[MMPC_WAVE], w[MMPC_WAVE];
     for (int l = 0; l < MMPC_WAVE; l++) v[l] = wr[l][i];
-    for (int o = 32; o > 0; o >>= 1) {
+    for (int q = 0; q < 6; q++) {
+        const int o = MMPC_RED_DPP ? (1 << q) : (32 >> q);
         for (int l = 0; l < MMPC_WAVE; l++) {
-            const double a = v[l], b = v[l ^ o];
+            // partner of the device butterfly: lane ^ 1, ^ 2, the mirror inside 8 / 16 lanes, lane ^ 16, ^ 32  (ds_bpermute form: lane ^ o)
+            const int p = !MMPC_RED_DPP ? (l ^ o) : (o == 4 ? ((l & ~7) | (7 - (l & 7))) : (o == 8 ? ((l & ~15) | (15 - (l & 15))) : (l ^ o)));
+            const double a = v[l], b = v[p];
             w[l] = op == 0 ? a + b : (op == 1 ? (a > b ? a : b) : (a < b ? a : b));
         }
         for (int l = 0; l < MMPC_WAVE; l++) v[l] = w[l];
