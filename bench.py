@@ -276,18 +276,23 @@ def main():
     # ---- collective extras (every rank takes part): the pipelined-budget mode on the same batches, and - in a weak-scaling
     #      multi-rank run - config C4 read literally (global batch 8192, 1024 per GPU at N = 8)
     extras = {}
-    if not args.no_extras and (world > 1 or not args.no_cpu):
+
+    def pipelined_extra():
+        P = run_config(args.scaling, args.pipelined_budget, args.steps, max(args.warmup, 2))
+        r_ = {"iteration_budget": args.pipelined_budget, "handles": P["NH"], "value": P["value"], "unit": "solves/s",
+              "ms_per_step": P["ms_per_step"], "converged_frac": sum(p[0] for p in P["parts"]) / P["Bg"],
+              "gather_checked": P["gather_ok"],
+              "per_rank_ms_per_step": [p[4] for p in P["parts"]],
+              "note": "same batches, same results: at most %d iterations per launch, the instances that need more are "
+                      "finished by continuation launches on side streams while the next batches run (%d handles in "
+                      "rotation) - the throughput of a stream of batches does not wait for a batch's slowest instance; "
+                      "no roofline figure for this mode (the continuation runs beside the next launch)" % (args.pipelined_budget, P["NH"])}
+        del P
+        return r_
+
+    if not args.no_extras and world > 1:
         if budget == 0:
-            P = run_config(args.scaling, args.pipelined_budget, args.steps, max(args.warmup, 2))
-            extras["pipelined_budget"] = {"iteration_budget": args.pipelined_budget, "handles": P["NH"], "value": P["value"], "unit": "solves/s",
-                                          "ms_per_step": P["ms_per_step"], "converged_frac": sum(p[0] for p in P["parts"]) / P["Bg"],
-                                          "gather_checked": P["gather_ok"],
-                                          "per_rank_ms_per_step": [p[4] for p in P["parts"]],
-                                          "note": "same batches, same results: at most %d iterations per launch, the instances that need more are "
-                                                  "finished by continuation launches on side streams while the next batches run (%d handles in "
-                                                  "rotation) - the throughput of a stream of batches does not wait for a batch's slowest instance; "
-                                                  "no roofline figure for this mode (the continuation runs beside the next launch)" % (args.pipelined_budget, P["NH"])}
-            del P
+            extras["pipelined_budget"] = pipelined_extra()
         if world > 1 and args.scaling == "weak":
             S = run_config("strong", 0, args.steps, max(args.warmup, 2))
             extras["strong_scaling"] = {"value": S["value"], "unit": "solves/s", "ms_per_step": S["ms_per_step"], "global_batch": S["Bg"],
@@ -490,6 +495,13 @@ def main():
                     res["stream_of_batches"] = stream_of_batches_extra(mm, robot, dev, local_dev, args.seed_base, N, M, Bl, nu, ctrl.xlim)
                 except Exception as e:
                     res["stream_of_batches"] = {"error": repr(e)}
+            # (6b) the pipelined-budget mode on the headline's own batch (the collective extra of the multi-rank runs, here at N = 1;
+            # after the other extras: its side streams would otherwise take the hardware queues of theirs)
+            if budget == 0:
+                try:
+                    res["pipelined_budget"] = pipelined_extra()
+                except Exception as e:
+                    res["pipelined_budget"] = {"error": repr(e)}
             # (7) config C5 (N = 30, 8 moving obstacles, warm-started receding horizon) in short form: `python bench.py --config c5`
             # prints the full line
             try:
