@@ -241,12 +241,40 @@ MMPC_DEV void mmpc_prox_update(double alpha, double &prox, int &nsmall) {
 }
 MMPC_DEV bool mmpc_finite(double v) { return fabs(v) < 1.0e300; }
 
+// ---- light-weight sincos (both kernels; the generic one used the library routine until round 3) ------------
+// sin/cos: Cody-Waite reduction by pi/2 (three-part constant, exact for |x| < ~1e6 rad: heading and
+// joint angles stay far below that) + the fdlibm kernel polynomials on [-pi/4, pi/4] (< 1 ulp).
+// The library sincos carries a Payne-Hanek path that costs ~700 instructions per call site.
+MMPC_DEV void mmpc_sincos(double x, double *sn, double *cs) {
+    const double n = rint(x * 6.36619772367581382433e-01);
+    double r = fma(-n, 1.57079632673412561417e+00, x);
+    r = fma(-n, 6.07710050630396597660e-11, r);
+    r = fma(-n, 2.02226624879595063154e-21, r);
+    const double z = r * r;
+    const double ps = fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08),
+                      2.75573137070700676789e-06), -1.98412698298579493134e-04), 8.33333333332248946124e-03),
+                      -1.66666666666666324348e-01);
+    const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09),
+                      -2.75573143513906633035e-07), 2.48015872894767294178e-05), -1.38888888888741095749e-03),
+                      4.16666666666666019037e-02);
+    const double s0 = fma(r * z, ps, r);
+    const double c0 = fma(z * z, pc, fma(-0.5, z, 1.0));
+    const int q = (int)n & 3;
+    const double sa = (q & 1) ? c0 : s0, ca = (q & 1) ? s0 : c0;
+    *sn = (q & 2) ? -sa : sa;
+    *cs = ((q + 1) & 2) ? -ca : ca;
+}
+#ifndef MMPC_LIBM_SINCOS
+#define MMPC_SINCOS(x, s, c) mmpc_sincos((x), (s), (c))
+#else
+#define MMPC_SINCOS(x, s, c) sincos((x), (s), (c))
+#endif
 // planar arm segments, manipulator_3DoF.py:29-73 collapsed with A=q1-q2, B=q1-q2-q3
 MMPC_DEV void mmpc_arm_segments(double q1, double q2, double q3, double dr[3], double dz[3]) {
     double s1, c1, sA, cA, sB, cB;
-    sincos(q1, &s1, &c1);
-    sincos(q1 - q2, &sA, &cA);
-    sincos(q1 - q2 - q3, &sB, &cB);
+    MMPC_SINCOS(q1, &s1, &c1);
+    MMPC_SINCOS(q1 - q2, &sA, &cA);
+    MMPC_SINCOS(q1 - q2 - q3, &sB, &cB);
     dr[0] = MMPC_A2 * s1 + MMPC_A3 * c1;
     dz[0] = MMPC_A2 * c1 - MMPC_A3 * s1;
     dr[1] = -MMPC_A3 * cA + MMPC_A5 * sA;
@@ -404,7 +432,7 @@ MMPC_DEV double mmpc_state_cost(const double *WTS, bool terminal, const double *
         return q;
     } else {
     double sn, cs, dr[3], dz[3];
-    sincos(xk[2], &sn, &cs);
+    MMPC_SINCOS(xk[2], &sn, &cs);
     mmpc_arm_segments(xk[NX - 3], xk[NX - 2], xk[NX - 1], dr, dz);
     const double R = MMPC_BX + dr[0] + dr[1] + dr[2], Z = MMPC_BZ + dz[0] + dz[1] + dz[2];
     const double e[4] = {xk[0] + R * cs - ref[0], xk[1] + R * sn - ref[1], Z - ref[2], xk[2] - ref[3]};
@@ -578,14 +606,14 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
         }
         if (NSELF) {
             double dr[3], dz[3], sn, cs;
-            sincos(xk[2], &sn, &cs);
+            MMPC_SINCOS(xk[2], &sn, &cs);
             mmpc_arm_segments(xk[NX - 3], xk[NX - 2], xk[NX - 1], dr, dz);
             for (int i = 0; i < NSELF; i++) hr[M + i] = mmpc_self_row(i, xk[0], xk[1], cs, sn, dr, dz, nullptr) - sks;
             for (int i = 0; i < NHS; i++) hr[M + NSELF + i] = mmpc_hs_row(P, i, xk[0], xk[1], cs, sn, dr, dz, nullptr) - sk;
             if (NQ && k >= 1) {
                 const double *xp = X + (k - 1) * NX;
                 double drp[3], dzp[3], snp, csp;
-                sincos(xp[2], &snp, &csp);
+                MMPC_SINCOS(xp[2], &snp, &csp);
                 mmpc_arm_segments(xp[NX - 3], xp[NX - 2], xp[NX - 1], drp, dzp);
                 for (int e = 0; e < NQ; e++) { int br; hr[M + NSELF + NHS + e] = q8_row(e, xk, cs, sn, dr, dz, xp, csp, snp, drp, dzp, br, nullptr, nullptr) - sk; }
             }
@@ -636,7 +664,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
         for (int k = lane; k < NS; k += MMPC_WAVE) {
             const double *xk = X + k * NX;
             double sn, cs;
-            sincos(xk[2], &sn, &cs);
+            MMPC_SINCOS(xk[2], &sn, &cs);
             double rdx[NX], rdu[NU > 0 ? NU : 1];
             // cost gradient (mpc_wholebody_qref.py:192-201,240-242; mpc_base.py:146-153)
             {
@@ -736,7 +764,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                     if (k >= 1) {
                         const double *xp = X + (k - 1) * NX;
                         double drp[3], dzp[3], snp, csp;
-                        sincos(xp[2], &snp, &csp);
+                        MMPC_SINCOS(xp[2], &snp, &csp);
                         mmpc_arm_segments(xp[NX - 3], xp[NX - 2], xp[NX - 1], drp, dzp);
                         for (int e = 0; e < NQ; e++) {
                             double g6[6];
@@ -909,7 +937,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                         // it the step is a Gauss-Newton step and convergence is linear
                         const double *xk = X + k * NX;
                         double sn, cs, dr[3], dz[3], gt[6], h10[10];
-                        sincos(xk[2], &sn, &cs);
+                        MMPC_SINCOS(xk[2], &sn, &cs);
                         mmpc_arm_segments(xk[NX - 3], xk[NX - 2], xk[NX - 1], dr, dz);
                         mmpc_hs_row(P, i, xk[0], xk[1], cs, sn, dr, dz, gt, h10);
                         for (int a = 0; a < 4; a++) {
@@ -928,8 +956,8 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                         const double *xk = X + k * NX, *xp = X + (k - 1) * NX;
                         double sn, cs, dr[3], dz[3], snp, csp, drp[3], dzp[3];
                         if (exact) {
-                            sincos(xk[2], &sn, &cs); mmpc_arm_segments(xk[NX - 3], xk[NX - 2], xk[NX - 1], dr, dz);
-                            sincos(xp[2], &snp, &csp); mmpc_arm_segments(xp[NX - 3], xp[NX - 2], xp[NX - 1], drp, dzp);
+                            MMPC_SINCOS(xk[2], &sn, &cs); mmpc_arm_segments(xk[NX - 3], xk[NX - 2], xk[NX - 1], dr, dz);
+                            MMPC_SINCOS(xp[2], &snp, &csp); mmpc_arm_segments(xp[NX - 3], xp[NX - 2], xp[NX - 1], drp, dzp);
                         }
                         for (int e = 0; e < NQ; e++) {
                             const double t = T[k * R + SL_Q + e], z = Z[k * R + SL_Q + e], w = z / t;
@@ -1377,7 +1405,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
             double f = Sw * sk * sk, th = 0.0;
             f += 0.5 * mmpc_state_cost<KIND>(WTS, k == N, xk, XREF + k * NREF, nullptr, nullptr, false);
             double sn, cs;
-            sincos(xk[2], &sn, &cs);
+            MMPC_SINCOS(xk[2], &sn, &cs);
             if (k < N) {
                 for (int a = 0; a < NU; a++) uk[a] = U[k * NU + a] + alpha * DU[k * NU + a];
                 double q = 0.0;
@@ -1426,7 +1454,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                     if (NQ && k >= 1) {
                         double xp[NX], drp[3], dzp[3], snp, csp;
                         for (int j = 0; j < NX; j++) xp[j] = X[(k - 1) * NX + j] + alpha * DX[(k - 1) * NX + j];
-                        sincos(xp[2], &snp, &csp);
+                        MMPC_SINCOS(xp[2], &snp, &csp);
                         mmpc_arm_segments(xp[NX - 3], xp[NX - 2], xp[NX - 1], drp, dzp);
                         for (int e = 0; e < NQ; e++) { int br; hr[M + NSELF + NHS + e] = q8_row(e, xk, cs, sn, dr, dz, xp, csp, snp, drp, dzp, br, nullptr, nullptr) - sk; }
                     }

@@ -55,29 +55,7 @@ __device__ unsigned long long mmpc_stamp_acc[16];
 #endif
 #define MMPC_MC_MAX 8    // largest number of circle rows the register-resident path is instantiated for
 
-// ---- light-weight fp64 math for the fast path -------------------------------------------------
-// sin/cos: Cody-Waite reduction by pi/2 (three-part constant, exact for |x| < ~1e6 rad: heading and
-// joint angles stay far below that) + the fdlibm kernel polynomials on [-pi/4, pi/4] (< 1 ulp).
-// The library sincos carries a Payne-Hanek path that costs ~700 instructions per call site.
-MMPC_DEV void mmpc_sincos(double x, double *sn, double *cs) {
-    const double n = rint(x * 6.36619772367581382433e-01);
-    double r = fma(-n, 1.57079632673412561417e+00, x);
-    r = fma(-n, 6.07710050630396597660e-11, r);
-    r = fma(-n, 2.02226624879595063154e-21, r);
-    const double z = r * r;
-    const double ps = fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08),
-                      2.75573137070700676789e-06), -1.98412698298579493134e-04), 8.33333333332248946124e-03),
-                      -1.66666666666666324348e-01);
-    const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09),
-                      -2.75573143513906633035e-07), 2.48015872894767294178e-05), -1.38888888888741095749e-03),
-                      4.16666666666666019037e-02);
-    const double s0 = fma(r * z, ps, r);
-    const double c0 = fma(z * z, pc, fma(-0.5, z, 1.0));
-    const int q = (int)n & 3;
-    const double sa = (q & 1) ? c0 : s0, ca = (q & 1) ? s0 : c0;
-    *sn = (q & 2) ? -sa : sa;
-    *cs = ((q + 1) & 2) ? -ca : ca;
-}
+// (mmpc_sincos: mmpc_core.h)
 // max / min of this path: v_max_f64 / v_min_f64 on the device (the ternary form of mmpc_core.h costs a compare and two selects
 // per use - it hands a NaN in its second argument through; here NaNs are caught by the sums of the evaluation instead, see the
 // status 2 test of the main loop)
