@@ -455,9 +455,12 @@ def test_as_written_converges_on_2048_starts(mm):
     assert (o["status"] == 0).all()
     same = np.abs(r["cost"] / o["cost"] - 1) < 1e-6
     assert same.sum() >= B - 20, int(same.sum())           # (a kink of a max can send the two builds to different branches)
-    # (U is the least determined block - the arm inputs carry no R weight -: measured 2.0e-5 on one of the 2048, X 2.0e-6)
-    assert np.abs(r["X"][same] - o["X"][same]).max() < 1e-5 and np.abs(r["U"][same] - o["U"][same]).max() < 5e-5
-    sel = np.unique(np.concatenate([[66, 144, 293, 1948], np.argsort(-r["iters"], kind="stable")[:12]]))
+    # (U is the least determined block - the arm inputs carry no R weight -: a 1e-8 KKT test pins it to ~1e-4 on the flattest of
+    #  the 2048 instances; measured: X 2.0e-6, U 1.0e-4 on one instance, 2.0e-5 on the next)
+    dX = np.abs(r["X"] - o["X"]).reshape(B, -1).max(1); dU = np.abs(r["U"] - o["U"]).reshape(B, -1).max(1)
+    assert dX[same].max() < 1e-5 and dU[same].max() < 5e-4 and (dU[same] > 5e-5).sum() <= 4, (dX[same].max(), dU[same].max(), int((dU[same] > 5e-5).sum()))
+    loose = np.nonzero(same & (dU > 5e-5))[0]
+    sel = np.unique(np.concatenate([[66, 144, 293, 1948], loose, np.argsort(-r["iters"], kind="stable")[:12]]))
     cs = certify([(nlp.Problem(par, x[b], tr[b], z[b], z[b], obs[b], hs, as_written=True), r["X"][b], r["U"][b], r["s"][b]) for b in sel])
     assert all(cert_ok(c) for c in cs), max(c["E0"] for c in cs)
     print("as written, 2048 starts: mean %.1f iterations, max %d; %d of 2048 in the C oracle's minimum" % (r["iters"].mean(), r["iters"].max(), int(same.sum())))
