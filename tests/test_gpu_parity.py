@@ -421,3 +421,50 @@ def test_asynchronous_receding_horizon_equals_lock_step(mm):
     # and once more with another budget: the split of a solve into launches does not matter
     c = fleet.run_async(T, budget=40)
     assert bool(c["all_converged"]) and torch.equal(a["u0"], c["u0"]) and torch.equal(a["x"], c["x"])
+
+
+@pytest.mark.gpu
+def test_list_launch_solves_exactly_the_listed_rows(mm):
+    """mmpc_solve_list_device: a device-side list (and count) of row indices - the listed instances get bitwise the results of
+    the whole-batch call, every other row of the outputs is left as it was; with and without an iteration budget; a list on
+    the generic kernel is refused."""
+    import torch
+    B, N, M = 1024, 20, 5
+    d = synth.make_batch(B)
+    par = nlp.WholeBodyParams()
+    ctrl = mm.MPCWholeBody(mm.MobileManipulator(0.1), [], [], N=N, max_batch=B, n_obstacles=M)
+    eng = ctrl._engine
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    xi, tr, ur, ob = t(np.clip(d["x_init"], par.xlim[0], par.xlim[1])), t(d["traj_ref"]), t(d["u_ref"]), t(d["obs"])
+    ul = torch.zeros((B, N, 5), dtype=torch.float64, device=dev)
+    ref = {k: v.clone() for k, v in eng.solve_batch_device(xi, tr, ur, ul, ob).items()}
+    rows = torch.tensor([5, 900, 17, 333, 64, 1023, 0], dtype=torch.int32, device=dev)
+    lst = torch.zeros(B, dtype=torch.int32, device=dev); lst[:rows.numel()] = rows
+    cnt = torch.tensor([rows.numel()], dtype=torch.int32, device=dev)
+    for budget in (0, 12):
+        eng.set_iteration_budget(budget)
+        out = {k: torch.full_like(v, -7) for k, v in ref.items()}
+        eng.solve_batch_device(xi, tr, ur, ul, ob, out=out, rows=(lst, cnt))
+        if budget:
+            eng.resume_batch_device(xi, tr, ur, ul, ob, out)
+        torch.cuda.synchronize()
+        sel = rows.long()
+        rest = torch.ones(B, dtype=torch.bool, device=dev); rest[sel] = False
+        for k in ("X", "U", "s", "status", "iters", "cost", "err"):
+            assert torch.equal(out[k][sel], ref[k][sel]), (budget, k)
+            assert bool((out[k][rest] == -7).all()), (budget, k)
+    eng.set_iteration_budget(0)
+    cnt.zero_()                                                   # an empty list: nothing is touched
+    out = {k: torch.full_like(v, -7) for k, v in ref.items()}
+    eng.solve_batch_device(xi, tr, ur, ul, ob, out=out, rows=(lst, cnt))
+    torch.cuda.synchronize()
+    assert all(bool((v == -7).all()) for v in out.values())
+    gen = mm.MPCWholeBody(mm.MobileManipulator(0.1), [], [], N=12, max_batch=B, n_obstacles=2)     # no specialised kernel for this shape
+    with pytest.raises(RuntimeError, match="list launches"):
+        d2 = synth.make_batch(B, N=12, M=2)
+        gen._engine.solve_batch_device(t(np.clip(d2["x_init"], par.xlim[0], par.xlim[1])), t(d2["traj_ref"]), t(d2["u_ref"]),
+                                       torch.zeros((B, 12, 5), dtype=torch.float64, device=dev), t(d2["obs"]),
+                                       out={k: torch.zeros_like(v) for k, v in gen._engine.solve_batch_device(
+                                           t(np.clip(d2["x_init"], par.xlim[0], par.xlim[1])), t(d2["traj_ref"]), t(d2["u_ref"]),
+                                           torch.zeros((B, 12, 5), dtype=torch.float64, device=dev), t(d2["obs"])).items()}, rows=(lst, cnt))
