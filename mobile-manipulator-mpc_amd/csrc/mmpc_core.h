@@ -53,6 +53,17 @@ __device__ __forceinline__ int mmpc_lane_id() { int l = (int)threadIdx.x; asm vo
 #define MMPC_WAVE 64
 #define MMPC_FCAP 16
 #define MMPC_MAX_LS 20
+// Diagnostic build only (-DMMPC_STAMP_GEN): per-phase wave-cycle accounting of the generic kernel (tools/probe_stamps_generic.py)
+#if defined(MMPC_STAMP_GEN) && !defined(MMPC_EMU)
+__device__ unsigned long long mmpc_gstamp_acc[16];
+#define MMPC_G0() unsigned long long g_prev_ = __builtin_readcyclecounter(), g_now_, g_acc_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define MMPC_GS(i) { g_now_ = __builtin_readcyclecounter(); g_acc_[i] += g_now_ - g_prev_; g_prev_ = g_now_; }
+#define MMPC_GEND() { if (threadIdx.x == 0) for (int i_ = 0; i_ < 10; i_++) atomicAdd(&mmpc_gstamp_acc[i_], g_acc_[i_]); }
+#else
+#define MMPC_G0()
+#define MMPC_GS(i)
+#define MMPC_GEND()
+#endif
 
 // Per-launch constants (device memory, read through the scalar cache).
 struct MmpcParams {
@@ -657,7 +668,9 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
     }
     nrows_act += NS * NR - NQ;
 
+    MMPC_G0()
     for (it = 0; it <= P.max_iter; it++) {
+        MMPC_GS(0)
         // ============================================================ E1: evaluation + KKT partials
         LANES_BEGIN
         double e_d = 0.0, e_p = 0.0, tzmax = 0.0, tzmin = 1e300, zsum = 0.0;
@@ -849,6 +862,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
             if (changed) filt_init = 0;
         }
 
+        MMPC_GS(1)
         // ============================================================ Newton direction
         int failed = 0;
         // Hessian ladder: exact Lagrangian Hessian; on a non-positive pivot the same without the curvature of the dynamics
@@ -1093,6 +1107,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
             // unpack P_N (stage-N Hessian after its Schur step is written by another lane in this
             // phase, so the unpack happens in R0 below)
             LANES_END
+            MMPC_GS(2)
             // ---- R0: full copy of P_N
             const bool sig = NQ && SIGW[0] != 0.0;       // (uniform; written by A2)
             const bool brd = teq || sig;                  // border columns in play
@@ -1341,6 +1356,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                 LANES_END
             }
         }
+        MMPC_GS(3)
         // ---- forward roll-out of the linearised dynamics
         LANES_BEGIN
         for (int j = lane; j < NX; j += MMPC_WAVE) DX[j] = 0.0;
@@ -1365,6 +1381,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
             }
             LANES_END
         }
+        MMPC_GS(4)
         // ---- D1: multiplier step and slack-variable step
         LANES_BEGIN
         for (int k = lane; k < NS; k += MMPC_WAVE) {
@@ -1393,6 +1410,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
             if (back_self) for (int a = 0; a < 6; a++) DLAM[k * NX + kY[a]] += VX[k * 6 + a] * dsk;
         }
         LANES_END
+        MMPC_GS(5)
         // ---- D2: row steps, fraction-to-boundary, directional derivative, merit at alpha = 0
         const double tau = mmpc_max(0.99, 1.0 - mu);
         auto stage_merit = [&](int k, double alpha, double &phi_k, double &th_k) {
@@ -1523,6 +1541,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
             ad = mmpc_min(ad, RED[1 * MMPC_WAVE + i]);
             dphi += RED[2 * MMPC_WAVE + i];
         }
+        MMPC_GS(6)
         // ---- merit at the current point (needs DTR from D2 only formally: alpha = 0)
         LANES_BEGIN
         double ph = 0.0, th = 0.0;
@@ -1534,6 +1553,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
         if (!mmpc_finite(phi0) || !mmpc_finite(th0)) { status = 2; break; }   // (an infinite reference / obstacle: opti.solve() raises)
         if (!filt_init) { nfilt = 0; th_max = 1e4 * mmpc_max(1.0, th0); th_min = 1e-4 * mmpc_max(1.0, th0); filt_init = 1; }
 
+        MMPC_GS(7)
         // ---- filter line search (Waechter-Biegler acceptance rules, no restoration phase)
         double alpha = ap;
         for (int lspass = 0; lspass < 2; lspass++) {
@@ -1573,6 +1593,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
         fprintf(stderr, "generic it %d mu %.2e E0 %.3e err_d %.3e err_p %.3e alpha %.3e ap %.3e ad %.3e prox %.1e dphi %.3e\n", it, mu, E0, err_d, err_p, alpha, ap, ad, prox, dphi);
 #endif
         if (!teq) mmpc_prox_update(alpha, prox, nsmall);   // (with the terminal equality the forced correction makes nu grow like prox)
+        MMPC_GS(8)
         // ---- update
         LANES_BEGIN
         for (int k = lane; k < NS; k += MMPC_WAVE) {
@@ -1605,6 +1626,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
         LANES_END
     }
 
+    MMPC_GS(9) MMPC_GEND()
     // ---------------------------------------------------------------- results
     LANES_BEGIN
     double f = 0.0;

@@ -325,6 +325,14 @@ extern "C" int mmpc_debug_read_stamps(unsigned long long *out16) {
     return 0;
 }
 #endif
+#ifdef MMPC_STAMP_GEN
+extern "C" int mmpc_debug_read_gstamps(unsigned long long *out16) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(mmpc_gstamp_acc), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(mmpc_gstamp_acc), z, sizeof(z)) != hipSuccess) return -1;
+    return 0;
+}
+#endif
 extern "C" const char *mmpc_version(void) { return "mmpc 0.1 (gfx950)"; }
 static thread_local char g_err[512] = "";   // errors of the handle-less entry points (mmpc_ik_*)
 extern "C" const char *mmpc_last_error(mmpc_handle h) { return h ? h->err : g_err; }
