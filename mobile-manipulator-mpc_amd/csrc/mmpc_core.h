@@ -53,6 +53,7 @@ __device__ __forceinline__ int mmpc_lane_id() { int l = (int)threadIdx.x; asm vo
 #define MMPC_WAVE 64
 #define MMPC_FCAP 16
 #define MMPC_MAX_LS 20
+#include "mmpc_tile.h"
 // Diagnostic build only (-DMMPC_STAMP_GEN): per-phase wave-cycle accounting of the generic kernel (tools/probe_stamps_generic.py)
 #if defined(MMPC_STAMP_GEN) && !defined(MMPC_EMU)
 __device__ unsigned long long mmpc_gstamp_acc[16];

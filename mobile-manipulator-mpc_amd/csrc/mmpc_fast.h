@@ -21,26 +21,6 @@
 #pragma once
 #include "mmpc_core.h"
 
-#ifdef MMPC_EMU
-#define MMPC_LS ls_all[lane]
-#define MMPC_WR(i) wr_all[lane][i]
-// value a field of the lane state holds in lane j (the emulator runs the lanes of a phase one after another: a field that
-// is read across lanes and rewritten in the same phase is double-buffered by the parity of the stage)
-#define MMPC_LANE_GET(field, j) (ls_all[j].field)
-#define MMPC_LANE_XOR16(field) (ls_all[lane ^ 16].field)
-#define MMPC_FW_SLOTS 2
-#define MMPC_FW_SLOT(k) ((k) & 1)
-#define LANES_END_REG }
-#else
-#define MMPC_LS ls_one
-#define MMPC_WR(i) wr_one[i]
-#define MMPC_LANE_GET(field, j) mmpc_readlane_f64(ls_one.field, j)
-#define MMPC_LANE_XOR16(field) mmpc_xor16_f64(ls_one.field, lane)
-#define MMPC_FW_SLOTS 1
-#define MMPC_FW_SLOT(k) 0
-#define LANES_END_REG }      // end of a phase whose results travel in registers only: no LDS ordering to enforce
-#endif
-
 // Diagnostic build only (-DMMPC_STAMP): per-phase wave-cycle accounting, accumulated in registers and added to a
 // __device__ array at the end (read by tools/probe_stamps.py).  The shipped kernel contains no stamps.
 #if defined(MMPC_STAMP) && !defined(MMPC_EMU)
@@ -65,33 +45,6 @@ MMPC_DEV double mmpc_vmin(double a, double b) { return a < b ? a : b; }
 #else
 MMPC_DEV double mmpc_vmax(double a, double b) { return __builtin_fmax(a, b); }
 MMPC_DEV double mmpc_vmin(double a, double b) { return __builtin_fmin(a, b); }
-#endif
-#ifdef MMPC_EMU
-MMPC_DEV double mmpc_rcp(double x) { return 1.0 / x; }
-MMPC_DEV double mmpc_rsqrt(double x) { return 1.0 / sqrt(x); }
-MMPC_DEV double mmpc_rcp3(double x) { return 1.0 / x; }
-MMPC_DEV double mmpc_powf(double x, float e) { return (double)exp2f(e * log2f((float)x)); }
-MMPC_DEV void mmpc_sched_fence() {}
-#else
-// v_rcp_f64 / v_rsq_f64 (seeds good to 2^-24, tools/rcp_probe.hip) + one cubic step: 1.1e-16 / 1.4e-16 worst relative error in three
-// / five dependent operations; the IEEE division / sqrt sequences are ~3x longer
-MMPC_DEV double mmpc_rcp(double x) {
-    const double r = __builtin_amdgcn_rcp(x), e = fma(-x, r, 1.0);
-    return fma(fma(e, e, e), r, r);                    // r (1 + e + e^2), e = 1 - x r
-}
-MMPC_DEV double mmpc_rcp3(double x) { return mmpc_rcp(x); }
-MMPC_DEV double mmpc_rsqrt(double x) {
-    const double y = __builtin_amdgcn_rsq(x), e = fma(-(x * y), y, 1.0);
-    return fma(y * e, fma(0.375, e, 0.5), y);          // y (1 + e/2 + 3 e^2/8), e = 1 - x y^2
-}
-// x^e in single precision (only used by the filter's switching rule, a heuristic threshold)
-MMPC_DEV double mmpc_powf(double x, float e) { return (double)__builtin_amdgcn_exp2f(e * __builtin_amdgcn_logf((float)x)); }
-// keeps the scheduler from interleaving independent unrolled bodies (bounds the live registers)
-#ifdef MMPC_NO_SCHED_FENCE
-MMPC_DEV void mmpc_sched_fence() {}
-#else
-MMPC_DEV void mmpc_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
-#endif
 #endif
 // multiplier safeguard (mmpc_z_safeguard) as a clamp of z to [mu / (kappa t), kappa mu / t] with one reciprocal instead of
 // two IEEE divisions (38 inlined call sites in the trial-point phase)
@@ -126,12 +79,6 @@ MMPC_DEV void mmpc_arm_segments_fast(double q1, double q2, double q3, double dr[
     dr[2] = MMPC_A6 * cB - MMPC_A7 * sB;
     dz[2] = -MMPC_A6 * sB - MMPC_A7 * cB;
 }
-// product of two small non-negative integers (LDS offsets): v_mul_u32_u24 / v_mad_u32_u24 instead of the quarter-rate 32-bit multiply
-#ifdef MMPC_EMU
-#define MMPC_MUL24(a, b) ((a) * (b))
-#else
-#define MMPC_MUL24(a, b) ((int)__umul24((unsigned)(a), (unsigned)(b)))
-#endif
 // state entries the forward kinematics depends on (x, y, psi, q1, q2, q3), as a constant expression
 MMPC_HD constexpr int mmpc_y(int a) { return a < 3 ? a : a + 3; }
 
@@ -179,36 +126,6 @@ struct MmpcFastDims {
     static_assert(NV + 1 <= 16, "stage matrix over (x, 1, u) must fit one 16x16 tile");
 };
 
-// ---- v_mfma_f64_16x16x4_f64: D = A B + C on one wavefront.  Lane l supplies A[l&15][l>>4] and B[l>>4][l&15] and holds
-// rows (l>>4) + 4r of column l&15 of C/D in accumulator register r (tools/mfma_probe.hip checks this map on the device).
-// An accumulator's register r is therefore K-block r (rows 4r..4r+3) of a B operand as it stands, and - for a
-// symmetric matrix - of an A operand: chained products need no lane movement.
-#ifdef MMPC_EMU
-struct MmpcAcc {
-    double v[4];
-    double &operator[](int i) { return v[i]; }
-    const double &operator[](int i) const { return v[i]; }
-};
-#define MMPC_MFMA(ACC, AEXPR, BEXPR) {                                                                                  \
-    double a_[MMPC_WAVE], b_[MMPC_WAVE];                                                                               \
-    for (int lane = 0; lane < MMPC_WAVE; lane++) { auto &ls = ls_all[lane]; a_[lane] = (AEXPR); b_[lane] = (BEXPR); }   \
-    for (int lane = 0; lane < MMPC_WAVE; lane++) {                                                                     \
-        auto &ls = ls_all[lane];                                                                                       \
-        for (int r_ = 0; r_ < 4; r_++) {                                                                               \
-            double s_ = ls.ACC[r_];                                                                                    \
-            for (int k_ = 0; k_ < 4; k_++) s_ = fma(a_[16 * k_ + (lane >> 4) + 4 * r_], b_[16 * k_ + (lane & 15)], s_); \
-            ls.ACC[r_] = s_;                                                                                           \
-        }                                                                                                              \
-    } }
-#define MMPC_MFMA0(ACC, AEXPR, BEXPR) { for (int lane = 0; lane < MMPC_WAVE; lane++) for (int r_ = 0; r_ < 4; r_++) ls_all[lane].ACC[r_] = 0.0; \
-    MMPC_MFMA(ACC, AEXPR, BEXPR) }
-#else
-typedef double MmpcAcc __attribute__((ext_vector_type(4)));
-// (first product of a chain: zero accumulator input, no register initialisation)
-#define MMPC_MFMA0(ACC, AEXPR, BEXPR) { auto &ls = ls_one; const MmpcAcc z_ = {0.0, 0.0, 0.0, 0.0};                     \
-    ls.ACC = __builtin_amdgcn_mfma_f64_16x16x4f64((AEXPR), (BEXPR), z_, 0, 0, 0); }
-#define MMPC_MFMA(ACC, AEXPR, BEXPR) { auto &ls = ls_one; ls.ACC = __builtin_amdgcn_mfma_f64_16x16x4f64((AEXPR), (BEXPR), ls.ACC, 0, 0, 0); }
-#endif
 
 struct MmpcFastLayout {
     int XU, S, LAM, XUREF, ULAST, OBS, CST, CV, CD, TRG, HXX, QXU, HUXL, HUUL, HUX02, HUUD, SN, KK, KF, KU, DXU, DS, DLAM,
@@ -302,25 +219,6 @@ struct MmpcLaneState {
 #define MMPC_RED_DPP 1   // wave reductions through DPP / permlane swaps (steps 1..32) instead of ds_bpermute butterflies (steps 32..1)
 #endif
 #ifndef MMPC_EMU
-// broadcast of lane j's value to the whole wave through scalar registers (v_readlane_b32 x 2; j is a constant)
-MMPC_DEV double mmpc_readlane_f64(double v, int j) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), j), hi = __builtin_amdgcn_readlane(__double2hiint(v), j);
-    return __hiloint2double(hi, lo);
-}
-// value of lane (l ^ 16): the 16-lane rows 0 <-> 1 and 2 <-> 3 trade places (v_permlane16_swap_b32 x 2, gfx950; with both
-// operands equal it returns {even rows doubled, odd rows doubled})
-MMPC_DEV double mmpc_xor16_f64(double v, int lane) {
-    const int lo = __double2loint(v), hi = __double2hiint(v);
-    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-    const bool odd = (lane >> 4) & 1;
-    return __hiloint2double(odd ? b[0] : b[1], odd ? a[0] : a[1]);
-}
-// Wave-wide reductions as a butterfly over the steps 1, 2, 4, 8, 16, 32 without the LDS crossbar (ds_bpermute: 57 cycles per
-// step, tools/lat_probe.hip): the partner's value comes through DPP inside a row of 16 lanes (quad permutes for 1 and 2;
-// for 4 and 8 the half-row / row MIRROR - lane 7-i resp. 15-i holds the same value as lane i^4 resp. i^8 at that point, the
-// lanes of a reduced group being bitwise equal) and through v_permlane16_swap / v_permlane32_swap across rows.  Every lane
-// ends with the same bits (the combine is commutative), which the host emulation reproduces (mmpc_emu_red).
 #if MMPC_RED_DPP
 template <int CTRL>
 MMPC_DEV double mmpc_dpp_f64(double v) {

@@ -9,6 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SRC = os.path.join(_HERE, "emu", "mmpc_emu.cpp")
 _CORE = os.path.join(_HERE, "..", "mobile-manipulator-mpc_amd", "csrc", "mmpc_core.h")
 _FAST = os.path.join(_HERE, "..", "mobile-manipulator-mpc_amd", "csrc", "mmpc_fast.h")
+_TILE = os.path.join(_HERE, "..", "mobile-manipulator-mpc_amd", "csrc", "mmpc_tile.h")
 _IK = os.path.join(_HERE, "..", "mobile-manipulator-mpc_amd", "csrc", "mmpc_ik.h")
 
 
@@ -24,7 +25,7 @@ class MmpcParams(C.Structure):
 
 def build(asan=False):
     out = os.path.join(_HERE, "emu", "_build", "libmmpc_emu_asan.so" if asan else "libmmpc_emu.so")
-    newest = max(os.path.getmtime(f) for f in (_SRC, _CORE, _FAST, _IK))
+    newest = max(os.path.getmtime(f) for f in (_SRC, _CORE, _FAST, _TILE, _IK))
     if not os.path.exists(out) or os.path.getmtime(out) < newest:
         os.makedirs(os.path.dirname(out), exist_ok=True)
         flags = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer"] if asan else ["-O2"]
