@@ -171,12 +171,15 @@ struct MmpcDims {
 #define MMPC_W_ULIM 255  // [2][5]
 #define MMPC_W_DULIM 265 // [2][5]
 #define MMPC_W_SIZE 276
+#ifndef MMPC_GEN_TILE
+#define MMPC_GEN_TILE 1   // the generic kernel's Riccati pass on v_mfma_f64_16x16x4_f64 tiles (as the specialised kernel's); 0: scalar pass through LDS
+#endif
 #define MMPC_NBC 3   // border columns: terminal multipliers nu0, nu1 and the slack s_{N-1} of the NLP as written (see A2)
 // LDS slab layout (offsets in doubles).  Shared by host (size query) and device.
 struct MmpcLayout {
     int X, U, S, LAM, XREF, UREF, ULAST, OBS, T, Z, HR, DTR, GC, HC, GSF, CV, CD, GX, GU, HXX, QX, HUXL, HUUL,
         HUX02, HUUD, QU, HSS, GSS, VX, VXN, KK, KF, DX, DU, DS, DLAM, PF, TT, PC, MF, MG, MH, MGX, MGU, RED, FILT,
-        MISC, PNU, PNUS, KFV, GNU, FWV, NUEQ, GHS, WTS, GQ8, BQ8, VQ, RQ, HQX, QQX, HUXS, HUUS, RDX, SIGW, total;
+        MISC, PNU, PNUS, KFV, GNU, FWV, NUEQ, GHS, WTS, GQ8, BQ8, VQ, RQ, HQX, QQX, HUXS, HUUS, RDX, SIGW, KU, PIV, total;
     int R, NR;
 };
 
@@ -208,6 +211,7 @@ MMPC_HD constexpr MmpcLayout mmpc_layout(int N, int M, int obs_per_stage, int nh
     // (interface_wholebody_qref.py:166-167) and the slack s_{N-1} when it reaches back to x_{N-2} (NLP as written): sensitivities
     MMPC_CARVE(PNU, D::NX * MMPC_NBC) MMPC_CARVE(PNUS, NS * D::NX * MMPC_NBC) MMPC_CARVE(KFV, N * D::NU * MMPC_NBC) MMPC_CARVE(GNU, D::NV * MMPC_NBC)
     MMPC_CARVE(FWV, 2 * (1 + MMPC_NBC) * D::NX) MMPC_CARVE(NUEQ, 4) MMPC_CARVE(GHS, NS * nhs * 6) MMPC_CARVE(WTS, MMPC_W_SIZE) MMPC_CARVE(SIGW, 16)
+    MMPC_CARVE(KU, MMPC_GEN_TILE ? N * (D::NU * (D::NU - 1) / 2) : 0) MMPC_CARVE(PIV, MMPC_GEN_TILE ? N * D::NU : 0)
     // as-written rows: gradient / branch per row; per stage: coupling of s_k to x_{k-1}, what stage k's rows add to stage k-1
     // (residual, Hessian y-block, gradient), dense blocks of a slack eliminated one stage earlier, x-stationarity residual
     MMPC_CARVE(GQ8, NS * nq * 6) MMPC_CARVE(BQ8, NS * nq) MMPC_CARVE(VQ, nq ? NS * 6 : 0) MMPC_CARVE(RQ, nq ? (NS + 1) * 6 : 0)
@@ -490,6 +494,26 @@ MMPC_DEV double mmpc_state_cost(const double *WTS, bool terminal, const double *
 // the whole solve - they spill to vector lanes, and those to scratch; instantiated for a shape they are constants.
 // NC, MC, OPSC, LC, AWC: horizon, circle obstacles, obs_per_stage, half-space planes and the as-written flag when they are
 // constants of the instantiation (the demo's shapes: every LDS offset is then an immediate), 0 / -1: read from the parameter block
+#if MMPC_GEN_TILE
+// lane state of the Riccati pass on MFMA tiles (lane = 16 g + j; accumulator register r <-> row g + 4 r, column j of the
+// 16x16 tile over (x, 1, u)); the same fields as the specialised kernel's MmpcLaneState (mmpc_fast.h)
+template <int KIND>
+struct MmpcGenRic {
+    typedef MmpcDims<KIND> D;
+    static constexpr int NKB = (D::NX + 1 + 3) / 4;           // K-blocks (4 rows each) that cover the (x, 1) rows
+    static constexpr int NPU = D::NU * (D::NU - 1) / 2;       // couplings between the inputs of a stage
+    static constexpr bool PAIRS = ((D::NX + 1) & 1) == 0;     // first input row even: rows (2q, 2q+1) share a register
+    static constexpr int NLEG = PAIRS ? (D::NU + 1) / 2 : D::NU;
+    static_assert(D::NV + 1 <= 16, "stage matrix over (x, 1, u) must fit one 16x16 tile");
+    unsigned ab_o[NKB];                  // [A B c; 0 0 1] operand rows 4r+g, column j: LDS offset | stage stride << 16
+    int p_o[4], p_s[4];                  // where register r of [P_k | p_k] is stored (offset at stage 0, stage stride; a dump slot otherwise)
+    int kl_b[NLEG], kl_s[NLEG];          // where the lane stores its entry of the normalised pivot row(s) of leg l
+    MmpcAcc rP, rT, rM;                  // cost-to-go [P p; p^T .], its product with the dynamics, stage matrix
+    double rAB[NKB], opa, opb;           // MFMA operands
+    double nab[NKB], nhm[4];             // next stage's dynamics rows and stage-matrix entries
+};
+#endif
+
 template <int KIND, int NC = 0, int MC = -1, int OPSC = -1, int LC = -1, int AWC = -1>
 MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds MMPC_EMU_ARG) {
     typedef MmpcDims<KIND> D;
@@ -513,7 +537,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
            *DS = lds + L.DS, *DLAM = lds + L.DLAM, *PF = lds + L.PF, *TT = lds + L.TT, *PC = lds + L.PC,
            *MF = lds + L.MF, *MG = lds + L.MG, *MH = lds + L.MH, *MGX = lds + L.MGX, *MGU = lds + L.MGU,
            *RED = lds + L.RED, *FILT = lds + L.FILT, *MISC = lds + L.MISC, *PNU = lds + L.PNU, *PNUS = lds + L.PNUS,
-           *KFV = lds + L.KFV, *GNU = lds + L.GNU, *FWV = lds + L.FWV, *NUEQ = lds + L.NUEQ, *GHS = lds + L.GHS, *SIGW = lds + L.SIGW;
+           *KFV = lds + L.KFV, *GNU = lds + L.GNU, *FWV = lds + L.FWV, *NUEQ = lds + L.NUEQ, *GHS = lds + L.GHS, *SIGW = lds + L.SIGW, *KU = lds + L.KU, *PIV = lds + L.PIV;
     double *const WTS = lds + L.WTS;
     double *const GQ8 = lds + L.GQ8, *const BQ8 = lds + L.BQ8, *const VQ = lds + L.VQ, *const RQ = lds + L.RQ, *const HQX = lds + L.HQX,
            *const QQX = lds + L.QQX, *const HUXS = lds + L.HUXS, *const HUUS = lds + L.HUUS, *const RDX = lds + L.RDX;
@@ -660,6 +684,62 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
 
     int status = 1, it = 0, nfilt = 0, filt_init = 0, nrows_act = 0, nsmall = 0;
     double prox = 0.0;
+#if MMPC_GEN_TILE
+    // Riccati recursion on MFMA tiles over (x, 1, u), as in mmpc_fast.h (see there for the lane <-> entry map): lane l = 16 g + j
+    // holds rows g + 4 r of column j in accumulator register r
+    typedef MmpcGenRic<KIND> GR;
+    constexpr int NKB = GR::NKB, NLEG = GR::NLEG, NPU = GR::NPU;
+    constexpr bool PAIRS = GR::PAIRS;
+#ifdef MMPC_EMU
+    static thread_local GR ls_all[MMPC_WAVE];
+#else
+    GR ls_one;
+#endif
+    // tile index -> index in the (x, u | gradient) numbering: state t, gradient NV, input NX + a, 99 = outside
+    auto tvar = [&](int t) -> int { return t < NX ? t : (t == NX ? NV : (t <= NV ? t - 1 : 99)); };
+    LANES_BEGIN
+    {
+        auto &ls = MMPC_LS;
+        const int g = lane >> 4, j = lane & 15, jl = tvar(j);
+        for (int r = 0; r < NKB; r++) {
+            // operand entry of [A B c; 0 0 1] (rows over (x, 1), columns over (x, 1, u)), row m = 4 r + g: a coefficient of CV[k]
+            // (ids 0, 1, 2 are the constants 0, 1, dt), the defect c_k[m] in the column of the 1, the 1 itself, or the constant 0
+            const int m = 4 * r + g;
+            unsigned off = (unsigned)L.CV, stride = 0;
+            if (m < NX && jl < NV) {
+                int id = 0;
+                for (int q = 0; q < 4; q++) if (TB::crow(jl, q) == m && TB::ccv(jl, q) != 0) id = TB::ccv(jl, q);
+                off = (unsigned)(L.CV + id); stride = id >= 3 ? MMPC_NCV : 0;
+            } else if (m < NX && jl == NV) { off = (unsigned)(L.CD + m); stride = NX; }
+            else if (m == NX && jl == NV) off = (unsigned)(L.CV + 1);
+            ls.ab_o[r] = off | (stride << 16);
+        }
+        for (int r = 0; r < 4; r++) {
+            // where register r of [P_k | p_k] goes: lower triangle of P_k -> HXX[k], p_k -> QX[k], everything else a dump slot
+            const int i = tvar(g + 4 * r);
+            int off = L.RED + lane, stride = 0;
+            if (i < NX && jl < NX && i >= jl) { off = L.HXX + i * (i + 1) / 2 + jl; stride = NXX; }
+            else if (i < NX && jl == NV) { off = L.QX + i; stride = NX; }
+            ls.p_o[r] = off; ls.p_s[r] = stride;
+        }
+        for (int l = 0; l < NLEG; l++) {
+            // entry of the normalised pivot row(s) of leg l this lane holds: gain row (column < NX), feed-forward (column NX),
+            // coupling to a later input, or nothing (dump slot)
+            const int a0 = PAIRS ? 2 * l : l;
+            int off = L.RED + lane, stride = 0;
+            for (int a = a0; a < NU && a <= a0 + (PAIRS ? 1 : 0); a++) {
+                const int ta = NX + 1 + a;
+                if (g == (ta & 3)) {
+                    if (j < NX) { off = L.KK + a * NX + j; stride = NU * NX; }
+                    else if (j == NX) { off = L.KF + a; stride = NU; }
+                    else if (j > ta && j <= NV) { const int b2 = j - NX - 1; off = L.KU + a * (2 * NU - a - 1) / 2 + (b2 - a - 1); stride = NPU; }
+                }
+            }
+            ls.kl_b[l] = off; ls.kl_s[l] = stride;
+        }
+    }
+    LANES_END
+#endif
     double E0 = 0.0, th_max = 0.0, th_min = 0.0;
     // number of active rows (uniform): box rows that exist + all non-box rows
     for (int r = 0; r < SL_C; r++) {
@@ -1114,6 +1194,176 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
             const bool brd = teq || sig;                  // border columns in play
             // y-entry of a state index (x, y, psi, q1, q2, q3 <-> 0..5), -1: none
             auto yix = [&](int i) -> int { return i < 3 ? i : (i >= NX - 3 ? i - (NX - 6) : -1); };
+#if MMPC_GEN_TILE
+            {
+                // entry (ti, tj) of stage k's matrix [Hxx Hxu q_x; Hux Huu q_u; q^T 0] in tile numbering (what R2 of the scalar
+                // pass adds to [A B]^T P [A B]): packed Hxx; Hux = (0,2) entry of the dynamics curvature + the dense blocks of a
+                // slack eliminated here (last stage: quirk Q1; as-written rows: any stage); Huu = R2 + W2 + diagonal barrier terms
+                // + the same dense blocks; gradient in row / column NX
+                auto stage_entry = [&](const int k, const int ti, const int tj) -> double {
+                    int i = tvar(ti), j = tvar(tj);
+                    if (i < j) { const int t_ = i; i = j; j = t_; }
+                    if (i == 99) return 0.0;
+                    if (i == NV) return j == NV ? 0.0 : (j < NX ? QX[k * NX + j] : QU[k * NU + j - NX]);
+                    if (i < NX) return HXX[k * NXX + i * (i + 1) / 2 + j];
+                    const int a_ = i - NX;
+                    if (j < NX) return (k == N - 1 ? HUXL[a_ * NX + j] : 0.0) + (NQ ? HUXS[(k * NU + a_) * NX + j] : 0.0) + ((a_ == 0 && j == 2) ? HUX02[k] : 0.0);
+                    const int b_ = j - NX, e2 = a_ * (a_ + 1) / 2 + b_;
+                    return WTS[MMPC_W_RW2 + a_ * NU + b_] + (a_ == b_ ? HUUD[k * NU + a_] : 0.0) + (k == N - 1 ? HUUL[e2] : 0.0) + (NQ ? HUUS[k * NUU + e2] : 0.0);
+                };
+                // R0: terminal cost-to-go [P_N p_N; p_N^T .] in accumulator layout (+ the augmentation of the terminal equality),
+                //     operands of stage N-1
+                LANES_BEGIN
+                {
+                    auto &ls = MMPC_LS;
+                    const int g = lane >> 4, j = lane & 15;
+                    for (int r = 0; r < 4; r++) {
+                        int i = tvar(g + 4 * r), jj = tvar(j);
+                        if (i < jj) { const int t_ = i; i = jj; jj = t_; }
+                        double v = 0.0;
+                        if (i < NX) v = HXX[N * NXX + i * (i + 1) / 2 + jj] + ((teq && i == jj && i < 2) ? MMPC_RHO_EQ : 0.0);
+                        else if (i == NV && jj < NX) v = QX[N * NX + jj] - ((teq && jj < 2) ? MMPC_RHO_EQ * (XREF[N * NX + jj] - X[N * NX + jj]) : 0.0);
+                        ls.rP[r] = v;
+                        ls.rM[r] = stage_entry(N - 1, g + 4 * r, j);
+                    }
+                    for (int r = 0; r < NKB; r++) { const unsigned o = ls.ab_o[r]; ls.rAB[r] = lds[(o & 0xffffu) + (N - 1) * (int)(o >> 16)]; }
+                }
+                if (brd)
+                    for (int e = lane; e < NX * MMPC_NBC; e += MMPC_WAVE) {   // p_N of the border columns: E^T (E = [I2 0]) and -vN
+                        const int i = e / MMPC_NBC, c = e % MMPC_NBC;
+                        double v = 0.0;
+                        if (c < 2) v = (teq && i == c) ? 1.0 : 0.0;
+                        else if (sig && yix(i) >= 0) v = -VXN[yix(i)];
+                        PNU[e] = v; PNUS[N * NX * MMPC_NBC + e] = v;
+                    }
+                LANES_END
+                int ric_bad = 0;
+                for (int k = N - 1; k >= 0; k--) {
+                    // R1: T = [P p; p^T .] [A B c; 0 0 1];  R2: M = [A B c; 0 0 1]^T T + stage matrix
+                    MMPC_MFMA0(rT, ls.rP[0], ls.rAB[0])
+                    MMPC_MFMA(rT, ls.rP[1], ls.rAB[1])
+                    if (NKB > 2) MMPC_MFMA(rT, ls.rP[NKB > 2 ? 2 : 0], ls.rAB[NKB > 2 ? 2 : 0])
+                    MMPC_MFMA(rM, ls.rAB[0], ls.rT[0])
+                    MMPC_MFMA(rM, ls.rAB[1], ls.rT[1])
+                    if (NKB > 2) MMPC_MFMA(rM, ls.rAB[NKB > 2 ? 2 : 0], ls.rT[NKB > 2 ? 2 : 0])
+                    // operands of the next stage travel while this one eliminates its inputs
+                    LANES_BEGIN
+                    {
+                        auto &ls = MMPC_LS;
+                        if (k > 0) {
+                            for (int r = 0; r < NKB; r++) { const unsigned o = ls.ab_o[r]; ls.nab[r] = lds[(o & 0xffffu) + (k - 1) * (int)(o >> 16)]; }
+                            for (int r = 0; r < 4; r++) ls.nhm[r] = stage_entry(k - 1, (lane >> 4) + 4 * r, lane & 15);
+                        }
+                    }
+                    LANES_END_REG
+                    // R3: the inputs are eliminated on the tile by rank-one MFMAs (mmpc_fast.h: pairs of inputs whose rows share an
+                    // accumulator register go as two K-slots of one MFMA, in sequential L D L^T arithmetic); the normalised pivot
+                    // rows go to KK / KF / KU, 1 / pivot to PIV (for the border columns)
+                    for (int leg = 0; leg < NLEG; leg++) {
+                        LANES_BEGIN
+                        {
+                            auto &ls = MMPC_LS;
+                            const int a0 = PAIRS ? 2 * leg : leg;
+                            const bool pair = PAIRS && a0 + 1 < NU;
+                            const int ta = NX + 1 + a0, ra = ta >> 2, ga = ta & 3, g = lane >> 4;
+                            const double c = ls.rM[ra];
+                            double w, cb = c;
+                            bool own;
+                            if (pair) {
+                                const double d00 = MMPC_LANE_GET(rM[ra], 16 * ga + ta), d01 = MMPC_LANE_GET(rM[ra], 16 * ga + ta + 1),
+                                             d11 = MMPC_LANE_GET(rM[ra], 16 * (ga + 1) + ta + 1);
+                                const double i0 = mmpc_rcp3(d00), l = d01 * i0, d1 = fma(-l, d01, d11);
+                                if (!(d00 > 0.0 && d1 > 0.0)) ric_bad = 1;
+                                const double i1 = mmpc_rcp3(d1), co = MMPC_LANE_XOR16(rM[ra]);
+                                const bool in1 = g == ga + 1;
+                                own = g == ga || in1;
+                                cb = fma(in1 ? -l : 0.0, co, c);      // (every lane uses the exchanged value, with a zero multiplier where it does not apply)
+                                w = cb * (in1 ? i1 : i0);
+                                if (lane == 0) { PIV[k * NU + a0] = i0; PIV[k * NU + a0 + 1] = i1; }
+                            } else {
+                                const double d = MMPC_LANE_GET(rM[ra], 16 * ga + ta);
+                                if (!(d > 0.0)) ric_bad = 1;
+                                own = g == ga;
+                                const double id = mmpc_rcp3(d);
+                                w = c * id;
+                                if (lane == 0) PIV[k * NU + a0] = id;
+                            }
+                            ls.opa = own ? -w : 0.0;
+                            ls.opb = own ? cb : 0.0;
+                            lds[ls.kl_b[leg] + k * ls.kl_s[leg]] = w;
+                        }
+                        LANES_END_REG
+                        MMPC_MFMA(rM, ls.opa, ls.opb)
+                    }
+                    LANES_BEGIN
+                    {
+                        auto &ls = MMPC_LS;
+                        for (int r = 0; r < 4; r++) {
+                            ls.rP[r] = ls.rM[r];
+                            lds[ls.p_o[r] + k * ls.p_s[r]] = ls.rM[r];
+                            ls.rM[r] = ls.nhm[r];
+                        }
+                        for (int r = 0; r < NKB; r++) ls.rAB[r] = ls.nab[r];
+                    }
+                    LANES_END
+                    if (ric_bad) { failed = 1; break; }
+                }
+                if (!failed) {
+                    // gains from the normalised pivot rows by back-substitution over the inputs: K_a = -(w_a[x,1] + sum_{b>a} w_a[u_b] K_b)
+                    LANES_BEGIN
+                    for (int i = lane; i < N * (NX + 1); i += MMPC_WAVE) {
+                        const int kk = i / (NX + 1), jj = i % (NX + 1);
+                        double kv[NU > 0 ? NU : 1];
+                        for (int a = 0; a < NU; a++) kv[a] = jj < NX ? KK[(kk * NU + a) * NX + jj] : KF[kk * NU + a];
+                        for (int a = NU - 1; a >= 0; a--) {
+                            double v = kv[a];
+                            for (int b2 = a + 1; b2 < NU; b2++) v += KU[kk * NPU + a * (2 * NU - a - 1) / 2 + (b2 - a - 1)] * kv[b2];
+                            kv[a] = -v;
+                        }
+                        for (int a = 0; a < NU; a++) { if (jj < NX) KK[(kk * NU + a) * NX + jj] = kv[a]; else KF[kk * NU + a] = kv[a]; }
+                    }
+                    LANES_END
+                    if (brd) {
+                        // border columns through the same factorisation: with bp = B^T p_{k+1},  kf = -Hh^{-1} bp  (Hh = L D L^T: L from
+                        // the couplings KU, 1 / D in PIV)  and  p_k = A^T p_{k+1} + K^T bp + (what the column adds at this stage);
+                        // one lane per column, stage by stage
+                        for (int k = N - 1; k >= 0; k--) {
+                            LANES_BEGIN
+                            if (lane < MMPC_NBC) {
+                                const int c = lane;
+                                const double *cv = CV + k * MMPC_NCV;
+                                double pn[NX], bp[NU > 0 ? NU : 1], y[NU > 0 ? NU : 1];
+                                for (int i = 0; i < NX; i++) pn[i] = PNU[i * MMPC_NBC + c];
+                                for (int a = 0; a < NU; a++) {
+                                    double v = 0.0;
+                                    for (int q = 0; q < 4; q++) v += cv[TB::ccv(NX + a, q)] * pn[TB::crow(NX + a, q)];
+                                    bp[a] = v; y[a] = v;
+                                }
+                                // L y' = bp (unit lower: L[b][a] = KU[k][a, b], b > a), y'' = D^{-1} y', L^T z = y''
+                                for (int a = 0; a < NU; a++) for (int b2 = a + 1; b2 < NU; b2++) y[b2] -= KU[k * NPU + a * (2 * NU - a - 1) / 2 + (b2 - a - 1)] * y[a];
+                                for (int a = 0; a < NU; a++) y[a] *= PIV[k * NU + a];
+                                for (int a = NU - 1; a >= 0; a--) for (int b2 = a + 1; b2 < NU; b2++) y[a] -= KU[k * NPU + a * (2 * NU - a - 1) / 2 + (b2 - a - 1)] * y[b2];
+                                for (int a = 0; a < NU; a++) KFV[(k * NU + a) * MMPC_NBC + c] = -y[a];
+                                for (int i = 0; i < NX; i++) {
+                                    double v = 0.0;
+                                    for (int q = 0; q < 4; q++) v += cv[TB::ccv(i, q)] * pn[TB::crow(i, q)];
+                                    for (int a = 0; a < NU; a++) v += KK[(k * NU + a) * NX + i] * bp[a];
+                                    if (c == 2 && sig && yix(i) >= 0) {
+                                        if (k == N - 1) v -= VX[(N - 1) * 6 + yix(i)];
+                                        if (k == N - 2) v -= VQ[(N - 1) * 6 + yix(i)];
+                                    }
+                                    PNUS[(k * NX + i) * MMPC_NBC + c] = v;
+                                }
+                            }
+                            LANES_END
+                            LANES_BEGIN
+                            for (int e = lane; e < NX * MMPC_NBC; e += MMPC_WAVE) PNU[e] = PNUS[k * NX * MMPC_NBC + e];
+                            LANES_END
+                        }
+                    }
+                }
+            }
+#else
             LANES_BEGIN
             for (int e = lane; e < NX * NX; e += MMPC_WAVE) {
                 const int i = e / NX, j = e % NX;
@@ -1259,6 +1509,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                 }
                 LANES_END
             }
+#endif
             if (!failed && brd) {
                 // the direction is affine in the border variables y = (nu0, nu1, dsigma): roll out the y = 0 solution and the
                 // sensitivities (same gains K; homogeneous dynamics for the sensitivities), and collect v~.d of every column
