@@ -141,7 +141,9 @@ __global__ __launch_bounds__(MMPC_WAVE, WPE) void mmpc_fast_kernel(
 // BASELINE configs C3/C4 (0,20,5), C5 (0,30,8), C2 (1,15,3); the reference demo (0,20,3).
 // The base-only kernel needs 16 KB of LDS per problem (9 problems/CU): it is built for 2 waves/SIMD (+21 % measured).
 #define MMPC_RESUME_GRID 256   // workgroups of a continuation launch (they stride over the list of suspended instances)
+#ifndef MMPC_FAST_LIST   // (experiments build other lists: -D'MMPC_FAST_LIST(X)=X(0, 10, 5, 2)', tools/occupancy_probe.sh)
 #define MMPC_FAST_LIST(X) X(0, 20, 5, 1) X(0, 30, 8, 1) X(0, 20, 3, 1) X(1, 15, 3, 2)
+#endif
 
 // Longest-processing-time-first order for the NEXT launch: instances sorted by descending iteration count of
 // this one (counting sort, 256 bins, one workgroup).  Kernel time is bounded by the slowest instance; starting
