@@ -232,6 +232,7 @@ struct MmpcIO {
     // with resume != 0 starts from that state and runs exactly the iterations the uninterrupted solve would have run next
     double *state;
     int budget, resume;
+    double *gscr;      // this instance's gain block in global memory (specialised kernels of long horizons, MmpcGainBlock), else unused
 };
 
 MMPC_DEV double mmpc_min(double a, double b) { return a < b ? a : b; }

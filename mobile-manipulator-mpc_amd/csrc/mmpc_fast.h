@@ -33,6 +33,15 @@ __device__ unsigned long long mmpc_stamp_acc[16];
 #define MMPC_TS(i)
 #define MMPC_TEND()
 #endif
+// A wave's stores to global memory (the gain block of long horizons) followed by loads of the same words from other lanes of the
+// SAME wave: the vector memory instructions of a wavefront are issued and processed in order, so the wavefront-scope fence of
+// LANES_END (compiler ordering only, no s_waitcnt) is all that is needed - waiting for the stores' acknowledgement here cost 2 x
+// ~1 k cycles per iteration (-DMMPC_GFENCE_WG restores the workgroup-scope fence for A/B checks).
+#if defined(MMPC_GFENCE_WG) && !defined(MMPC_EMU)
+#define MMPC_GFENCE() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+#else
+#define MMPC_GFENCE()
+#endif
 #define MMPC_MC_MAX 8    // largest number of circle rows the register-resident path is instantiated for
 
 // (mmpc_sincos: mmpc_core.h)
@@ -145,10 +154,25 @@ struct MmpcFastLayout {
 // Long horizons (N >= MMPC_SLIM_NMIN) leave the read-only inputs that are touched once or twice per iteration - the
 // reference trajectory, the previous inputs and the per-stage obstacle table - in HBM/L2 instead of LDS: at N = 30, M = 8 that is 63.2 -> 52.6 KB
 // per problem, i.e. three resident problems per CU instead of two.
+// Long horizons also keep the feedback gains (K_k, kf_k and the couplings between the inputs of a stage: 1 800 doubles at N = 30) in a
+// per-instance block of global memory (L2 / MALL resident): the Riccati legs only store them, the back-substitution is one
+// batched load / store pass and the roll-out fetches its gain row ahead of the chain.  At N = 30, M = 8 that is 52.6 -> 40.6 KB
+// of LDS per problem: four resident problems per CU - one per SIMD - instead of three.
+#ifndef MMPC_GAINS_GLOBAL_NMIN
+#define MMPC_GAINS_GLOBAL_NMIN MMPC_SLIM_NMIN
+#endif
+// the block: [KK: N NU NX][KF: N NU][KU: N NPU][dump: one slot per lane]
+template <int KIND, int N>
+struct MmpcGainBlock {
+    typedef MmpcFastDims<KIND, N> F;
+    static constexpr bool ON = N >= MMPC_GAINS_GLOBAL_NMIN;
+    static constexpr int KK = 0, KF = KK + N * F::NU * F::NX, KU = KF + N * F::NU, DUMP = KU + N * F::NPU, total = ON ? DUMP + MMPC_WAVE : 0;
+};
 template <int KIND, int N>
 MMPC_HD constexpr MmpcFastLayout mmpc_fast_layout(int M, int obs_per_stage) {
     typedef MmpcFastDims<KIND, N> F;
     constexpr bool SLIM = N >= MMPC_SLIM_NMIN;
+    constexpr bool GK = MmpcGainBlock<KIND, N>::ON;
     MmpcFastLayout L{};
     int o = 0;
 #define MMPC_CARVE(name, n) L.name = o; o += (n); o = (o + 1) & ~1;
@@ -158,12 +182,12 @@ MMPC_HD constexpr MmpcFastLayout mmpc_fast_layout(int M, int obs_per_stage) {
     MMPC_CARVE(CST, MMPC_C_SIZE) MMPC_CARVE(CV, F::NS * MMPC_NCV) MMPC_CARVE(CD, F::NS * F::NX) MMPC_CARVE(TRG, F::NS * 8)
     MMPC_CARVE(HXX, F::NS * F::NXX) MMPC_CARVE(QXU, F::NS * F::NV) MMPC_CARVE(HUXL, F::NU * F::NX)
     MMPC_CARVE(HUUL, F::NUU) MMPC_CARVE(HUX02, F::NS) MMPC_CARVE(HUUD, F::NS * F::NU) MMPC_CARVE(SN, 16)
-    MMPC_CARVE(KK, N * F::NU * F::NX) MMPC_CARVE(KF, N * F::NU) MMPC_CARVE(DXU, F::NS * F::NV) MMPC_CARVE(DS, F::NS)
+    MMPC_CARVE(KK, GK ? 0 : N * F::NU * F::NX) MMPC_CARVE(KF, GK ? 0 : N * F::NU) MMPC_CARVE(DXU, F::NS * F::NV) MMPC_CARVE(DS, F::NS)
     MMPC_CARVE(DLAM, F::NS * F::NX) MMPC_CARVE(RB, F::NS * F::NV) MMPC_CARVE(RDS, F::NS) MMPC_CARVE(Q1V, F::NV + 2) MMPC_CARVE(FILT, 2 * MMPC_FCAP)
     // scratch of the backward pass lives, where it fits, in arrays that are dead while it runs: the couplings between the
     // inputs of a stage in the search direction (written by the forward roll-out afterwards), the dump slots in the
     // multiplier step (D1)
-    if (F::NS * F::NV >= N * F::NPU) L.KU = L.DXU; else { MMPC_CARVE(KU, N * F::NPU) }
+    if (GK || F::NS * F::NV >= N * F::NPU) L.KU = L.DXU; else { MMPC_CARVE(KU, N * F::NPU) }
     if (F::NS * F::NX >= MMPC_WAVE) L.DUMP = L.DLAM; else { MMPC_CARVE(DUMP, MMPC_WAVE) } MMPC_CARVE(MISC, 8)
 #undef MMPC_CARVE
     L.total = o;
@@ -326,8 +350,19 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
     double *XU = lds + L.XU, *S = lds + L.S, *LAM = lds + L.LAM, *XUREF = lds + L.XUREF, *ULAST = lds + L.ULAST,
            *OBS = lds + L.OBS, *CST = lds + L.CST, *CV = lds + L.CV, *CD = lds + L.CD, *TRG = lds + L.TRG, *HXX = lds + L.HXX,
            *QXU = lds + L.QXU, *HUXL = lds + L.HUXL, *HUUL = lds + L.HUUL, *HUX02 = lds + L.HUX02,
-           *HUUD = lds + L.HUUD, *SN = lds + L.SN, *KK = lds + L.KK, *KF = lds + L.KF, *DXU = lds + L.DXU,
-           *DS = lds + L.DS, *DLAM = lds + L.DLAM, *KU = lds + L.KU, *FILT = lds + L.FILT;
+           *HUUD = lds + L.HUUD, *SN = lds + L.SN, *DXU = lds + L.DXU,
+           *DS = lds + L.DS, *DLAM = lds + L.DLAM, *FILT = lds + L.FILT;
+    // gains and input couplings: LDS, or this instance's block of global memory (MmpcGainBlock)
+    typedef MmpcGainBlock<KIND, N> GB;
+    constexpr bool GK = GB::ON;
+    double *const KBASE = GK ? io.gscr : lds;     // what the store offsets of the elimination legs (kl_b) are relative to
+    double *const KK = GK ? io.gscr + GB::KK : lds + L.KK, *const KF = GK ? io.gscr + GB::KF : lds + L.KF, *const KU = GK ? io.gscr + GB::KU : lds + L.KU;
+    constexpr int O_KK = GK ? GB::KK : 0, O_KF = GK ? GB::KF : 0, O_KU = GK ? GB::KU : 0, O_KDUMP = GK ? GB::DUMP : 0;
+    // element `idx` of an array of the gain block: uniform base + 32-bit byte offset (the scalar-base form of the global
+    // load / store: one address register per access instead of a 64-bit pair built per lane)
+    auto gk = [](double *base, int idx) -> double & {
+        if constexpr (GK) return *(double *)((char *)base + (size_t)((unsigned)idx * 8u)); else return base[idx];
+    };
     double *const RB = lds + L.RB, *const RDS = lds + L.RDS, *const Q1V = lds + L.Q1V;   // residual base r[k][v] and the s_k residual of the current point
     const double dt = P.dt, Sw = P.S, tol = P.tol;
 #ifdef MMPC_EMU
@@ -444,14 +479,14 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
             // divided by the pivot, is a gain-row entry (j < NX), the feed-forward (j = NX) or the coupling to a later input.
             // A leg eliminates input a0 or the pair (a0, a0 + 1), whose rows sit in neighbouring lane groups
             const int a0 = F::PAIRS ? 2 * l : l;
-            unsigned off = (unsigned)(L.DUMP + lane), stride = 0;
+            unsigned off = (unsigned)((GK ? O_KDUMP : L.DUMP) + lane), stride = 0;
 #pragma unroll
             for (int a = a0; a < NU && a <= a0 + (F::PAIRS ? 1 : 0); a++) {
                 const int ta = NX + 1 + a;
                 if (g == (ta & 3)) {
-                    if (j < NX) { off = (unsigned)(L.KK + a * NX + j); stride = NU * NX; }
-                    else if (j == NX) { off = (unsigned)(L.KF + a); stride = NU; }
-                    else if (j > ta && j <= NV) { const int b2 = j - NX - 1; off = (unsigned)(L.KU + a * (2 * NU - a - 1) / 2 + (b2 - a - 1)); stride = NPU; }
+                    if (j < NX) { off = (unsigned)((GK ? O_KK : L.KK) + a * NX + j); stride = NU * NX; }
+                    else if (j == NX) { off = (unsigned)((GK ? O_KF : L.KF) + a); stride = NU; }
+                    else if (j > ta && j <= NV) { const int b2 = j - NX - 1; off = (unsigned)((GK ? O_KU : L.KU) + a * (2 * NU - a - 1) / 2 + (b2 - a - 1)); stride = NPU; }
                 }
             }
             ls.kl_b[l] = (int)off * 8; ls.kl_s[l] = (int)stride * 8;
@@ -1259,7 +1294,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                     }
                     ls.opa = own ? -w : 0.0;
                     ls.opb = own ? cb : 0.0;
-                    *(double *)((char *)lds + (ls.kl_b[leg] + MMPC_MUL24(k, ls.kl_s[leg]))) = w;   // (lanes that hold no entry of the row write to their dump slot: no branch)
+                    *(double *)((char *)KBASE + (unsigned)(ls.kl_b[leg] + MMPC_MUL24(k, ls.kl_s[leg]))) = w;   // (lanes that hold no entry of the row write to their dump slot: no branch)
                     LANES_END_REG
                     MMPC_MFMA(rM, ls.opa, ls.opb)
                 }
@@ -1295,29 +1330,39 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
             status = 2; break; }
         // ---- gains of all stages from the normalised pivot rows, by back-substitution over the inputs (the last eliminated
         //      input depends on x only): K_a = -(w_a[x,1] + sum_{b>a} w_a[u_b] K_b), in place, one lane per (stage, column)
+        if (GK) MMPC_GFENCE();   // the legs' stores to the gain block are read by other lanes
         LANES_BEGIN
         {
             // two (stage, column) items per lane at a time, the loads of both ahead of the arithmetic: the update is in place, so the
             // compiler cannot move the loads of one item above the stores of the one before
             constexpr int NITEM = N * (NX + 1), NTRIP = (NITEM + MMPC_WAVE - 1) / MMPC_WAVE;
+            // entry (stage, input, column) of [K_k | kf_k]; in the gain block one access with a selected offset (a select between two
+            // global accesses becomes a branch per access)
+            auto kref = [&](int kq, int a, int jq) -> double & {
+                if constexpr (GK) return gk(io.gscr, jq < NX ? GB::KK + (kq * NU + a) * NX + jq : GB::KF + kq * NU + a);
+                else return jq < NX ? KK[(kq * NU + a) * NX + jq] : KF[kq * NU + a];
+            };
+            // (gain block in global memory: the loads of half of the lane's items ahead of their arithmetic - two exposed round trips to L2
+            //  instead of one per pair of items)
+            constexpr int TSTEP = GK ? (NTRIP + 1) / 2 : 2;
 #pragma unroll
-            for (int t0 = 0; t0 < NTRIP; t0 += 2) {
-                double kv[2][NU], cu[2][NPU > 0 ? NPU : 1];
-                int kk[2], jj[2];
-                bool ok[2];
+            for (int t0 = 0; t0 < NTRIP; t0 += TSTEP) {
+                double kv[TSTEP][NU], cu[TSTEP][NPU > 0 ? NPU : 1];
+                int kk[TSTEP], jj[TSTEP];
+                bool ok[TSTEP];
 #pragma unroll
-                for (int u = 0; u < 2; u++) {
+                for (int u = 0; u < TSTEP; u++) {
                     const int i = lane + MMPC_WAVE * (t0 + u);
                     ok[u] = t0 + u < NTRIP && i < NITEM;
                     const int ii = ok[u] ? i : 0;
                     kk[u] = ii / (NX + 1); jj[u] = ii % (NX + 1);
 #pragma unroll
-                    for (int a = 0; a < NU; a++) kv[u][a] = jj[u] < NX ? KK[(kk[u] * NU + a) * NX + jj[u]] : KF[kk[u] * NU + a];
+                    for (int a = 0; a < NU; a++) kv[u][a] = kref(kk[u], a, jj[u]);
 #pragma unroll
-                    for (int q = 0; q < NPU; q++) cu[u][q] = KU[kk[u] * NPU + q];
+                    for (int q = 0; q < NPU; q++) cu[u][q] = gk(KU, kk[u] * NPU + q);
                 }
 #pragma unroll
-                for (int u = 0; u < 2; u++) {
+                for (int u = 0; u < TSTEP; u++) {
 #pragma unroll
                     for (int a = NU - 1; a >= 0; a--) {
                         double v = kv[u][a];
@@ -1327,15 +1372,16 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < 2; u++) {
+                for (int u = 0; u < TSTEP; u++) {
                     if (ok[u]) {
 #pragma unroll
-                        for (int a = 0; a < NU; a++) { if (jj[u] < NX) KK[(kk[u] * NU + a) * NX + jj[u]] = kv[u][a]; else KF[kk[u] * NU + a] = kv[u][a]; }
+                        for (int a = 0; a < NU; a++) kref(kk[u], a, jj[u]) = kv[u][a];
                     }
                 }
             }
         }
         LANES_END
+        if (GK) MMPC_GFENCE();
         MMPC_TS(8)
         // ---- forward roll-out: lane i < NX carries dx_k[i] in a register; a stage broadcasts the NX values through scalar
         //      registers (v_readlane), forms the input step of its row and the next dx - no LDS round trip on the chain.
@@ -1357,13 +1403,38 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
             }
             LANES_END
 #ifndef MMPC_EMU
+            // Gains in global memory (GK): lane l < GRS carries element l of a stage's (K_k, kf_k).  A ring of four stage slots in
+            // LDS - over the stage-matrix extras HUXL .. HUUD, dead since the backward pass - is filled two stages ahead of the
+            // chain from registers that were loaded from the gain block three stages before that; the row lanes read their gain
+            // row from the ring one stage ahead, as they read it from the LDS copy of the short horizons.
+            constexpr int GRS = NU * NX + NU;
+            static_assert(!GK || 4 * GRS <= NU * NX + NUU + NS + NS * NU, "the gain ring must fit the stage-matrix extras");
+            static_assert(!GK || FWD_UNROLL >= N, "the gain ring's registers rotate statically: the roll-out must be fully unrolled");
+            double *const RING = lds + L.HUXL;
+            double gpre[3] = {0.0, 0.0, 0.0};
+            unsigned g_off = 0, g_st = 0;
+            int r_off = 0, r_st = 0;
+            auto gload = [&](int stage) -> double { return *(const double *)((const char *)io.gscr + (size_t)(g_off + (unsigned)stage * g_st)); };
+            if (GK) {
+                const int lane = mmpc_lane_id();
+                const bool isk = lane < NU * NX, isf = !isk && lane < GRS;
+                g_off = (unsigned)(isk ? GB::KK + lane : (isf ? GB::KF + lane - NU * NX : GB::DUMP + lane)) * 8u;
+                g_st = isk ? (unsigned)(NU * NX) * 8u : (isf ? (unsigned)NU * 8u : 0u);
+                r_off = lane < GRS ? L.HUXL + lane : L.DUMP + lane;
+                r_st = lane < GRS ? GRS : 0;
+                const double e0 = gload(0), e1 = N > 1 ? gload(1) : 0.0;
+#pragma unroll
+                for (int q = 0; q < 3; q++) if (q + 2 < N) gpre[q] = gload(q + 2);
+                lds[r_off] = e0; lds[r_off + r_st] = e1;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
             {   // operands of stage 0
                 const int lane = mmpc_lane_id();
                 auto &ls = MMPC_LS;
                 const int i = lane < NX ? lane : 0, a = (int)MMPC_B(ls.f_x, 2) - 1, aa = a < 0 ? 0 : a;
 #pragma unroll
-                for (int j = 0; j < NX; j++) nkr[j] = KK[aa * NX + j];
-                nkf = KF[aa]; nc0 = CD[i];
+                for (int j = 0; j < NX; j++) nkr[j] = GK ? RING[aa * NX + j] : KK[aa * NX + j];
+                nkf = GK ? RING[NU * NX + aa] : KF[aa]; nc0 = CD[i];
 #pragma unroll
                 for (int q = 0; q < 4; q++) ncf[q] = CV[MMPC_B(ls.f_v, q)];
                 ncf[4] = CV[MMPC_B(ls.f_x, 1)];
@@ -1393,11 +1464,15 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                 if (k + 1 < N) {
                     const double *cv = CV + (k + 1) * MMPC_NCV;
 #pragma unroll
-                    for (int j = 0; j < NX; j++) nkr[j] = KK[((k + 1) * NU + aa) * NX + j];
-                    nkf = KF[(k + 1) * NU + aa]; nc0 = CD[(k + 1) * NX + i];
+                    for (int j = 0; j < NX; j++) nkr[j] = GK ? RING[((k + 1) & 3) * GRS + aa * NX + j] : KK[((k + 1) * NU + aa) * NX + j];
+                    nkf = GK ? RING[((k + 1) & 3) * GRS + NU * NX + aa] : KF[(k + 1) * NU + aa]; nc0 = CD[(k + 1) * NX + i];
 #pragma unroll
                     for (int q = 0; q < 4; q++) ncf[q] = cv[MMPC_B(ls.f_v, q)];
                     ncf[4] = cv[MMPC_B(ls.f_x, 1)];
+                }
+                if (GK) {
+                    if (k + 2 < N) lds[r_off + ((k + 2) & 3) * r_st] = gpre[k % 3];
+                    if (k + 5 < N) gpre[k % 3] = gload(k + 5);
                 }
 #endif
                 double dx[NX];

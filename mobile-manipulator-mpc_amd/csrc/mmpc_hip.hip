@@ -43,7 +43,7 @@ __global__ __launch_bounds__(MMPC_WAVE) void mmpc_solve_kernel(
     io.iters = iters + b;
     io.cost = cost + b;
     io.err = err + b;
-    io.state = nullptr; io.budget = 0; io.resume = 0;   // (iteration budgets are a feature of the specialised kernels)
+    io.state = nullptr; io.budget = 0; io.resume = 0; io.gscr = nullptr;   // (iteration budgets are a feature of the specialised kernels)
     mmpc_solve_one<KIND, NC, MC, OPSC, LC>(P, io, lds);
 }
 
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(MMPC_WAVE) void mmpc_solve_kernel_static(
     io.iters = iters + b;
     io.cost = cost + b;
     io.err = err + b;
-    io.state = nullptr; io.budget = 0; io.resume = 0;
+    io.state = nullptr; io.budget = 0; io.resume = 0; io.gscr = nullptr;
     mmpc_solve_one<KIND, NC, MC, OPSC, LC, AWC>(P, io, lds);
 }
 // (kind, N, M, obs_per_stage, L, as_written): demo_wholebody_qref.py scenario 2 (two planes) as written and with the intended
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(MMPC_WAVE, WPE) void mmpc_fast_kernel(
     const double *__restrict__ obs, double *__restrict__ X, double *__restrict__ U, double *__restrict__ s,
     int *__restrict__ status, int *__restrict__ iters, double *__restrict__ cost, double *__restrict__ err,
     const int *__restrict__ order, int budget, double *__restrict__ state, int state_stride, const int *__restrict__ resume_count,
-    const int *__restrict__ list_count) {
+    const int *__restrict__ list_count, double *__restrict__ gscr) {
     __shared__ double lds[mmpc_fast_layout<KIND, N>(MC, OPS).total];
     typedef MmpcDims<KIND> D;
     // A continuation launch (resume_count != null): `order` is the compacted list of the suspended instances, *resume_count its
@@ -131,6 +131,7 @@ __global__ __launch_bounds__(MMPC_WAVE, WPE) void mmpc_fast_kernel(
         io.state = state ? state + (size_t)b * state_stride : nullptr;
         io.budget = budget;
         io.resume = resume_count ? 1 : 0;
+        io.gscr = MmpcGainBlock<KIND, N>::ON ? gscr + (size_t)b * MmpcGainBlock<KIND, N>::total : nullptr;
         mmpc_solve_fast<KIND, N, MC, CONT, OPS>(P, io, lds);
         if (!CONT || !resume_count) break;      // (one instance per workgroup except in a continuation launch)
         __builtin_amdgcn_s_barrier();           // the next instance reuses the LDS block
@@ -255,6 +256,8 @@ struct mmpc_handle_s {
     int budget;             // iterations a launch may spend on an instance before it is suspended (0: no budget)
     int state_doubles;      // save area per instance
     double *d_state;        // [max_batch][state_doubles], allocated when a budget is first set
+    double *d_gscr;         // [max_batch][gscr_doubles]: gain blocks of the specialised kernels of long horizons (MmpcGainBlock), else null
+    int gscr_doubles;
     int *d_list, *d_count;  // compacted list of the suspended instances of the last launch
     int resume_B;           // batch size of the budgeted launch whose suspended instances can still be continued (0: nothing to resume)
     int no_lpt_env, force_generic_env;   // MMPC_NO_LPT / MMPC_FORCE_GENERIC, read once at create (diagnostics)
@@ -408,6 +411,7 @@ extern "C" int mmpc_create(const mmpc_config *cfg, mmpc_handle *out) {
         if (cfg->kind == K && cfg->N == NN && cfg->M == MM && cfg->L == 0) {                                                                       \
             h->fast = 1;                                                                                               \
             h->state_doubles = mmpc_fast_state_doubles<K, NN>(MM);                                                     \
+            h->gscr_doubles = MmpcGainBlock<K, NN>::total;                                                             \
             h->fast_lds_bytes = mmpc_fast_layout<K, NN>(MM, p.obs_per_stage).total * (int)sizeof(double);         \
             if (p.obs_per_stage) HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&h->fast_per_cu, mmpc_fast_kernel<K, NN, MM, WW, false, 1>, MMPC_WAVE, 0)); \
             else HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&h->fast_per_cu, mmpc_fast_kernel<K, NN, MM, WW, false, 0>, MMPC_WAVE, 0)); \
@@ -435,6 +439,7 @@ extern "C" int mmpc_create(const mmpc_config *cfg, mmpc_handle *out) {
     HIPCHK(h, hipMalloc(&h->d_order, B * 4));
     HIPCHK(h, hipMalloc(&h->d_warm, B * 4));
     HIPCHK(h, hipMalloc(&h->d_key, B * 4));
+    if (h->fast && h->gscr_doubles) HIPCHK(h, hipMalloc(&h->d_gscr, B * (size_t)h->gscr_doubles * 8));
     h->order_B = 0;
     h->hint_on = 1;
     h->no_lpt_env = getenv("MMPC_NO_LPT") != nullptr;
@@ -454,7 +459,7 @@ extern "C" int mmpc_destroy(mmpc_handle h) {
     if (!h) return MMPC_E_ARG;
     void *ptrs[] = {h->dp, h->d_x_init, h->d_traj, h->d_uref, h->d_obs, h->d_ulatest, h->d_xguess, h->d_X, h->d_U,
                     h->d_s, h->d_cost, h->d_err, h->d_u0, h->d_status, h->d_iters, h->d_order, h->d_warm, h->d_key, h->d_state,
-                    h->d_list, h->d_count};
+                    h->d_list, h->d_count, h->d_gscr};
     (void)hipSetDevice(h->cfg.device);
     if (h->ev_valid) (void)hipEventSynchronize(h->ev);
     if (h->ev) (void)hipEventDestroy(h->ev);
@@ -530,11 +535,11 @@ static int launch(mmpc_handle h, int B, const double *x_init, const double *traj
                 hipLaunchKernelGGL((mmpc_fast_kernel<K, NN, MM, WW, true, OPS>), dim3(resume ? (B < MMPC_RESUME_GRID ? B : MMPC_RESUME_GRID) : grid), dim3(MMPC_WAVE), 0, st, h->dp, B, \
                                    x_init, traj, uref, ulast, xguess, obs, X, U, s, status, iters, cost, err, resume ? h->d_list : order, \
                                    resume ? 0 : h->budget, h->d_state, h->state_doubles, resume ? h->d_count : (const int *)nullptr,      \
-                                   resume ? (const int *)nullptr : ucount);                                                               \
+                                   resume ? (const int *)nullptr : ucount, h->d_gscr);                                                    \
             else                                                                                                                       \
                 hipLaunchKernelGGL((mmpc_fast_kernel<K, NN, MM, WW, false, OPS>), dim3(grid), dim3(MMPC_WAVE), 0, st, h->dp, B,           \
                                    x_init, traj, uref, ulast, xguess, obs, X, U, s, status, iters, cost, err, order, 0,                  \
-                                   (double *)nullptr, 0, (const int *)nullptr, ucount);
+                                   (double *)nullptr, 0, (const int *)nullptr, ucount, h->d_gscr);
 #define MMPC_X(K, NN, MM, WW)                                                                                          \
         if (h->cfg.kind == K && h->cfg.N == NN && h->cfg.M == MM) {                                                   \
             if (h->cfg.obs_per_stage) { MMPC_LAUNCH_FAST(K, NN, MM, WW, 1) } else { MMPC_LAUNCH_FAST(K, NN, MM, WW, 0) }   \

@@ -35,7 +35,7 @@ static void run(const MmpcParams *P, int B, const double *x_init, const double *
         io.U = U + (size_t)b * N * D::NU;
         io.s = s + (size_t)b * (N + 1);
         io.status = status + b; io.iters = iters + b; io.cost = cost + b; io.err = err + b;
-        io.state = nullptr; io.budget = 0; io.resume = 0;
+        io.state = nullptr; io.budget = 0; io.resume = 0; io.gscr = nullptr;
         MmpcEmu emu = reverse ? MmpcEmu{63, -1, -1} : MmpcEmu{0, 64, 1};
         mmpc_solve_one<KIND>(*P, io, lds, emu);
         free(lds);
@@ -70,7 +70,13 @@ static void run_fast(const MmpcParams *P, int B, const double *x_init, const dou
         io.state = state ? state + (size_t)b * sd : nullptr; io.budget = budget; io.resume = resume;
         if (resume && status[b] != 3) { free(lds); continue; }   // a continuation launch only runs the suspended instances
         MmpcEmu emu = reverse ? MmpcEmu{63, -1, -1} : MmpcEmu{0, 64, 1};
+        // gain block of the long horizons (global memory on the device)
+        const int gd = MmpcGainBlock<KIND, N>::total;
+        double *gscr = gd ? (double *)malloc(sizeof(double) * gd) : nullptr;
+        for (int i = 0; i < gd; i++) gscr[i] = NAN;
+        io.gscr = gscr;
         if (budget > 0 || resume) mmpc_solve_fast<KIND, N, MC, true>(*P, io, lds, emu); else mmpc_solve_fast<KIND, N, MC, false>(*P, io, lds, emu);
+        free(gscr);
         free(lds);
     }
 }

@@ -66,6 +66,13 @@ for t in range(T):
                      ul=ul[b].cpu().numpy(), obs=obs[b].cpu().numpy(), iters=int(out["iters"][b]))
     if "--iters" in sys.argv:
         np.save(os.path.join(ROOT, "gpurun_out", "c5_iters_t%d.npy" % t), out["iters"].cpu().numpy())
+        # the a-priori difficulty key of this tick's data (as mmpc_difficulty_key) and a few other features, for offline schedule studies
+        dd = torch.linalg.norm(loc[:, :, None, :2] - obs[..., :2], dim=3)                     # [B, N+1, M]
+        pen = (obs[..., 2] + 0.4) - dd
+        xd = torch.linalg.norm(x[:, None, None, :2] - obs[:, :1, :, :2], dim=3)[:, 0]        # start position to the discs at stage 0
+        np.savez(os.path.join(ROOT, "gpurun_out", "c5_feat_t%d.npz" % t), key=pen.amax(dim=(1, 2)).cpu().numpy(), key_first=pen[:, :8].amax(dim=(1, 2)).cpu().numpy(),
+                 ncut=(pen.amax(dim=1) > 0).sum(dim=1).cpu().numpy(), start_clear=(xd - obs[:, 0, :, 2] - 0.4).amin(dim=1).cpu().numpy(),
+                 speed=torch.linalg.norm(x[:, 3:5], dim=1).cpu().numpy())
     ul = out["U"].clone(); u0 = out["U"][:, 0]
     xc = torch.minimum(torch.maximum(x, xlo), xhi)
     c, s = torch.cos(xc[:, 2]), torch.sin(xc[:, 2])

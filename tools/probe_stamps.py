@@ -5,10 +5,12 @@ os.environ["MMPC_LIB"] = os.environ.get("MMPC_STAMP_LIB", os.path.join(ROOT, "mo
 import torch, mmpc_loader
 from oracle import synth
 mm = mmpc_loader.load()
-N, M, B = 20, 5, 1024
-d = synth.make_batch(8192, N=N, M=M)
+N, M, B = int(os.environ.get("MMPC_PROBE_N", 20)), int(os.environ.get("MMPC_PROBE_M", 5)), 1024   # (30, 8: the C5 kernel, obstacle table per stage)
+OPS = N == 30
+d = synth.make_batch(8192, N=N, M=M, config_id=5, moving=True) if OPS else synth.make_batch(8192, N=N, M=M)
+if OPS: d["obs"] = d["obs"][:, None, :, :] + np.arange(N + 1)[None, :, None, None] * 0.1 * np.concatenate([d["obs_vel"], np.zeros_like(d["obs_vel"][..., :1])], axis=-1)[:, None, :, :]
 dev = torch.device("cuda", 0)
-ctrl = mm.MPCWholeBody(mm.MobileManipulator(0.1), [], [], N=N, max_batch=B, n_obstacles=M)
+ctrl = mm.MPCWholeBody(mm.MobileManipulator(0.1), [], [], N=N, max_batch=B, n_obstacles=M, obs_per_stage=OPS)
 eng = ctrl._engine
 idx = np.zeros(B, int)
 t = lambda a: torch.from_numpy(np.ascontiguousarray(a[idx])).to(dev)
