@@ -847,8 +847,11 @@ def run_c5(args, torch, mm, dist, rank, world, dev, local_dev, steps, warmup, cp
             del ctrl, eng
             fleet = mm.DeviceFleet(mm, x0, glob, obs0, vel, N=N, device=local_dev)
             fa = {}
-            for mode in ("lockstep", "async"):
-                fn = (lambda: fleet.run_lockstep(T)) if mode == "lockstep" else (lambda: fleet.run_async(T, budget=args.async_budget))
+            for mode in ("lockstep", "async", "groups2", "groups3", "groups4"):
+                if mode.startswith("groups") and B < 1024:
+                    continue
+                fn = (lambda: fleet.run_lockstep(T)) if mode == "lockstep" else ((lambda: fleet.run_async(T, budget=args.async_budget)) if mode == "async" else
+                                                                              (lambda: fleet.run_groups(T, groups=int(mode[6:]))))
                 fn(); torch.cuda.synchronize()
                 f0 = time.perf_counter()
                 for _ in range(steps):
@@ -864,9 +867,21 @@ def run_c5(args, torch, mm, dist, rank, world, dev, local_dev, steps, warmup, cp
                 "note": "same robots, same per-robot results: a launch gives a robot at most %d iterations; robots that converge take "
                         "their plant step and are launched again in the next round (device-side list, mmpc_solve_list_device), suspended "
                         "ones are continued on a side stream and rejoin two rounds later; the reference's warm-start protocol" % args.async_budget}
+            res["groups_out_of_phase"] = {
+                "note": "same robots, same per-robot results (reference warm-start protocol): the fleet as G contiguous groups, each in lock step on its own "
+                        "HIP stream and handle at descending stream priority, so that one group's tail overlaps another group's bulk "
+                        "(mmpc_amd.fleet.DeviceFleet.run_groups)",
+                "unit": "solves/s", "lockstep_value": B * T * steps / fa["lockstep"][0]}
+            for mode in fa:
+                if mode.startswith("groups"):
+                    res["groups_out_of_phase"][mode[6:]] = {
+                        "value": B * T * steps / fa[mode][0], "ms_per_step": fa[mode][0] / steps * 1e3, "all_converged": bool(fa[mode][1]["all_converged"]),
+                        "bitwise_equal_to_lockstep": bool(torch.equal(fa["lockstep"][1]["u0"], fa[mode][1]["u0"]) and torch.equal(fa["lockstep"][1]["x"], fa[mode][1]["x"])
+                                                          and torch.equal(fa["lockstep"][1]["iters"], fa[mode][1]["iters"]))}
             del fleet, fa
         except Exception as e:
-            res["async_receding_horizon"] = {"error": repr(e)}
+            import traceback
+            res["async_receding_horizon"] = {"error": repr(e), "trace": traceback.format_exc()[-1500:]}
     if cpu_instances > 0 and rank == 0:
         # CPU leg: the same two captured ticks (the cold one and the last warm one), first instances, C oracle on the host cores
         ns = min(cpu_instances, B)
@@ -879,7 +894,7 @@ def run_c5(args, torch, mm, dist, rank, world, dev, local_dev, steps, warmup, cp
                                "kind": "port", "sample": "ticks 0 and %d of the timed loop, first %d instances each: " % (T - 1, ns) + legs[0]["sample"],
                                "per_tick": legs, "casadi": legs[0]["casadi"]}
     if compact:
-        keep = ("value", "unit", "ms_per_step", "steps", "roofline", "cpu_baseline", "async_receding_horizon")
+        keep = ("value", "unit", "ms_per_step", "steps", "roofline", "cpu_baseline", "async_receding_horizon", "groups_out_of_phase")
         out = {k: res[k] for k in keep if k in res}
         out["workload"] = res["config"]["workload"]
         out["max_iters_per_tick"] = res["solver"]["max_iters_per_tick"]; out["mean_iters_per_tick"] = res["solver"]["mean_iters_per_tick"]

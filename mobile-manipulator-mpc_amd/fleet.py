@@ -21,14 +21,14 @@ import numpy as np
 
 
 class DeviceFleet:
-    def __init__(self, mm, x0, glob, obs0, vel, N=30, device=0, dt=0.1):
+    def __init__(self, mm, x0, glob, obs0, vel, N=30, device=0, dt=0.1, handles=3):
         import torch
         self.torch = torch
         self.B, self.N, self.M, self.dt = int(x0.shape[0]), int(N), int(obs0.shape[1]), float(dt)
         self.dev = torch.device("cuda", device)
         B, M = self.B, self.M
         mk = lambda: mm.MPCWholeBody(mm.MobileManipulator(dt), [], [], N=N, max_batch=max(B, 1), device=device, n_obstacles=M, obs_per_stage=True)
-        self.ctrls = [mk(), mk(), mk()]          # [0]: lock step (plain kernel); [1], [2]: the two alternating handles of run_async
+        self.ctrls = [mk() for _ in range(handles)]   # [0]: lock step (plain kernel); [1], [2]: the two alternating handles of run_async
         self.engs = [c._engine for c in self.ctrls]
         f64 = dict(dtype=torch.float64, device=self.dev)
         self.f64 = f64
@@ -69,6 +69,13 @@ class DeviceFleet:
 
     # ---- lock step
     def run_lockstep(self, T):
+        res = {}
+        for _ in self._lockstep_ticks(T, res):
+            pass
+        return res
+
+    def _lockstep_ticks(self, T, res):
+        """run_lockstep as a generator: one tick's work is queued on the current stream per next(); the result lands in `res`"""
         torch = self.torch
         B, N = self.B, self.N
         eng = self.engs[0]
@@ -87,7 +94,50 @@ class DeviceFleet:
             hist[:, t] = u0; its[:, t] = out["iters"]
             x = self.plant(x, u0)
             tick += 1
-        return dict(u0=hist, x=x, iters=its, all_converged=ok, rounds=T)
+            res.update(u0=hist, x=x, iters=its, all_converged=ok, rounds=T)
+            yield t
+
+    # ---- groups in lock step, out of phase
+    def run_groups(self, T, groups=2):
+        """The fleet as `groups` contiguous groups of robots, each in lock step on its own HIP stream and handle, the streams at
+        descending priority: the workgroup dispatcher serves the first group's launch first and fills the slots its tail leaves
+        empty - a tick lasts as long as its slowest robot, 200-450 iterations against a mean of 34 - with the other group's
+        launch, so the groups run out of phase and one group's tail overlaps the other's bulk.  Robots do not interact: every
+        robot's numbers are those of run_lockstep (tests/test_gpu_parity.py).  Same reference protocol per robot."""
+        torch = self.torch
+        G = int(groups)
+        if not hasattr(self, "_groups") or len(self._groups) != G:
+            from . import sharding
+            import sys
+            mm = sys.modules[__package__]
+            lo_pr, hi_pr = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, -1)
+            self._groups = []
+            for g in range(G):
+                lo, hi = sharding.shard_bounds(self.B, G, g)
+                sub = DeviceFleet(mm, self.x0[lo:hi], self.glob[lo:hi], self.obs0[lo:hi], self.vel[lo:hi], N=self.N, device=self.dev.index, dt=self.dt,
+                                  handles=1)
+                # (priority: lower number = served first; the last group runs at the default priority)
+                pr = max(hi_pr, min(lo_pr, 0 - (G - 1 - g))) if hi_pr < 0 else 0
+                self._groups.append((lo, hi, sub, torch.cuda.Stream(device=self.dev, priority=pr)))
+        main = torch.cuda.current_stream(self.dev)
+        ev0 = torch.cuda.Event(); ev0.record(main)
+        res = [dict() for _ in range(G)]
+        gens = []
+        for g, (lo, hi, sub, st) in enumerate(self._groups):
+            st.wait_event(ev0)
+            with torch.cuda.stream(st):
+                gens.append(sub._lockstep_ticks(T, res[g]))
+        for t in range(T):
+            for g, (lo, hi, sub, st) in enumerate(self._groups):
+                with torch.cuda.stream(st):
+                    next(gens[g])
+        for g, (lo, hi, sub, st) in enumerate(self._groups):
+            ev = torch.cuda.Event(); ev.record(st); main.wait_event(ev)
+        ok = res[0]["all_converged"]
+        for r_ in res[1:]:
+            ok = ok & r_["all_converged"]
+        return dict(u0=torch.cat([r_["u0"] for r_ in res]), x=torch.cat([r_["x"] for r_ in res]), iters=torch.cat([r_["iters"] for r_ in res]),
+                    all_converged=ok, rounds=T, groups=G)
 
     # ---- asynchronous
     def run_async(self, T, budget=48, max_rounds=None):

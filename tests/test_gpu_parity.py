@@ -422,6 +422,12 @@ def test_asynchronous_receding_horizon_equals_lock_step(mm):
     # and once more with another budget: the split of a solve into launches does not matter
     c = fleet.run_async(T, budget=40)
     assert bool(c["all_converged"]) and torch.equal(a["u0"], c["u0"]) and torch.equal(a["x"], c["x"])
+    # the fleet as groups in lock step on their own streams, out of phase (DeviceFleet.run_groups; ragged groups with G = 3)
+    for G in (2, 3):
+        g = fleet.run_groups(T, groups=G)
+        torch.cuda.synchronize()
+        assert bool(g["all_converged"]) and g["groups"] == G
+        assert torch.equal(a["u0"], g["u0"]) and torch.equal(a["x"], g["x"]) and torch.equal(a["iters"], g["iters"])
 
 
 @pytest.mark.gpu
