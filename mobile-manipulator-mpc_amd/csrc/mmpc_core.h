@@ -1743,9 +1743,12 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
         };
         LANES_BEGIN
         double ap = 1.0, ad = 1.0, dphi = 0.0;
-        for (int k = lane; k < NS; k += MMPC_WAVE) {
+        // one item per (row, stage), row-major: the lanes of a trip run the same row type on different stages (three rows of NS
+        // stages per trip) instead of 21 lanes walking through all the rows of their stage
+        for (int item = lane; item < R * NS; item += MMPC_WAVE) {
+            const int r = item / NS, k = item - r * NS;
             const double *dx = DX + k * NX;
-            for (int r = 0; r < R; r++) {
+            {
                 double h, jd, b;
                 if (r < SL_C) {
                     if (!box_bound(k, r, b)) continue;
@@ -1782,6 +1785,9 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                 if (dzv < 0) ad = mmpc_min(ad, -tau * z / dzv);
                 dphi -= mu * dtv / t;
             }
+        }
+        for (int k = lane; k < NS; k += MMPC_WAVE) {
+            const double *dx = DX + k * NX;
             for (int j = 0; j < NX; j++) dphi += GX[k * NX + j] * dx[j];
             if (k < N) for (int a = 0; a < NU; a++) dphi += GU[k * NU + a] * DU[k * NU + a];
             dphi += 2 * Sw * S[k] * DS[k];
@@ -1847,10 +1853,11 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
 #endif
         if (!teq) mmpc_prox_update(alpha, prox, nsmall);   // (with the terminal equality the forced correction makes nu grow like prox)
         MMPC_GS(8)
-        // ---- update
+        // ---- update (one item per (row, stage), row-major as in D2)
         LANES_BEGIN
-        for (int k = lane; k < NS; k += MMPC_WAVE) {
-            for (int r = 0; r < R; r++) {
+        for (int item = lane; item < R * NS; item += MMPC_WAVE) {
+            const int r = item / NS, k = item - r * NS;
+            {
                 double dtv, b;
                 if (r < SL_C) {
                     if (!box_bound(k, r, b)) continue;
