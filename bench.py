@@ -840,7 +840,7 @@ def run_c5(args, torch, mm, dist, rank, world, dev, local_dev, steps, warmup, cp
     if world > 1:
         res["per_rank"] = [{"rank": r, "converged": int(p[0]), "solves": int(p[1]), "max_iters": int(p[2]), "kernel_ms_per_pass": p[3]} for r, p in enumerate(allp)]
         res["gather_checked"] = gok
-    else:
+    elif not args.no_extras:
         # the same fleet driven asynchronously (mmpc_amd.fleet.DeviceFleet.run_async: iteration budget per launch, the robots that
         # converge move on, the suspended ones are continued on a side stream and rejoin later), against the same class's lock step
         try:

@@ -158,6 +158,11 @@ struct MmpcFastLayout {
 // per-instance block of global memory (L2 / MALL resident): the Riccati legs only store them, the back-substitution is one
 // batched load / store pass and the roll-out fetches its gain row ahead of the chain.  At N = 30, M = 8 that is 52.6 -> 40.6 KB
 // of LDS per problem: four resident problems per CU - one per SIMD - instead of three.
+#ifndef MMPC_GK_MASK
+#define MMPC_GK_MASK 0   // gain block: 1 = lanes without an entry of a pivot row do not store, 0 = they store to a dump slot of the block as the
+                         // LDS variant does (measured on C5: the masked store - exec handling on the chain of every leg - 300 k against 314 k solves/s,
+                         // for 10 % less write traffic out of L2)
+#endif
 #ifndef MMPC_GAINS_GLOBAL_NMIN
 #define MMPC_GAINS_GLOBAL_NMIN MMPC_SLIM_NMIN
 #endif
@@ -1294,7 +1299,9 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                     }
                     ls.opa = own ? -w : 0.0;
                     ls.opb = own ? cb : 0.0;
-                    *(double *)((char *)KBASE + (unsigned)(ls.kl_b[leg] + MMPC_MUL24(k, ls.kl_s[leg]))) = w;   // (lanes that hold no entry of the row write to their dump slot: no branch)
+                    // (lanes that hold no entry of the row write to their dump slot - no branch; MMPC_GK_MASK: masked instead, see there)
+                    if (!(GK && MMPC_GK_MASK) || ls.kl_s[leg] != 0)
+                        *(double *)((char *)KBASE + (unsigned)(ls.kl_b[leg] + MMPC_MUL24(k, ls.kl_s[leg]))) = w;
                     LANES_END_REG
                     MMPC_MFMA(rM, ls.opa, ls.opb)
                 }

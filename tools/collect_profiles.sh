@@ -20,11 +20,11 @@ bash tools/pmc_collect.sh $o/pmc > /dev/null
 cp $o/pmc/summary.json $o/pmc_mfma.json
 echo "[4/8] C5 kernel trace"
 mkdir -p $o/c5
-rocprofv3 --kernel-trace --stats -d $o/c5/kt -o run --output-format csv -- python3 bench.py --config c5 --steps 1 --warmup 2 --no-cpu > $o/c5/kt.log 2>&1
+rocprofv3 --kernel-trace --stats -d $o/c5/kt -o run --output-format csv -- python3 bench.py --config c5 --steps 1 --warmup 2 --no-cpu --no-extras > $o/c5/kt.log 2>&1
 cp $(find $o/c5/kt -name "*kernel_stats.csv" | head -1) $o/c5_kernel_stats.csv
 echo "[5/8] C5 FETCH_SIZE / WRITE_SIZE"
-rocprofv3 --pmc FETCH_SIZE -d $o/c5/pf -o run --output-format csv -- python3 bench.py --config c5 --steps 1 --warmup 2 --no-cpu > $o/c5/pf.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $o/c5/pw -o run --output-format csv -- python3 bench.py --config c5 --steps 1 --warmup 2 --no-cpu > $o/c5/pw.log 2>&1
+rocprofv3 --pmc FETCH_SIZE -d $o/c5/pf -o run --output-format csv -- python3 bench.py --config c5 --steps 1 --warmup 2 --no-cpu --no-extras > $o/c5/pf.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $o/c5/pw -o run --output-format csv -- python3 bench.py --config c5 --steps 1 --warmup 2 --no-cpu --no-extras > $o/c5/pw.log 2>&1
 python3 tools/pmc_traffic.py $o/c5 "mmpc_fast_kernel" $o/c5_pmc_traffic.json $((8192 * 14336)) "bench.py --config c5 --steps 1 --warmup 2 --no-cpu (B=8192, N=30, M=8 moving obstacles, per tick)"
 echo "[6/8] phase stamps"
 if [ -f mobile-manipulator-mpc_amd/csrc/libmmpc_stamp.so ]; then python3 tools/probe_stamps.py > $o/phase_stamps.txt 2>&1; fi
