@@ -419,7 +419,7 @@ def main():
             res["generic_kernel"] = {"ms": g_ms, "value": Bl / (g_ms * 1e-3), "unit": "solves/s",
                                      "lds_bytes_per_problem": ctrlg._engine.lds_bytes, "problems_per_cu": ctrlg._engine.problems_per_cu,
                                      "max_abs_dX_vs_specialised": float((outg["X"] - out["X"]).abs().max()),
-                                     "note": "mmpc_solve_kernel<0> (all state in LDS, scalar Riccati) on the same batch"}
+                                     "note": "mmpc_solve_kernel<0> (all state in LDS, Riccati pass on MFMA tiles) on the same batch"}
             del ctrlg, outg
             # (1d) the demo's shape (config C1: N = 20, three circle obstacles, two half-space planes): generic kernel with a
             # static LDS block (MMPC_STATIC_LIST), 2048 starts around the planes' ridge, intended rows and rows as written
@@ -505,7 +505,7 @@ def main():
             # (7) config C5 (N = 30, 8 moving obstacles, warm-started receding horizon) in short form: `python bench.py --config c5`
             # prints the full line
             try:
-                res["c5"] = run_c5(args, torch, mm, None, 0, 1, dev, local_dev, steps=2, warmup=2, cpu_instances=256, compact=True)
+                res["c5"] = run_c5(args, torch, mm, None, 0, 1, dev, local_dev, steps=2, warmup=4, cpu_instances=256, compact=True)
             except Exception as e:
                 res["c5"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu:
@@ -567,7 +567,7 @@ def c1_shape_extra(mm, robot, dev, B=2048, N=20):
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     xi, trd, ob = t(x), t(tr), t(obs)
     z = torch.zeros((B, N, 5), dtype=torch.float64, device=dev)
-    out = {"unit": "solves/s", "batch": B, "note": "mmpc_solve_kernel_static<0,20,3,0,2,*>: all state in LDS, scalar Riccati; a-priori order"}
+    out = {"unit": "solves/s", "batch": B, "note": "mmpc_solve_kernel_static<0,20,3,0,2,*>: all state in LDS, Riccati pass on MFMA tiles; a-priori order"}
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for name, fc in (("intended_rows", False), ("rows_as_written", None)):
         ctrl = mm.MPCWholeBody(robot, [], oml, N=N, max_batch=B, device=dev.index if dev.index is not None else 0, n_obstacles=3, faithful_convex=fc)
