@@ -98,7 +98,10 @@ __global__ __launch_bounds__(MMPC_WAVE, WPE) void mmpc_fast_kernel(
     int *__restrict__ status, int *__restrict__ iters, double *__restrict__ cost, double *__restrict__ err,
     const int *__restrict__ order, int budget, double *__restrict__ state, int state_stride, const int *__restrict__ resume_count,
     const int *__restrict__ list_count, double *__restrict__ gscr) {
-    __shared__ double lds[mmpc_fast_layout<KIND, N>(MC, OPS).total];
+#ifndef MMPC_LDS_PAD
+#define MMPC_LDS_PAD 0     // (experiments: extra doubles of LDS per problem, to lower the number of resident problems per CU)
+#endif
+    __shared__ double lds[mmpc_fast_layout<KIND, N>(MC, OPS).total + MMPC_LDS_PAD];
     typedef MmpcDims<KIND> D;
     // A continuation launch (resume_count != null): `order` is the compacted list of the suspended instances, *resume_count its
     // length, and the grid is SMALL (MMPC_RESUME_GRID workgroups that stride over the list): a handful of instances is left,

@@ -12,7 +12,7 @@ if OPS: d["obs"] = d["obs"][:, None, :, :] + np.arange(N + 1)[None, :, None, Non
 dev = torch.device("cuda", 0)
 ctrl = mm.MPCWholeBody(mm.MobileManipulator(0.1), [], [], N=N, max_batch=B, n_obstacles=M, obs_per_stage=OPS)
 eng = ctrl._engine
-idx = np.zeros(B, int)
+idx = np.arange(B) if os.environ.get("MMPC_PROBE_DISTINCT") else np.zeros(B, int)   # (distinct instances: the waves of a CU drift out of phase)
 t = lambda a: torch.from_numpy(np.ascontiguousarray(a[idx])).to(dev)
 xi = t(np.clip(d["x_init"], ctrl.xlim[0], ctrl.xlim[1])); tr = t(d["traj_ref"]); ur = t(d["u_ref"]); ob = t(d["obs"])
 ul = torch.zeros((B, N, 5), dtype=torch.float64, device=dev)
