@@ -756,15 +756,20 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
         // ============================================================ E1: evaluation + KKT partials
         LANES_BEGIN
         double e_d = 0.0, e_p = 0.0, tzmax = 0.0, tzmin = 1e300, zsum = 0.0;
+        // the merit function at this point (what the line search compares its trials with) falls out of the same evaluation:
+        // objective terms, l1 infeasibility, sum of log t (the barrier parameter may still change before the line search)
+        double m_f = 0.0, m_th = 0.0, m_lg = 0.0;
         for (int k = lane; k < NS; k += MMPC_WAVE) {
             const double *xk = X + k * NX;
+            double mant = 1.0; int ex = 0;   // product of the mantissas of the stage's slacks + sum of their exponents (one log per stage)
+            auto acc = [&](double tv) { int e2; mant *= frexp(tv, &e2); ex += e2; if (mant < 1e-200) { mant = frexp(mant, &e2); ex += e2; } };
             double sn, cs;
             MMPC_SINCOS(xk[2], &sn, &cs);
             double rdx[NX], rdu[NU > 0 ? NU : 1];
             // cost gradient (mpc_wholebody_qref.py:192-201,240-242; mpc_base.py:146-153)
             {
                 double g[NX];
-                mmpc_state_cost<KIND>(WTS, k == N, xk, XREF + k * NREF, g, nullptr, false);
+                m_f += Sw * S[k] * S[k] + 0.5 * mmpc_state_cost<KIND>(WTS, k == N, xk, XREF + k * NREF, g, nullptr, false);
                 for (int i = 0; i < NX; i++) { GX[k * NX + i] = g[i]; rdx[i] = g[i] + (k >= 1 ? LAM[k * NX + i] : 0.0); }
             }
             double *cv = CV + k * MMPC_NCV;
@@ -784,15 +789,21 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                     const double c = xn[j] - X[(k + 1) * NX + j];
                     CD[k * NX + j] = c;
                     e_p = mmpc_max_err(e_p, fabs(c));
+                    m_th += fabs(c);
                     zsum += fabs(LAM[(k + 1) * NX + j]);
                 }
+                double qin = 0.0;
                 for (int a = 0; a < NU; a++) {
-                    double v = 0.0;
-                    for (int b = 0; b < NU; b++)
-                        v += WTS[MMPC_W_R2 + a * NU + b] * (uk[b] - UREF[k * NU + b]) + WTS[MMPC_W_W2 + a * NU + b] * (uk[b] - ULAST[k * NU + b]);
+                    double v = 0.0, vr = 0.0, vw = 0.0;
+                    for (int b = 0; b < NU; b++) {
+                        const double tr = WTS[MMPC_W_R2 + a * NU + b] * (uk[b] - UREF[k * NU + b]), tw = WTS[MMPC_W_W2 + a * NU + b] * (uk[b] - ULAST[k * NU + b]);
+                        v += tr + tw; vr += tr; vw += tw;
+                    }
                     GU[k * NU + a] = v;
                     rdu[a] = v;
+                    qin += (uk[a] - UREF[k * NU + a]) * vr + (uk[a] - ULAST[k * NU + a]) * vw;
                 }
+                m_f += 0.5 * qin;
                 // - A^T lam_{k+1}, - B^T lam_{k+1}
                 const double *ln = LAM + (k + 1) * NX;
                 for (int j = 0; j < NV; j++) {
@@ -811,7 +822,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                 else if (r < SL_XLO) { h = U[k * NU + r - NU] - b; rdu[r - NU] += z; }
                 else if (r < SL_XHI) { h = b - xk[r - SL_XLO]; rdx[r - SL_XLO] -= z; }
                 else { h = xk[r - SL_XHI] - b; rdx[r - SL_XHI] += z; }
-                e_p = mmpc_max_err(e_p, fabs(h + t));
+                e_p = mmpc_max_err(e_p, fabs(h + t)); m_th += fabs(h + t); acc(t);
                 tzmax = mmpc_max(tzmax, t * z); tzmin = mmpc_min(tzmin, t * z); zsum += z;
             }
             // circle rows: value, gradient, Hessian (mpc_wholebody_qref.py:49-54)
@@ -827,7 +838,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                 HC[(k * M + m) * 3 + 2] = -(1 - nyv * nyv) * id;
                 const double t = T[k * R + SL_C + m], z = Z[k * R + SL_C + m];
                 rdx[0] -= nxv * z; rdx[1] -= nyv * z; rds -= z;
-                e_p = mmpc_max_err(e_p, fabs(h + t));
+                e_p = mmpc_max_err(e_p, fabs(h + t)); m_th += fabs(h + t); acc(t);
                 tzmax = mmpc_max(tzmax, t * z); tzmin = mmpc_min(tzmin, t * z); zsum += z;
             }
             if (NSELF) {
@@ -841,7 +852,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                     const double t = T[k * R + SL_S + i], z = Z[k * R + SL_S + i];
                     for (int a = 0; a < 6; a++) { GSF[(k * NSELF + i) * 6 + a] = g6[a]; rdx[kY[a]] += g6[a] * z; }
                     selfz += z;
-                    e_p = mmpc_max_err(e_p, fabs(h + t));
+                    e_p = mmpc_max_err(e_p, fabs(h + t)); m_th += fabs(h + t); acc(t);
                     tzmax = mmpc_max(tzmax, t * z); tzmin = mmpc_min(tzmin, t * z); zsum += z;
                 }
                 for (int i = 0; i < NHS; i++) {   // half-space rows, bound to s_k (s_N at the end, :268)
@@ -851,7 +862,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                     const double t = T[k * R + SL_H + i], z = Z[k * R + SL_H + i];
                     for (int a = 0; a < 6; a++) { GHS[(k * 6 + i) * 6 + a] = g6[a]; rdx[kY[a]] += g6[a] * z; }
                     rds -= z;
-                    e_p = mmpc_max_err(e_p, fabs(h + t));
+                    e_p = mmpc_max_err(e_p, fabs(h + t)); m_th += fabs(h + t); acc(t);
                     tzmax = mmpc_max(tzmax, t * z); tzmin = mmpc_min(tzmin, t * z); zsum += z;
                 }
                 if (NQ) {   // rows of the NLP as written (quirk Q8): planes 0..j at x_k, planes j+1.. at x_{k-1}
@@ -873,7 +884,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                                 if (br) rq[a] += g6[a] * z; else rdx[kY[a]] += g6[a] * z;
                             }
                             rds -= z;
-                            e_p = mmpc_max_err(e_p, fabs(h + t));
+                            e_p = mmpc_max_err(e_p, fabs(h + t)); m_th += fabs(h + t); acc(t);
                             tzmax = mmpc_max(tzmax, t * z); tzmin = mmpc_min(tzmin, t * z); zsum += z;
                         }
                     }
@@ -887,13 +898,16 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                 for (int j = 0; j < 2; j++) {
                     rdx[j] += NUEQ[j];
                     e_p = mmpc_max_err(e_p, fabs(xk[j] - XREF[N * NX + j]));
+                    m_th += fabs(xk[j] - XREF[N * NX + j]);
                     zsum += fabs(NUEQ[j]);
                 }
             }
             if (NQ) { for (int i = 0; i < NX; i++) RDX[k * NX + i] = rdx[i]; }   // finished in E1b (the next stage's rows add to it)
             else if (k >= 1) for (int i = 0; i < NX; i++) e_d = mmpc_max_err(e_d, fabs(rdx[i]));
             if (k < N) for (int a = 0; a < NU; a++) e_d = mmpc_max_err(e_d, fabs(rdu[a]));
+            m_lg += log(mant) + (double)ex * 0.69314718055994530942;
         }
+        RED[6 * MMPC_WAVE + lane] = m_f; RED[7 * MMPC_WAVE + lane] = m_th; PF[lane] = m_lg;   // (PF, with TT behind it: >= 64 doubles, not in use before the backward pass)
         RED[0 * MMPC_WAVE + lane] = e_d; RED[1 * MMPC_WAVE + lane] = e_p; RED[2 * MMPC_WAVE + lane] = tzmax;
         RED[3 * MMPC_WAVE + lane] = tzmin; RED[4 * MMPC_WAVE + lane] = zsum;
         if (lane == 0) MISC[0] = 0.0;
@@ -914,6 +928,8 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
         RED[5 * MMPC_WAVE + lane] = e_s;
         LANES_END
         double err_d = 0.0, err_p = 0.0, tzmax = 0.0, tzmin = 1e300, zsum = 0.0;
+        double m_F0 = 0.0, m_TH0 = 0.0, m_LG0 = 0.0;
+        for (int i = 0; i < MMPC_WAVE; i++) { m_F0 += RED[6 * MMPC_WAVE + i]; m_TH0 += RED[7 * MMPC_WAVE + i]; m_LG0 += PF[i]; }
         for (int i = 0; i < MMPC_WAVE; i++) {
             err_d = mmpc_max_err(err_d, mmpc_max_err(RED[0 * MMPC_WAVE + i], RED[5 * MMPC_WAVE + i]));
             err_p = mmpc_max_err(err_p, RED[1 * MMPC_WAVE + i]);
@@ -1801,14 +1817,8 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
             dphi += RED[2 * MMPC_WAVE + i];
         }
         MMPC_GS(6)
-        // ---- merit at the current point (needs DTR from D2 only formally: alpha = 0)
-        LANES_BEGIN
-        double ph = 0.0, th = 0.0;
-        for (int k = lane; k < NS; k += MMPC_WAVE) { double a, b; stage_merit(k, 0.0, a, b); ph += a; th += b; }
-        RED[3 * MMPC_WAVE + lane] = ph; RED[4 * MMPC_WAVE + lane] = th;
-        LANES_END
-        double phi0 = 0.0, th0 = 0.0;
-        for (int i = 0; i < MMPC_WAVE; i++) { phi0 += RED[3 * MMPC_WAVE + i]; th0 += RED[4 * MMPC_WAVE + i]; }
+        // ---- merit at the current point: from the evaluation E1 (same point, same slacks), with the barrier parameter as it is now
+        const double phi0 = m_F0 - mu * m_LG0, th0 = m_TH0;
         if (!mmpc_finite(phi0) || !mmpc_finite(th0)) { status = 2; break; }   // (an infinite reference / obstacle: opti.solve() raises)
         if (!filt_init) { nfilt = 0; th_max = 1e4 * mmpc_max(1.0, th0); th_min = 1e-4 * mmpc_max(1.0, th0); filt_init = 1; }
 
