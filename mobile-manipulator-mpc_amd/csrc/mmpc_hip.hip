@@ -185,11 +185,28 @@ __global__ __launch_bounds__(256) void mmpc_collect_suspended_list(const int *__
 // three quarters of what the exact longest-first order gains over batch order (list-scheduling the measured counts on
 // 1024 slots: 192 iterations of wall time in batch order, 168 by this key, 160 exact).  Written as a pseudo iteration
 // count 0..255 so that mmpc_lpt_order sorts it.
+// With half-space obstacles (whole-body kind, L > 0) a second term: how far the arm's sample points of the START state reach
+// into the planes (the largest half-space row value at x_init; [-0.5 m clear .. 0.4 m inside] -> 0..255), the larger of the two
+// is the key.  On the demo's shape (2048 starts around the two planes, list-scheduled on 256 slots: 372 iterations of wall time
+// in batch order, 250 exact) it gives 258 for the rows as written and 256 for the intended rows (exact there: 219) - the
+// circles of that scenario are far away and their key alone is batch order.
 __global__ __launch_bounds__(64) void mmpc_difficulty_key(int B, int N, int M, int nref, int obs_per_stage,
                                                           const double *__restrict__ traj_ref, const double *__restrict__ obs,
-                                                          int *__restrict__ key) {
+                                                          int *__restrict__ key, const MmpcParams *__restrict__ Pp,
+                                                          const double *__restrict__ x_init, int planes) {
     const int b = blockIdx.x * 64 + threadIdx.x;
     if (b >= B) return;
+    int key_hs = 0;
+    if (planes > 0) {
+        const MmpcParams &P = *Pp;
+        const double *x0 = x_init + (size_t)b * 9;
+        double sn, cs, dr[3], dz[3], worst_hs = -1.0e9;
+        mmpc_sincos(x0[2], &sn, &cs);
+        mmpc_arm_segments(x0[6], x0[7], x0[8], dr, dz);
+        for (int i = 0; i < 6; i++) worst_hs = fmax(worst_hs, mmpc_hs_row(P, i, x0[0], x0[1], cs, sn, dr, dz, nullptr));
+        const double q2 = (worst_hs + 0.5) * (255.0 / 0.9);
+        key_hs = (int)fmin(fmax(q2, 0.0), 255.0);   // (a NaN start: 0 - the solve reports it)
+    }
     const double *tr = traj_ref + (size_t)b * (N + 1) * nref;
     const double *ob = obs + (size_t)b * (obs_per_stage ? N + 1 : 1) * M * 3;
     double worst = -1.0e9;
@@ -203,7 +220,8 @@ __global__ __launch_bounds__(64) void mmpc_difficulty_key(int B, int N, int M, i
     }
     // [-1.5 m clearance .. 1.0 m penetration] -> 0..255
     const double q = (worst + 1.5) * (255.0 / 2.5);
-    key[b] = M > 0 ? (int)fmin(fmax(q, 0.0), 255.0) : 0;
+    const int key_c = M > 0 ? (int)fmin(fmax(q, 0.0), 255.0) : 0;
+    key[b] = key_c > key_hs ? key_c : key_hs;
 }
 
 // out_u0[b][a] = U[b][0][a]
@@ -525,12 +543,13 @@ static int launch(mmpc_handle h, int B, const double *x_init, const double *traj
     if (ulist && !use_fast) return fail(h, MMPC_E_UNSUPPORTED, "%s%s", "list launches need a specialised kernel (this (kind, N, M, weights) runs the generic one)");
     const bool lpt = !resume && !ulist && h->hint_on && !h->no_lpt_env && B <= h->cfg.max_batch && B > 256;
     const bool history = lpt && h->hint_on == 1 && h->order_B == B;
-    if (lpt && !history && h->cfg.M > 0) {
+    const int key_planes = (h->cfg.kind == MMPC_KIND_WHOLEBODY && h->hp.L > 0) ? h->hp.L : 0;
+    if (lpt && !history && (h->cfg.M > 0 || key_planes)) {
         hipLaunchKernelGGL(mmpc_difficulty_key, dim3((B + 63) / 64), dim3(64), 0, st, B, h->cfg.N, h->cfg.M, h->nref,
-                           h->hp.obs_per_stage, traj, obs, h->d_key);
+                           h->hp.obs_per_stage, traj, obs, h->d_key, h->dp, x_init, key_planes);
         hipLaunchKernelGGL(mmpc_lpt_order, dim3(1), dim3(1024), 0, st, B, h->d_key, h->d_order);
     }
-    const int *order = ulist ? ulist : ((history || (lpt && h->cfg.M > 0)) ? h->d_order : nullptr);
+    const int *order = ulist ? ulist : ((history || (lpt && (h->cfg.M > 0 || key_planes))) ? h->d_order : nullptr);
     const int grid = ulist ? ucap : B;
     if (use_fast) {
 #define MMPC_LAUNCH_FAST(K, NN, MM, WW, OPS)                                                                              \

@@ -24,7 +24,7 @@ dev = torch.device("cuda", 0)
 t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 xi, trd, ob = t(x), t(tr), t(obs)
 z = torch.zeros((B, N, 5), dtype=torch.float64, device=dev)
-eng.set_schedule_hint(2)
+eng.set_schedule_hint(1 if "--history" in sys.argv else 2)
 out = eng.solve_batch_device(xi, trd, z, z, ob); torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 ts = []
@@ -34,3 +34,6 @@ it = out["iters"].cpu().numpy(); st = out["status"].cpu().numpy()
 print("C1 shape (%s rows) B=%d lds %d B, %d per CU: %.2f ms -> %.0f solves/s; iters mean %.1f max %d; converged %.4f; checksum %.9f" % (
     "as-written" if as_written else "intended", B, eng.lds_bytes, eng.problems_per_cu, min(ts), B / min(ts) * 1e3, it.mean(), it.max(), (st == 0).mean(),
     float(out["X"][st == 0].double().sum().item())))
+
+if "--dump-iters" in sys.argv:
+    np.save(os.path.join(ROOT, "gpurun_out", "c1_iters_%s_%d.npy" % ("aw" if as_written else "int", B)), it)
