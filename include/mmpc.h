@@ -51,7 +51,9 @@ typedef struct mmpc_config {
     int N;             /* horizon, 1 <= N <= 63 */
     int M;             /* circle obstacles per instance, 0 <= M <= 16 (len(obstacle_list)) */
     int obs_per_stage; /* 0: obs[B][M][3]; 1: obs[B][N+1][M][3] */
-    int max_batch;     /* capacity of the device-side warm-start buffers */
+    int max_batch;     /* capacity of the device-side buffers: warm start, outputs of the host-pointer call, launch order and - for
+                          horizons N >= 21 on a specialised kernel - one 8 (N nu (nx + 1) + N nu (nu - 1) / 2 + 64) byte block of
+                          feedback gains per instance (14.9 KB at N = 30: 122 MB for 8192 instances) */
     int device;        /* HIP device ordinal */
     int max_iter;      /* interior-point iteration cap (reference passes ipopt.max_iter 2000, :280) */
     double dt;         /* robot.dt (demo_wholebody_qref.py:10) */

@@ -152,16 +152,20 @@ __global__ __launch_bounds__(MMPC_WAVE, WPE) void mmpc_fast_kernel(
 // Longest-processing-time-first order for the NEXT launch: instances sorted by descending iteration count of
 // this one (counting sort, 256 bins, one workgroup).  Kernel time is bounded by the slowest instance; starting
 // the slow ones first removes the tail.  In receding-horizon use consecutive ticks have correlated difficulty.
-__global__ __launch_bounds__(1024) void mmpc_lpt_order(int B, const int *__restrict__ iters, int *__restrict__ order) {
+// (One workgroup of MMPC_LPT_THREADS = 256 threads: while another stream's solve launch fills the chip - groups of robots out of
+//  phase, fleet.py:run_groups - a workgroup only gets a CU slot where a solver wave has just ended, and four waves fit the one
+//  SIMD that frees; the 1024-thread form of round 2 needed two free SIMDs of one CU at once and waited up to 7 ms for them.)
+#define MMPC_LPT_THREADS 256
+__global__ __launch_bounds__(MMPC_LPT_THREADS) void mmpc_lpt_order(int B, const int *__restrict__ iters, int *__restrict__ order) {
     __shared__ int hist[256], start[256];
     const int t = (int)threadIdx.x;
-    if (t < 256) hist[t] = 0;
+    for (int v = t; v < 256; v += MMPC_LPT_THREADS) hist[v] = 0;
     __syncthreads();
-    for (int i = t; i < B; i += 1024) { int v = iters[i]; v = v < 0 ? 0 : (v > 255 ? 255 : v); atomicAdd(&hist[v], 1); }
+    for (int i = t; i < B; i += MMPC_LPT_THREADS) { int v = iters[i]; v = v < 0 ? 0 : (v > 255 ? 255 : v); atomicAdd(&hist[v], 1); }
     __syncthreads();
     if (t == 0) { int acc = 0; for (int v = 255; v >= 0; v--) { start[v] = acc; acc += hist[v]; } }
     __syncthreads();
-    for (int i = t; i < B; i += 1024) { int v = iters[i]; v = v < 0 ? 0 : (v > 255 ? 255 : v); order[atomicAdd(&start[v], 1)] = i; }
+    for (int i = t; i < B; i += MMPC_LPT_THREADS) { int v = iters[i]; v = v < 0 ? 0 : (v > 255 ? 255 : v); order[atomicAdd(&start[v], 1)] = i; }
 }
 
 // list of the instances a budgeted launch left suspended (any order), and their number
@@ -547,7 +551,7 @@ static int launch(mmpc_handle h, int B, const double *x_init, const double *traj
     if (lpt && !history && (h->cfg.M > 0 || key_planes)) {
         hipLaunchKernelGGL(mmpc_difficulty_key, dim3((B + 63) / 64), dim3(64), 0, st, B, h->cfg.N, h->cfg.M, h->nref,
                            h->hp.obs_per_stage, traj, obs, h->d_key, h->dp, x_init, key_planes);
-        hipLaunchKernelGGL(mmpc_lpt_order, dim3(1), dim3(1024), 0, st, B, h->d_key, h->d_order);
+        hipLaunchKernelGGL(mmpc_lpt_order, dim3(1), dim3(MMPC_LPT_THREADS), 0, st, B, h->d_key, h->d_order);
     }
     const int *order = ulist ? ulist : ((history || (lpt && (h->cfg.M > 0 || key_planes))) ? h->d_order : nullptr);
     const int grid = ulist ? ucap : B;
@@ -594,7 +598,7 @@ static int launch(mmpc_handle h, int B, const double *x_init, const double *traj
         h->resume_B = B;
     }
     if (lpt && h->hint_on == 1) {
-        hipLaunchKernelGGL(mmpc_lpt_order, dim3(1), dim3(1024), 0, st, B, iters, h->d_order);
+        hipLaunchKernelGGL(mmpc_lpt_order, dim3(1), dim3(MMPC_LPT_THREADS), 0, st, B, iters, h->d_order);
         h->order_B = B;
     }
     HIPCHK(h, hipEventRecord(h->ev, st));
