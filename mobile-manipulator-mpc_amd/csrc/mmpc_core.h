@@ -57,12 +57,18 @@ __device__ __forceinline__ int mmpc_lane_id() { int l = (int)threadIdx.x; asm vo
 // Diagnostic build only (-DMMPC_STAMP_GEN): per-phase wave-cycle accounting of the generic kernel (tools/probe_stamps_generic.py)
 #if defined(MMPC_STAMP_GEN) && !defined(MMPC_EMU)
 __device__ unsigned long long mmpc_gstamp_acc[16];
-#define MMPC_G0() unsigned long long g_prev_ = __builtin_readcyclecounter(), g_now_, g_acc_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define MMPC_G0() unsigned long long g_prev_ = __builtin_readcyclecounter(), g_now_, g_acc_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, g_acc2_[6] = {0, 0, 0, 0, 0, 0};
 #define MMPC_GS(i) { g_now_ = __builtin_readcyclecounter(); g_acc_[i] += g_now_ - g_prev_; g_prev_ = g_now_; }
-#define MMPC_GEND() { if (threadIdx.x == 0) for (int i_ = 0; i_ < 10; i_++) atomicAdd(&mmpc_gstamp_acc[i_], g_acc_[i_]); }
+// (slots 10..15: pieces of the Riccati pass - the terminal block R0, the two MFMA chains, the hand-over of the next stage's operands, the
+//  elimination legs, the P store, gains + border columns; they are INSIDE slot 3's interval and subtract from it)
+#define MMPC_G2() unsigned long long h_prev_ = __builtin_readcyclecounter(), h_now_;
+#define MMPC_GS2(i) { h_now_ = __builtin_readcyclecounter(); g_acc2_[i] += h_now_ - h_prev_; h_prev_ = h_now_; }
+#define MMPC_GEND() { if (threadIdx.x == 0) { for (int i_ = 0; i_ < 10; i_++) atomicAdd(&mmpc_gstamp_acc[i_], g_acc_[i_]); for (int i_ = 0; i_ < 6; i_++) atomicAdd(&mmpc_gstamp_acc[10 + i_], g_acc2_[i_]); } }
 #else
 #define MMPC_G0()
 #define MMPC_GS(i)
+#define MMPC_G2()
+#define MMPC_GS2(i)
 #define MMPC_GEND()
 #endif
 
@@ -508,6 +514,7 @@ struct MmpcGenRic {
     static_assert(D::NV + 1 <= 16, "stage matrix over (x, 1, u) must fit one 16x16 tile");
     unsigned ab_o[NKB];                  // [A B c; 0 0 1] operand rows 4r+g, column j: LDS offset | stage stride << 16
     int p_o[4], p_s[4];                  // where register r of [P_k | p_k] is stored (offset at stage 0, stage stride; a dump slot otherwise)
+    unsigned st_o[4][4];                 // stage-matrix entry of register r = sum of up to four LDS words: offset | stage stride << 16 | (only at the last stage) << 31
     int kl_b[NLEG], kl_s[NLEG];          // where the lane stores its entry of the normalised pivot row(s) of leg l
     MmpcAcc rP, rT, rM;                  // cost-to-go [P p; p^T .], its product with the dynamics, stage matrix
     double rAB[NKB], opa, opb;           // MFMA operands
@@ -722,6 +729,36 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
             if (i < NX && jl < NX && i >= jl) { off = L.HXX + i * (i + 1) / 2 + jl; stride = NXX; }
             else if (i < NX && jl == NV) { off = L.QX + i; stride = NX; }
             ls.p_o[r] = off; ls.p_s[r] = stride;
+        }
+        for (int r = 0; r < 4; r++) {
+            // entry (ti, tj) of a stage's matrix [Hxx Hxu q_x; Hux Huu q_u; q^T 0] in tile numbering (what R2 of the scalar pass adds
+            // to [A B]^T P [A B]), as the sum - in this order - of up to four words: packed Hxx; gradient in row / column NX;
+            // Hux = dense block of a slack eliminated at the last stage (quirk Q1) + the same of the as-written rows (any stage) + the
+            // (0,2) entry of the dynamics curvature; Huu = R2 + W2 + diagonal barrier terms + the two dense blocks.  An absent term
+            // reads the constant 0 of the coefficient vector (CV[0]).
+            int i = tvar(g + 4 * r), jj = jl;
+            if (i < jj) { const int t_ = i; i = jj; jj = t_; }
+            auto pk = [](int off, int stride, int lastonly) -> unsigned { return (unsigned)off | ((unsigned)stride << 16) | ((unsigned)lastonly << 31); };
+            unsigned t[4];
+            for (int q = 0; q < 4; q++) t[q] = pk(L.CV, 0, 0);
+            if (i == 99) { }
+            else if (i == NV) { if (jj < NX) t[0] = pk(L.QX + jj, NX, 0); else if (jj < NV) t[0] = pk(L.QU + jj - NX, NU, 0); }
+            else if (i < NX) t[0] = pk(L.HXX + i * (i + 1) / 2 + jj, NXX, 0);
+            else {
+                const int a_ = i - NX;
+                if (jj < NX) {
+                    t[0] = pk(L.HUXL + a_ * NX + jj, 0, 1);
+                    if (NQ) t[1] = pk(L.HUXS + a_ * NX + jj, NU * NX, 0);
+                    if (a_ == 0 && jj == 2) t[2] = pk(L.HUX02, 1, 0);
+                } else {
+                    const int b_ = jj - NX, e2 = a_ * (a_ + 1) / 2 + b_;
+                    t[0] = pk(L.WTS + MMPC_W_RW2 + a_ * NU + b_, 0, 0);
+                    if (a_ == b_) t[1] = pk(L.HUUD + a_, NU, 0);
+                    t[2] = pk(L.HUUL + e2, 0, 1);
+                    if (NQ) t[3] = pk(L.HUUS + e2, NUU, 0);
+                }
+            }
+            for (int q = 0; q < 4; q++) ls.st_o[r][q] = t[q];
         }
         for (int l = 0; l < NLEG; l++) {
             // entry of the normalised pivot row(s) of leg l this lane holds: gain row (column < NX), feed-forward (column NX),
@@ -1217,19 +1254,18 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                 // pass adds to [A B]^T P [A B]): packed Hxx; Hux = (0,2) entry of the dynamics curvature + the dense blocks of a
                 // slack eliminated here (last stage: quirk Q1; as-written rows: any stage); Huu = R2 + W2 + diagonal barrier terms
                 // + the same dense blocks; gradient in row / column NX
-                auto stage_entry = [&](const int k, const int ti, const int tj) -> double {
-                    int i = tvar(ti), j = tvar(tj);
-                    if (i < j) { const int t_ = i; i = j; j = t_; }
-                    if (i == 99) return 0.0;
-                    if (i == NV) return j == NV ? 0.0 : (j < NX ? QX[k * NX + j] : QU[k * NU + j - NX]);
-                    if (i < NX) return HXX[k * NXX + i * (i + 1) / 2 + j];
-                    const int a_ = i - NX;
-                    if (j < NX) return (k == N - 1 ? HUXL[a_ * NX + j] : 0.0) + (NQ ? HUXS[(k * NU + a_) * NX + j] : 0.0) + ((a_ == 0 && j == 2) ? HUX02[k] : 0.0);
-                    const int b_ = j - NX, e2 = a_ * (a_ + 1) / 2 + b_;
-                    return WTS[MMPC_W_RW2 + a_ * NU + b_] + (a_ == b_ ? HUUD[k * NU + a_] : 0.0) + (k == N - 1 ? HUUL[e2] : 0.0) + (NQ ? HUUS[k * NUU + e2] : 0.0);
+                auto stage_entry = [&](const unsigned (&t)[4], const int k) -> double {
+                    double x[4];
+                    for (int q = 0; q < 4; q++) {
+                        const unsigned w = t[q];
+                        const double v = lds[(int)(w & 0xffffu) + k * (int)((w >> 16) & 0x7fffu)];
+                        x[q] = ((w >> 31) && k != N - 1) ? 0.0 : v;
+                    }
+                    return ((x[0] + x[1]) + x[2]) + x[3];
                 };
                 // R0: terminal cost-to-go [P_N p_N; p_N^T .] in accumulator layout (+ the augmentation of the terminal equality),
                 //     operands of stage N-1
+                MMPC_G2()
                 LANES_BEGIN
                 {
                     auto &ls = MMPC_LS;
@@ -1241,7 +1277,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                         if (i < NX) v = HXX[N * NXX + i * (i + 1) / 2 + jj] + ((teq && i == jj && i < 2) ? MMPC_RHO_EQ : 0.0);
                         else if (i == NV && jj < NX) v = QX[N * NX + jj] - ((teq && jj < 2) ? MMPC_RHO_EQ * (XREF[N * NX + jj] - X[N * NX + jj]) : 0.0);
                         ls.rP[r] = v;
-                        ls.rM[r] = stage_entry(N - 1, g + 4 * r, j);
+                        ls.rM[r] = stage_entry(ls.st_o[r], N - 1);
                     }
                     for (int r = 0; r < NKB; r++) { const unsigned o = ls.ab_o[r]; ls.rAB[r] = lds[(o & 0xffffu) + (N - 1) * (int)(o >> 16)]; }
                 }
@@ -1255,6 +1291,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                     }
                 LANES_END
                 int ric_bad = 0;
+                MMPC_GS2(0)
                 for (int k = N - 1; k >= 0; k--) {
                     // R1: T = [P p; p^T .] [A B c; 0 0 1];  R2: M = [A B c; 0 0 1]^T T + stage matrix
                     MMPC_MFMA0(rT, ls.rP[0], ls.rAB[0])
@@ -1263,16 +1300,18 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                     MMPC_MFMA(rM, ls.rAB[0], ls.rT[0])
                     MMPC_MFMA(rM, ls.rAB[1], ls.rT[1])
                     if (NKB > 2) MMPC_MFMA(rM, ls.rAB[NKB > 2 ? 2 : 0], ls.rT[NKB > 2 ? 2 : 0])
+                    MMPC_GS2(1)
                     // operands of the next stage travel while this one eliminates its inputs
                     LANES_BEGIN
                     {
                         auto &ls = MMPC_LS;
                         if (k > 0) {
                             for (int r = 0; r < NKB; r++) { const unsigned o = ls.ab_o[r]; ls.nab[r] = lds[(o & 0xffffu) + (k - 1) * (int)(o >> 16)]; }
-                            for (int r = 0; r < 4; r++) ls.nhm[r] = stage_entry(k - 1, (lane >> 4) + 4 * r, lane & 15);
+                            for (int r = 0; r < 4; r++) ls.nhm[r] = stage_entry(ls.st_o[r], k - 1);
                         }
                     }
                     LANES_END_REG
+                    MMPC_GS2(2)
                     // R3: the inputs are eliminated on the tile by rank-one MFMAs (mmpc_fast.h: pairs of inputs whose rows share an
                     // accumulator register go as two K-slots of one MFMA, in sequential L D L^T arithmetic); the normalised pivot
                     // rows go to KK / KF / KU, 1 / pivot to PIV (for the border columns)
@@ -1312,6 +1351,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                         LANES_END_REG
                         MMPC_MFMA(rM, ls.opa, ls.opb)
                     }
+                    MMPC_GS2(3)
                     LANES_BEGIN
                     {
                         auto &ls = MMPC_LS;
@@ -1323,6 +1363,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                         for (int r = 0; r < NKB; r++) ls.rAB[r] = ls.nab[r];
                     }
                     LANES_END
+                    MMPC_GS2(4)
                     if (ric_bad) { failed = 1; break; }
                 }
                 if (!failed) {
@@ -1379,6 +1420,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                         }
                     }
                 }
+                MMPC_GS2(5)
             }
 #else
             LANES_BEGIN

@@ -26,3 +26,8 @@ for name, fc in (("intended rows", False), ("rows as written", None)):
     for i, n in enumerate(names):
         print("  %-48s %5.1f %%  %9.0f cycles/iter/wave" % (n, 100 * v[i] / v.sum(), v[i] / its))
     print("  total %.0f cycles/iter/wave" % (v.sum() / its))
+    v2 = np.array(list(buf), float)[10:16]
+    if v2.sum() > 0:
+        for i, n in enumerate(["R0 terminal block", "R1 + R2 MFMA chains", "operands of the next stage (stage_entry)", "R3 elimination legs", "P store", "gains + border columns in the pass"]):
+            print("     inside the pass: %-42s %9.0f cycles/iter/wave" % (n, v2[i] / its))
+        print("     inside the pass: %-42s %9.0f cycles/iter/wave" % ("rest (border roll-out, small solve, retries)", (v[3] - v2.sum()) / its))
