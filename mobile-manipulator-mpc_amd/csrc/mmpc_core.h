@@ -514,6 +514,8 @@ struct MmpcGenRic {
     static_assert(D::NV + 1 <= 16, "stage matrix over (x, 1, u) must fit one 16x16 tile");
     unsigned ab_o[NKB];                  // [A B c; 0 0 1] operand rows 4r+g, column j: LDS offset | stage stride << 16
     int p_o[4], p_s[4];                  // where register r of [P_k | p_k] is stored (offset at stage 0, stage stride; a dump slot otherwise)
+    unsigned bdA, bdB;                   // border columns: the <= 4 (row, coefficient id) pairs (4 + 4 bits each) of the dynamics column this lane
+                                         // handles in the input part (lane = c NU + a) and in the state part (lane = c NX + i) of their recursion
     unsigned st_o[4][4];                 // stage-matrix entry of register r = sum of up to four LDS words: offset | stage stride << 16 | (only at the last stage) << 31
     int kl_b[NLEG], kl_s[NLEG];          // where the lane stores its entry of the normalised pivot row(s) of leg l
     MmpcAcc rP, rT, rM;                  // cost-to-go [P p; p^T .], its product with the dynamics, stage matrix
@@ -759,6 +761,15 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                 }
             }
             for (int q = 0; q < 4; q++) ls.st_o[r][q] = t[q];
+        }
+        {
+            const int colA = NX + (NU > 0 ? lane % (NU > 0 ? NU : 1) : 0), colB = lane % NX;
+            unsigned wa = 0, wb = 0;
+            for (int q = 0; q < 4; q++) {
+                if (lane < MMPC_NBC * NU) wa |= ((unsigned)TB::crow(colA, q) | ((unsigned)TB::ccv(colA, q) << 4)) << (8 * q);
+                if (lane < MMPC_NBC * NX) wb |= ((unsigned)TB::crow(colB, q) | ((unsigned)TB::ccv(colB, q) << 4)) << (8 * q);
+            }
+            ls.bdA = wa; ls.bdB = wb;
         }
         for (int l = 0; l < NLEG; l++) {
             // entry of the normalised pivot row(s) of leg l this lane holds: gain row (column < NX), feed-forward (column NX),
@@ -1383,41 +1394,56 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                     LANES_END
                     if (brd) {
                         // border columns through the same factorisation: with bp = B^T p_{k+1},  kf = -Hh^{-1} bp  (Hh = L D L^T: L from
-                        // the couplings KU, 1 / D in PIV)  and  p_k = A^T p_{k+1} + K^T bp + (what the column adds at this stage);
-                        // one lane per column, stage by stage
+                        // the couplings KU, 1 / D in PIV)  and  p_k = A^T p_{k+1} + K^T bp + (what the column adds at this stage)
+                        // (two short phases per stage - bp by one lane per (column, input), p_k by one lane per (column, state), both
+                        //  reading p_{k+1} from its stored copy - and the kf of all stages and columns in one phase afterwards: the
+                        //  same sums in the same order as one lane per column would form them, a third of the time)
+                        double *const BPS = GNU;   // (the scalar pass's array: NV x NBC >= NBC x NU doubles)
                         for (int k = N - 1; k >= 0; k--) {
+                            const double *cv = CV + k * MMPC_NCV;
+                            const double *pn = PNUS + (k + 1) * NX * MMPC_NBC;
                             LANES_BEGIN
-                            if (lane < MMPC_NBC) {
-                                const int c = lane;
-                                const double *cv = CV + k * MMPC_NCV;
-                                double pn[NX], bp[NU > 0 ? NU : 1], y[NU > 0 ? NU : 1];
-                                for (int i = 0; i < NX; i++) pn[i] = PNU[i * MMPC_NBC + c];
-                                for (int a = 0; a < NU; a++) {
-                                    double v = 0.0;
-                                    for (int q = 0; q < 4; q++) v += cv[TB::ccv(NX + a, q)] * pn[TB::crow(NX + a, q)];
-                                    bp[a] = v; y[a] = v;
-                                }
-                                // L y' = bp (unit lower: L[b][a] = KU[k][a, b], b > a), y'' = D^{-1} y', L^T z = y''
-                                for (int a = 0; a < NU; a++) for (int b2 = a + 1; b2 < NU; b2++) y[b2] -= KU[k * NPU + a * (2 * NU - a - 1) / 2 + (b2 - a - 1)] * y[a];
-                                for (int a = 0; a < NU; a++) y[a] *= PIV[k * NU + a];
-                                for (int a = NU - 1; a >= 0; a--) for (int b2 = a + 1; b2 < NU; b2++) y[a] -= KU[k * NPU + a * (2 * NU - a - 1) / 2 + (b2 - a - 1)] * y[b2];
-                                for (int a = 0; a < NU; a++) KFV[(k * NU + a) * MMPC_NBC + c] = -y[a];
-                                for (int i = 0; i < NX; i++) {
-                                    double v = 0.0;
-                                    for (int q = 0; q < 4; q++) v += cv[TB::ccv(i, q)] * pn[TB::crow(i, q)];
-                                    for (int a = 0; a < NU; a++) v += KK[(k * NU + a) * NX + i] * bp[a];
-                                    if (c == 2 && sig && yix(i) >= 0) {
-                                        if (k == N - 1) v -= VX[(N - 1) * 6 + yix(i)];
-                                        if (k == N - 2) v -= VQ[(N - 1) * 6 + yix(i)];
-                                    }
-                                    PNUS[(k * NX + i) * MMPC_NBC + c] = v;
-                                }
+                            if (lane < MMPC_NBC * NU) {
+                                const unsigned w = MMPC_LS.bdA;
+                                const int c = lane / (NU > 0 ? NU : 1);
+                                double v = 0.0;
+                                for (int q = 0; q < 4; q++) v += cv[(w >> (8 * q + 4)) & 15u] * pn[((w >> (8 * q)) & 15u) * MMPC_NBC + c];
+                                BPS[lane] = v;
                             }
                             LANES_END
                             LANES_BEGIN
-                            for (int e = lane; e < NX * MMPC_NBC; e += MMPC_WAVE) PNU[e] = PNUS[k * NX * MMPC_NBC + e];
+                            if (lane < MMPC_NBC * NX) {
+                                const unsigned w = MMPC_LS.bdB;
+                                const int c = lane / NX, i = lane - c * NX;
+                                double v = 0.0;
+                                for (int q = 0; q < 4; q++) v += cv[(w >> (8 * q + 4)) & 15u] * pn[((w >> (8 * q)) & 15u) * MMPC_NBC + c];
+                                for (int a = 0; a < NU; a++) v += KK[(k * NU + a) * NX + i] * BPS[c * NU + a];
+                                if (c == 2 && sig && yix(i) >= 0) {
+                                    if (k == N - 1) v -= VX[(N - 1) * 6 + yix(i)];
+                                    if (k == N - 2) v -= VQ[(N - 1) * 6 + yix(i)];
+                                }
+                                PNUS[(k * NX + i) * MMPC_NBC + c] = v;
+                            }
                             LANES_END
                         }
+                        LANES_BEGIN
+                        for (int item = lane; item < N * MMPC_NBC; item += MMPC_WAVE) {
+                            const int k = item / MMPC_NBC, c = item - k * MMPC_NBC;
+                            const double *cv = CV + k * MMPC_NCV;
+                            double pn[NX], y[NU > 0 ? NU : 1];
+                            for (int i = 0; i < NX; i++) pn[i] = PNUS[((k + 1) * NX + i) * MMPC_NBC + c];
+                            for (int a = 0; a < NU; a++) {
+                                double v = 0.0;
+                                for (int q = 0; q < 4; q++) v += cv[TB::ccv(NX + a, q)] * pn[TB::crow(NX + a, q)];
+                                y[a] = v;
+                            }
+                            // L y' = bp (unit lower: L[b][a] = KU[k][a, b], b > a), y'' = D^{-1} y', L^T z = y''
+                            for (int a = 0; a < NU; a++) for (int b2 = a + 1; b2 < NU; b2++) y[b2] -= KU[k * NPU + a * (2 * NU - a - 1) / 2 + (b2 - a - 1)] * y[a];
+                            for (int a = 0; a < NU; a++) y[a] *= PIV[k * NU + a];
+                            for (int a = NU - 1; a >= 0; a--) for (int b2 = a + 1; b2 < NU; b2++) y[a] -= KU[k * NPU + a * (2 * NU - a - 1) / 2 + (b2 - a - 1)] * y[b2];
+                            for (int a = 0; a < NU; a++) KFV[(k * NU + a) * MMPC_NBC + c] = -y[a];
+                        }
+                        LANES_END
                     }
                 }
                 MMPC_GS2(5)
