@@ -1082,6 +1082,14 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                     if (k < N) { hss += w; gss -= zh; for (int a = 0; a < 6; a++) vx[a] += w * g6[a]; }
                     else { hssN += w; gssN -= zh; for (int a = 0; a < 6; a++) vN[a] += w * g6[a]; }
                 }
+                // forward kinematics of the stage for the exact curvature of the half-space rows (both forms): once per stage (inside
+                // the row loops the compiler cannot hoist it - the stores to the Hessian block may alias the trajectory)
+                double snF = 0.0, csF = 1.0, drF[3] = {0, 0, 0}, dzF[3] = {0, 0, 0};
+                if (exact && NHS > 0) {
+                    const double *xk = X + k * NX;
+                    MMPC_SINCOS(xk[2], &snF, &csF);
+                    mmpc_arm_segments(xk[NX - 3], xk[NX - 2], xk[NX - 1], drF, dzF);
+                }
                 for (int i = 0; i < NHS; i++) {
                     const double t = T[k * R + SL_H + i], z = Z[k * R + SL_H + i], w = z / t;
                     const double zh = mu / t + w * (HR[k * NR + M + NSELF + i] + t);
@@ -1096,10 +1104,8 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                         // curvature z * d2(n.FK point) over (psi, q1, q2, q3): the row multipliers are large (S = 1e5), without
                         // it the step is a Gauss-Newton step and convergence is linear
                         const double *xk = X + k * NX;
-                        double sn, cs, dr[3], dz[3], gt[6], h10[10];
-                        MMPC_SINCOS(xk[2], &sn, &cs);
-                        mmpc_arm_segments(xk[NX - 3], xk[NX - 2], xk[NX - 1], dr, dz);
-                        mmpc_hs_row(P, i, xk[0], xk[1], cs, sn, dr, dz, gt, h10);
+                        double gt[6], h10[10];
+                        mmpc_hs_row(P, i, xk[0], xk[1], csF, snF, drF, dzF, gt, h10);
                         for (int a = 0; a < 4; a++) {
                             const int ia = kY[2 + a];
                             for (int b = 0; b <= a; b++) hxx[ia * (ia + 1) / 2 + kY[2 + b]] += z * h10[a * (a + 1) / 2 + b];
@@ -1116,7 +1122,8 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                         const double *xk = X + k * NX, *xp = X + (k - 1) * NX;
                         double sn, cs, dr[3], dz[3], snp, csp, drp[3], dzp[3];
                         if (exact) {
-                            MMPC_SINCOS(xk[2], &sn, &cs); mmpc_arm_segments(xk[NX - 3], xk[NX - 2], xk[NX - 1], dr, dz);
+                            sn = snF; cs = csF;
+                            for (int a = 0; a < 3; a++) { dr[a] = drF[a]; dz[a] = dzF[a]; }
                             MMPC_SINCOS(xp[2], &snp, &csp); mmpc_arm_segments(xp[NX - 3], xp[NX - 2], xp[NX - 1], drp, dzp);
                         }
                         for (int e = 0; e < NQ; e++) {
@@ -1862,12 +1869,13 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                     jd = -DS[k];
                     for (int a = 0; a < 6; a++) jd += GQ8[(k * NQ + e) * 6 + a] * dq[kY[a]];
                 }
-                const double t = T[k * R + r], z = Z[k * R + r];
-                const double dtv = -(h + t) - jd, dzv = mu / t - z - (z / t) * dtv;
+                // (reciprocals instead of IEEE divisions, as in the specialised kernel: the five quotients of a row were most of this phase)
+                const double t = T[k * R + r], z = Z[k * R + r], it_ = mmpc_rcp(t);
+                const double dtv = -(h + t) - jd, dzv = mu * it_ - z - (z * it_) * dtv;
                 if (r >= SL_C) DTR[k * NR + r - SL_C] = dtv;
-                if (dtv < 0) ap = mmpc_min(ap, -tau * t / dtv);
-                if (dzv < 0) ad = mmpc_min(ad, -tau * z / dzv);
-                dphi -= mu * dtv / t;
+                if (dtv < 0) ap = mmpc_min(ap, -tau * t * mmpc_rcp(dtv));
+                if (dzv < 0) ad = mmpc_min(ad, -tau * z * mmpc_rcp(dzv));
+                dphi -= mu * dtv * it_;
             }
         }
         for (int k = lane; k < NS; k += MMPC_WAVE) {
@@ -1947,8 +1955,8 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                     dtv = -(h + T[k * R + r]) - jd;
                 } else if (r >= SL_Q && k == 0) continue;
                 else dtv = DTR[k * NR + r - SL_C];
-                const double t = T[k * R + r], z = Z[k * R + r];
-                const double dzv = mu / t - z - (z / t) * dtv;
+                const double t = T[k * R + r], z = Z[k * R + r], it_ = mmpc_rcp(t);
+                const double dzv = mu * it_ - z - (z * it_) * dtv;      // (the same expression as in D2: ad was formed from it)
                 const double tn = t + alpha * dtv;
                 T[k * R + r] = tn;
                 Z[k * R + r] = mmpc_z_safeguard(z + ad * dzv, tn, mu);
