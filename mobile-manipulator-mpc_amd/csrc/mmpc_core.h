@@ -251,6 +251,29 @@ MMPC_DEV double mmpc_max(double a, double b) { return a > b ? a : b; }
 // the same for running error maxima: a NaN on EITHER side stays (mmpc_max hands only a NaN in b through), so that a
 // non-finite residual anywhere reaches the status 2 test of the main loop
 MMPC_DEV double mmpc_max_err(double a, double b) { return (a > b || a != a) ? a : b; }
+// Reductions of the generic kernel over the MMPC_WAVE per-lane partials a phase left in LDS: one LDS read per lane and a butterfly
+// through DPP / permlane swaps (mmpc_tile.h) instead of every lane walking through all 64 words (~10 k cycles per reduction site,
+// five to eight sites per iteration).  With the operations of this file (a NaN partial reaches the result of MAXERR).
+#ifdef MMPC_EMU
+#define MMPC_GRED_SUM(ARR) mmpc_emu_red_arr((ARR), 0)
+#define MMPC_GRED_MAX(ARR) mmpc_emu_red_arr((ARR), 1)
+#define MMPC_GRED_MIN(ARR) mmpc_emu_red_arr((ARR), 2)
+#define MMPC_GRED_MAXERR(ARR) mmpc_emu_red_arr((ARR), 3)
+#else
+#if MMPC_RED_DPP
+MMPC_DEV double mmpc_gop_add(double a, double b) { return a + b; }
+MMPC_WAVE_RED(mmpc_gwave_sum, mmpc_gop_add)
+MMPC_WAVE_RED(mmpc_gwave_max, mmpc_max)
+MMPC_WAVE_RED(mmpc_gwave_min, mmpc_min)
+MMPC_WAVE_RED(mmpc_gwave_maxerr, mmpc_max_err)
+#else
+#error "the generic kernel's reductions need MMPC_RED_DPP"
+#endif
+#define MMPC_GRED_SUM(ARR) mmpc_gwave_sum((ARR)[mmpc_lane_id()])
+#define MMPC_GRED_MAX(ARR) mmpc_gwave_max((ARR)[mmpc_lane_id()])
+#define MMPC_GRED_MIN(ARR) mmpc_gwave_min((ARR)[mmpc_lane_id()])
+#define MMPC_GRED_MAXERR(ARR) mmpc_gwave_maxerr((ARR)[mmpc_lane_id()])
+#endif
 MMPC_DEV double mmpc_z_safeguard(double z, double t, double mu) {
     const double p = z * t;
     if (p > MMPC_KAPPA_SIGMA * mu) return MMPC_KAPPA_SIGMA * mu / t;
@@ -977,14 +1000,12 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
         LANES_END
         double err_d = 0.0, err_p = 0.0, tzmax = 0.0, tzmin = 1e300, zsum = 0.0;
         double m_F0 = 0.0, m_TH0 = 0.0, m_LG0 = 0.0;
-        for (int i = 0; i < MMPC_WAVE; i++) { m_F0 += RED[6 * MMPC_WAVE + i]; m_TH0 += RED[7 * MMPC_WAVE + i]; m_LG0 += PF[i]; }
-        for (int i = 0; i < MMPC_WAVE; i++) {
-            err_d = mmpc_max_err(err_d, mmpc_max_err(RED[0 * MMPC_WAVE + i], RED[5 * MMPC_WAVE + i]));
-            err_p = mmpc_max_err(err_p, RED[1 * MMPC_WAVE + i]);
-            tzmax = mmpc_max(tzmax, RED[2 * MMPC_WAVE + i]);
-            tzmin = mmpc_min(tzmin, RED[3 * MMPC_WAVE + i]);
-            zsum += RED[4 * MMPC_WAVE + i];
-        }
+        m_F0 = MMPC_GRED_SUM(RED + 6 * MMPC_WAVE); m_TH0 = MMPC_GRED_SUM(RED + 7 * MMPC_WAVE); m_LG0 = MMPC_GRED_SUM(PF);
+        err_d = mmpc_max_err(MMPC_GRED_MAXERR(RED + 0 * MMPC_WAVE), MMPC_GRED_MAXERR(RED + 5 * MMPC_WAVE));
+        err_p = MMPC_GRED_MAXERR(RED + 1 * MMPC_WAVE);
+        tzmax = MMPC_GRED_MAX(RED + 2 * MMPC_WAVE);
+        tzmin = MMPC_GRED_MIN(RED + 3 * MMPC_WAVE);
+        zsum = MMPC_GRED_SUM(RED + 4 * MMPC_WAVE);
         double sd = zsum / (double)(nrows_act + NS * NX);
         sd = (sd > 100.0 ? sd : 100.0) / 100.0;
         E0 = mmpc_max_err(mmpc_max_err(err_d / sd, err_p), tzmax / sd);
@@ -1887,11 +1908,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
         RED[0 * MMPC_WAVE + lane] = ap; RED[1 * MMPC_WAVE + lane] = ad; RED[2 * MMPC_WAVE + lane] = dphi;
         LANES_END
         double ap = 1.0, ad = 1.0, dphi = 0.0;
-        for (int i = 0; i < MMPC_WAVE; i++) {
-            ap = mmpc_min(ap, RED[0 * MMPC_WAVE + i]);
-            ad = mmpc_min(ad, RED[1 * MMPC_WAVE + i]);
-            dphi += RED[2 * MMPC_WAVE + i];
-        }
+        ap = MMPC_GRED_MIN(RED + 0 * MMPC_WAVE); ad = MMPC_GRED_MIN(RED + 1 * MMPC_WAVE); dphi = MMPC_GRED_SUM(RED + 2 * MMPC_WAVE);
         MMPC_GS(6)
         // ---- merit at the current point: from the evaluation E1 (same point, same slacks), with the barrier parameter as it is now
         const double phi0 = m_F0 - mu * m_LG0, th0 = m_TH0;
@@ -1911,7 +1928,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                 RED[5 * MMPC_WAVE + lane] = ph; RED[6 * MMPC_WAVE + lane] = th;
                 LANES_END
                 double phi = 0.0, th = 0.0;
-                for (int i = 0; i < MMPC_WAVE; i++) { phi += RED[5 * MMPC_WAVE + i]; th += RED[6 * MMPC_WAVE + i]; }
+                phi = MMPC_GRED_SUM(RED + 5 * MMPC_WAVE); th = MMPC_GRED_SUM(RED + 6 * MMPC_WAVE);
                 bool okf = th < th_max;
                 for (int i = 0; i < nfilt && okf; i++) if (th >= FILT[2 * i] && phi >= FILT[2 * i + 1]) okf = false;
                 const bool ftype = dphi < 0 && th0 <= th_min && alpha * pow(-dphi, 2.3) > pow(th0, 1.1);
@@ -1993,7 +2010,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
     for (int i = lane; i < NS; i += MMPC_WAVE) io.s[i] = S[i];
     LANES_END
     double cost = 0.0;
-    for (int i = 0; i < MMPC_WAVE; i++) cost += RED[i];
+    cost = MMPC_GRED_SUM(RED);
     LANES_BEGIN
     if (lane == 0) { *io.status = status; *io.iters = it; *io.cost = cost; *io.err = E0; }
     LANES_END

@@ -244,33 +244,8 @@ struct MmpcLaneState {
                                                      // (set once per roll-out: the lane id is opaque to the compiler in every phase)
 };
 
-#ifndef MMPC_RED_DPP
-#define MMPC_RED_DPP 1   // wave reductions through DPP / permlane swaps (steps 1..32) instead of ds_bpermute butterflies (steps 32..1)
-#endif
 #ifndef MMPC_EMU
 #if MMPC_RED_DPP
-template <int CTRL>
-MMPC_DEV double mmpc_dpp_f64(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
-    return __hiloint2double(hi, lo);
-}
-MMPC_DEV double mmpc_xor32_f64(double v) {
-    const int lo = __double2loint(v), hi = __double2hiint(v);
-    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-    const bool up = (mmpc_lane_id() >> 5) & 1;
-    return __hiloint2double(up ? b[0] : b[1], up ? a[0] : a[1]);
-}
-#define MMPC_WAVE_RED(NAME, OP)                                                                              \
-MMPC_DEV double NAME(double v) {                                                                             \
-    v = OP(v, mmpc_dpp_f64<0xB1>(v));    /* quad_perm [1,0,3,2]: lane ^ 1 */                                  \
-    v = OP(v, mmpc_dpp_f64<0x4E>(v));    /* quad_perm [2,3,0,1]: lane ^ 2 */                                  \
-    v = OP(v, mmpc_dpp_f64<0x141>(v));   /* row_half_mirror: the other quad of the 8 */                       \
-    v = OP(v, mmpc_dpp_f64<0x140>(v));   /* row_mirror: the other half of the row */                          \
-    v = OP(v, mmpc_xor16_f64(v, mmpc_lane_id()));                                                             \
-    v = OP(v, mmpc_xor32_f64(v));                                                                             \
-    return v; }
 MMPC_DEV double mmpc_op_add(double a, double b) { return a + b; }
 MMPC_WAVE_RED(mmpc_wave_sum, mmpc_op_add)
 MMPC_WAVE_RED(mmpc_wave_max, mmpc_vmax)

@@ -111,3 +111,52 @@ MMPC_DEV double mmpc_xor16_f64(double v, int lane) {
 // lanes of a reduced group being bitwise equal) and through v_permlane16_swap / v_permlane32_swap across rows.  Every lane
 // ends with the same bits (the combine is commutative), which the host emulation reproduces (mmpc_emu_red).
 #endif
+#ifndef MMPC_RED_DPP
+#define MMPC_RED_DPP 1   // wave reductions through DPP / permlane swaps (steps 1..32) instead of ds_bpermute butterflies (steps 32..1)
+#endif
+#ifndef MMPC_EMU
+#if MMPC_RED_DPP
+template <int CTRL>
+MMPC_DEV double mmpc_dpp_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+MMPC_DEV double mmpc_xor32_f64(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    const bool up = (mmpc_lane_id() >> 5) & 1;
+    return __hiloint2double(up ? b[0] : b[1], up ? a[0] : a[1]);
+}
+#define MMPC_WAVE_RED(NAME, OP)                                                                              \
+MMPC_DEV double NAME(double v) {                                                                             \
+    v = OP(v, mmpc_dpp_f64<0xB1>(v));    /* quad_perm [1,0,3,2]: lane ^ 1 */                                  \
+    v = OP(v, mmpc_dpp_f64<0x4E>(v));    /* quad_perm [2,3,0,1]: lane ^ 2 */                                  \
+    v = OP(v, mmpc_dpp_f64<0x141>(v));   /* row_half_mirror: the other quad of the 8 */                       \
+    v = OP(v, mmpc_dpp_f64<0x140>(v));   /* row_mirror: the other half of the row */                          \
+    v = OP(v, mmpc_xor16_f64(v, mmpc_lane_id()));                                                             \
+    v = OP(v, mmpc_xor32_f64(v));                                                                             \
+    return v; }
+#endif
+#endif
+
+// the same butterfly over an array of MMPC_WAVE per-lane partials in LDS (the generic kernel's reductions): device - every lane
+// takes its own word and all end with the same bits; host - the same pairing order.  OP: 0 sum, 1 max, 2 min, 3 the running
+// maximum of error measures in which a NaN on either side stays (mmpc_max_err)
+#ifdef MMPC_EMU
+static inline double mmpc_emu_red_arr(const double *a, int op) {
+    double v[MMPC_WAVE], w[MMPC_WAVE];
+    for (int l = 0; l < MMPC_WAVE; l++) v[l] = a[l];
+    for (int q = 0; q < 6; q++) {
+        const int o = MMPC_RED_DPP ? (1 << q) : (32 >> q);
+        for (int l = 0; l < MMPC_WAVE; l++) {
+            const int p = !MMPC_RED_DPP ? (l ^ o) : (o == 4 ? ((l & ~7) | (7 - (l & 7))) : (o == 8 ? ((l & ~15) | (15 - (l & 15))) : (l ^ o)));
+            const double x = v[l], y = v[p];
+            w[l] = op == 0 ? x + y : (op == 1 ? (x > y ? x : y) : (op == 2 ? (x < y ? x : y) : ((x > y || x != x) ? x : y)));
+        }
+        for (int l = 0; l < MMPC_WAVE; l++) v[l] = w[l];
+    }
+    return v[0];
+}
+#endif
