@@ -62,13 +62,20 @@ __device__ unsigned long long mmpc_gstamp_acc[16];
 // (slots 10..15: pieces of the Riccati pass - the terminal block R0, the two MFMA chains, the hand-over of the next stage's operands, the
 //  elimination legs, the P store, gains + border columns; they are INSIDE slot 3's interval and subtract from it)
 #define MMPC_G2() unsigned long long h_prev_ = __builtin_readcyclecounter(), h_now_;
+#ifdef MMPC_STAMP_GEN_A   // (slots 10..15 = pieces of the assembly instead: cost + dynamics curvature, box rows, circle + self rows, half-space rows, rows as written, A2)
+#define MMPC_GS2(i)
+#define MMPC_GSA(i) { h_now_ = __builtin_readcyclecounter(); g_acc2_[i] += h_now_ - h_prev_; h_prev_ = h_now_; }
+#else
 #define MMPC_GS2(i) { h_now_ = __builtin_readcyclecounter(); g_acc2_[i] += h_now_ - h_prev_; h_prev_ = h_now_; }
+#define MMPC_GSA(i)
+#endif
 #define MMPC_GEND() { if (threadIdx.x == 0) { for (int i_ = 0; i_ < 10; i_++) atomicAdd(&mmpc_gstamp_acc[i_], g_acc_[i_]); for (int i_ = 0; i_ < 6; i_++) atomicAdd(&mmpc_gstamp_acc[10 + i_], g_acc2_[i_]); } }
 #else
 #define MMPC_G0()
 #define MMPC_GS(i)
 #define MMPC_G2()
 #define MMPC_GS2(i)
+#define MMPC_GSA(i)
 #define MMPC_GEND()
 #endif
 
@@ -1042,6 +1049,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
             const bool exact = attempt <= 1, dyn_curv = attempt == 0;
             const double reg = prox;
             // ---- A1: stage Hessian / gradient assembly
+            MMPC_G2()
             LANES_BEGIN
             for (int k = lane; k < NS; k += MMPC_WAVE) {
                 double *hxx = HXX + k * NXX, *qx = QX + k * NX;
@@ -1063,48 +1071,72 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                     HUX02[k] = h02;
                 }
                 double hss = 2 * Sw, gss = 2 * Sw * S[k], vx[6] = {0, 0, 0, 0, 0, 0};
-                for (int r = 0; r < SL_C; r++) {
+                MMPC_GSA(0)
+                // The rows of the stage add to REGISTERS - the diagonal terms of the box rows, the 2 x 2 block of the circle rows, the
+                // 6 x 6 block over y = (x, y, psi, q1, q2, q3) of the arm's rows with its gradient - and these to the stage's block in LDS
+                // once, after each group of rows: every "+=" on the LDS block was a load -> add -> store round trip the compiler could not overlap
+                // with the next (the row gradients it reads may alias the block): 570 cycles per box row, 4 k per half-space row.
+                double dgx[NX], dqx[NX], dgu[NU > 0 ? NU : 1], dqu[NU > 0 ? NU : 1];
+                for (int j = 0; j < NX; j++) { dgx[j] = 0.0; dqx[j] = 0.0; }
+                for (int a = 0; a < NU; a++) { dgu[a] = 0.0; dqu[a] = 0.0; }
+                if (k < N)
+                    for (int a = 0; a < NU; a++) {
+                        double b;
+                        if (box_bound(k, a, b)) {
+                            const double t = T[k * R + a], z = Z[k * R + a], w = z / t, h = b - U[k * NU + a];
+                            dgu[a] += w; dqu[a] -= mu / t + w * (h + t);
+                        }
+                        if (box_bound(k, NU + a, b)) {
+                            const double t = T[k * R + NU + a], z = Z[k * R + NU + a], w = z / t, h = U[k * NU + a] - b;
+                            dgu[a] += w; dqu[a] += mu / t + w * (h + t);
+                        }
+                    }
+                for (int j = 0; j < NX; j++) {
                     double b;
-                    if (!box_bound(k, r, b)) continue;
-                    const double t = T[k * R + r], z = Z[k * R + r], w = z / t;
-                    double h;
-                    if (r < NU) h = b - U[k * NU + r];
-                    else if (r < SL_XLO) h = U[k * NU + r - NU] - b;
-                    else if (r < SL_XHI) h = b - X[k * NX + r - SL_XLO];
-                    else h = X[k * NX + r - SL_XHI] - b;
-                    const double zh = mu / t + w * (h + t);
-                    if (r < NU) { HUUD[k * NU + r] += w; QU[k * NU + r] -= zh; }
-                    else if (r < SL_XLO) { HUUD[k * NU + r - NU] += w; QU[k * NU + r - NU] += zh; }
-                    else if (r < SL_XHI) { const int j = r - SL_XLO; hxx[j * (j + 1) / 2 + j] += w; qx[j] -= zh; }
-                    else { const int j = r - SL_XHI; hxx[j * (j + 1) / 2 + j] += w; qx[j] += zh; }
+                    if (box_bound(k, SL_XLO + j, b)) {
+                        const double t = T[k * R + SL_XLO + j], z = Z[k * R + SL_XLO + j], w = z / t, h = b - X[k * NX + j];
+                        dgx[j] += w; dqx[j] -= mu / t + w * (h + t);
+                    }
+                    if (box_bound(k, SL_XHI + j, b)) {
+                        const double t = T[k * R + SL_XHI + j], z = Z[k * R + SL_XHI + j], w = z / t, h = X[k * NX + j] - b;
+                        dgx[j] += w; dqx[j] += mu / t + w * (h + t);
+                    }
                 }
+                if (k < N) for (int a = 0; a < NU; a++) { HUUD[k * NU + a] += dgu[a]; QU[k * NU + a] += dqu[a]; }
+                for (int j = 0; j < NX; j++) { hxx[j * (j + 1) / 2 + j] += dgx[j]; qx[j] += dqx[j]; }
+                MMPC_GSA(1)
+                double c00 = 0.0, c01 = 0.0, c11 = 0.0, cq0 = 0.0, cq1 = 0.0;
                 for (int m = 0; m < M; m++) {
                     const double t = T[k * R + SL_C + m], z = Z[k * R + SL_C + m], w = z / t;
                     const double zh = mu / t + w * (HR[k * NR + m] + t);
                     const double g0 = GC[(k * M + m) * 2], g1 = GC[(k * M + m) * 2 + 1];
-                    hxx[0] += w * g0 * g0; hxx[1] += w * g1 * g0; hxx[2] += w * g1 * g1;
+                    c00 += w * g0 * g0; c01 += w * g1 * g0; c11 += w * g1 * g1;
                     if (exact) {
-                        hxx[0] += z * HC[(k * M + m) * 3]; hxx[1] += z * HC[(k * M + m) * 3 + 1];
-                        hxx[2] += z * HC[(k * M + m) * 3 + 2];
+                        c00 += z * HC[(k * M + m) * 3]; c01 += z * HC[(k * M + m) * 3 + 1];
+                        c11 += z * HC[(k * M + m) * 3 + 2];
                     }
-                    qx[0] += g0 * zh; qx[1] += g1 * zh;
+                    cq0 += g0 * zh; cq1 += g1 * zh;
                     hss += w; gss -= zh; vx[0] += w * g0; vx[1] += w * g1;
                 }
+                hxx[0] += c00; hxx[1] += c01; hxx[2] += c11; qx[0] += cq0; qx[1] += cq1;
+                double yb[21], qy[6];     // y-block of the arm's rows (packed lower) and their gradient
+                for (int e2 = 0; e2 < 21; e2++) yb[e2] = 0.0;
+                for (int a = 0; a < 6; a++) qy[a] = 0.0;
                 double hssN = 0.0, gssN = 0.0, vN[6] = {0, 0, 0, 0, 0, 0};
                 for (int i = 0; i < NSELF; i++) {
                     const double t = T[k * R + SL_S + i], z = Z[k * R + SL_S + i], w = z / t;
                     const double zh = mu / t + w * (HR[k * NR + M + i] + t);
-                    const double *g6 = GSF + (k * NSELF + i) * 6;
+                    double g6[6];
+                    for (int a = 0; a < 6; a++) g6[a] = GSF[(k * NSELF + i) * 6 + a];
                     for (int a = 0; a < 6; a++) {
-                        const int ia = kY[a];
-                        for (int b = 0; b <= a; b++) hxx[ia * (ia + 1) / 2 + kY[b]] += w * g6[a] * g6[b];
-                        qx[ia] += g6[a] * zh;
+                        for (int b = 0; b <= a; b++) yb[a * (a + 1) / 2 + b] += w * g6[a] * g6[b];
+                        qy[a] += g6[a] * zh;
                     }
                     if (k < N) { hss += w; gss -= zh; for (int a = 0; a < 6; a++) vx[a] += w * g6[a]; }
                     else { hssN += w; gssN -= zh; for (int a = 0; a < 6; a++) vN[a] += w * g6[a]; }
                 }
-                // forward kinematics of the stage for the exact curvature of the half-space rows (both forms): once per stage (inside
-                // the row loops the compiler cannot hoist it - the stores to the Hessian block may alias the trajectory)
+                MMPC_GSA(2)
+                // forward kinematics of the stage for the exact curvature of the half-space rows (both forms): once per stage
                 double snF = 0.0, csF = 1.0, drF[3] = {0, 0, 0}, dzF[3] = {0, 0, 0};
                 if (exact && NHS > 0) {
                     const double *xk = X + k * NX;
@@ -1114,11 +1146,11 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                 for (int i = 0; i < NHS; i++) {
                     const double t = T[k * R + SL_H + i], z = Z[k * R + SL_H + i], w = z / t;
                     const double zh = mu / t + w * (HR[k * NR + M + NSELF + i] + t);
-                    const double *g6 = GHS + (k * 6 + i) * 6;
+                    double g6[6];
+                    for (int a = 0; a < 6; a++) g6[a] = GHS[(k * 6 + i) * 6 + a];
                     for (int a = 0; a < 6; a++) {
-                        const int ia = kY[a];
-                        for (int b = 0; b <= a; b++) hxx[ia * (ia + 1) / 2 + kY[b]] += w * g6[a] * g6[b];
-                        qx[ia] += g6[a] * zh;
+                        for (int b = 0; b <= a; b++) yb[a * (a + 1) / 2 + b] += w * g6[a] * g6[b];
+                        qy[a] += g6[a] * zh;
                         vx[a] += w * g6[a];
                     }
                     if (exact) {
@@ -1127,13 +1159,18 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                         const double *xk = X + k * NX;
                         double gt[6], h10[10];
                         mmpc_hs_row(P, i, xk[0], xk[1], csF, snF, drF, dzF, gt, h10);
-                        for (int a = 0; a < 4; a++) {
-                            const int ia = kY[2 + a];
-                            for (int b = 0; b <= a; b++) hxx[ia * (ia + 1) / 2 + kY[2 + b]] += z * h10[a * (a + 1) / 2 + b];
-                        }
+                        for (int a = 0; a < 4; a++)
+                            for (int b = 0; b <= a; b++) yb[(2 + a) * (3 + a) / 2 + 2 + b] += z * h10[a * (a + 1) / 2 + b];
                     }
                     hss += w; gss -= zh;
                 }
+                if (NSELF)
+                    for (int a = 0; a < 6; a++) {
+                        const int ia = kY[a];
+                        for (int b = 0; b <= a; b++) hxx[ia * (ia + 1) / 2 + kY[b]] += yb[a * (a + 1) / 2 + b];
+                        qx[ia] += qy[a];
+                    }
+                MMPC_GSA(3)
                 if (NQ) {
                     // rows of the NLP as written: a row whose previous-stage entry attains the max acts on x_{k-1}; its blocks are
                     // handed to stage k-1 (HQX, QQX: added in A2), its tie between s_k and x_{k-1} is VQ
@@ -1150,7 +1187,8 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                         for (int e = 0; e < NQ; e++) {
                             const double t = T[k * R + SL_Q + e], z = Z[k * R + SL_Q + e], w = z / t;
                             const double zh = mu / t + w * (HR[k * NR + M + NSELF + NHS + e] + t);
-                            const double *g6 = GQ8 + (k * NQ + e) * 6;
+                            double g6[6];
+                            for (int a = 0; a < 6; a++) g6[a] = GQ8[(k * NQ + e) * 6 + a];
                             const bool br = BQ8[k * NQ + e] != 0.0;
                             double h10[10];
                             if (exact) { double gt[6]; int b2; q8_row(e, xk, cs, sn, dr, dz, xp, csp, snp, drp, dzp, b2, gt, h10); }
@@ -1179,6 +1217,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                 if (NQ && k == N - 1) { MISC[4] = hss; MISC[5] = gss; }   // (copies for the lane of stage N-2, see A2)
                 for (int a = 0; a < 6; a++) VX[k * 6 + a] = vx[a];
                 if (k == N) { MISC[2] = hssN; MISC[3] = gssN; for (int a = 0; a < 6; a++) VXN[a] = vN[a]; }
+                MMPC_GSA(4)
             }
             LANES_END
             // ---- A2: Schur complement of s_k (H_xs = -v); stage N-1 also carries the terminal
@@ -1281,6 +1320,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
             // unpack P_N (stage-N Hessian after its Schur step is written by another lane in this
             // phase, so the unpack happens in R0 below)
             LANES_END
+            MMPC_GSA(5)
             MMPC_GS(2)
             // ---- R0: full copy of P_N
             const bool sig = NQ && SIGW[0] != 0.0;       // (uniform; written by A2)
