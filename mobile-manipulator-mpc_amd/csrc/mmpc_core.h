@@ -1175,7 +1175,8 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                     // rows of the NLP as written: a row whose previous-stage entry attains the max acts on x_{k-1}; its blocks are
                     // handed to stage k-1 (HQX, QQX: added in A2), its tie between s_k and x_{k-1} is VQ
                     double hq[21], qq[6] = {0, 0, 0, 0, 0, 0}, vq[6] = {0, 0, 0, 0, 0, 0};
-                    for (int e2 = 0; e2 < 21; e2++) hq[e2] = 0.0;
+                    for (int e2 = 0; e2 < 21; e2++) { hq[e2] = 0.0; yb[e2] = 0.0; }     // (yb, qy: the rows of this set that act on x_k)
+                    for (int a = 0; a < 6; a++) qy[a] = 0.0;
                     if (k >= 1) {
                         const double *xk = X + k * NX, *xp = X + (k - 1) * NX;
                         double sn, cs, dr[3], dz[3], snp, csp, drp[3], dzp[3];
@@ -1200,14 +1201,18 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                                 if (exact) for (int a = 0; a < 4; a++) for (int b = 0; b <= a; b++) hq[(2 + a) * (3 + a) / 2 + 2 + b] += z * h10[a * (a + 1) / 2 + b];
                             } else {
                                 for (int a = 0; a < 6; a++) {
-                                    const int ia = kY[a];
-                                    for (int b = 0; b <= a; b++) hxx[ia * (ia + 1) / 2 + kY[b]] += w * g6[a] * g6[b];
-                                    qx[ia] += g6[a] * zh; vx[a] += w * g6[a];
+                                    for (int b = 0; b <= a; b++) yb[a * (a + 1) / 2 + b] += w * g6[a] * g6[b];
+                                    qy[a] += g6[a] * zh; vx[a] += w * g6[a];
                                 }
-                                if (exact) for (int a = 0; a < 4; a++) { const int ia = kY[2 + a]; for (int b = 0; b <= a; b++) hxx[ia * (ia + 1) / 2 + kY[2 + b]] += z * h10[a * (a + 1) / 2 + b]; }
+                                if (exact) for (int a = 0; a < 4; a++) for (int b = 0; b <= a; b++) yb[(2 + a) * (3 + a) / 2 + 2 + b] += z * h10[a * (a + 1) / 2 + b];
                             }
                             hss += w; gss -= zh;
                         }
+                    }
+                    for (int a = 0; a < 6; a++) {
+                        const int ia = kY[a];
+                        for (int b = 0; b <= a; b++) hxx[ia * (ia + 1) / 2 + kY[b]] += yb[a * (a + 1) / 2 + b];
+                        qx[ia] += qy[a];
                     }
                     for (int e2 = 0; e2 < 21; e2++) HQX[k * 21 + e2] = hq[e2];
                     for (int a = 0; a < 6; a++) { QQX[k * 6 + a] = qq[a]; VQ[k * 6 + a] = vq[a]; }
