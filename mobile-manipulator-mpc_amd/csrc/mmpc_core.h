@@ -544,6 +544,8 @@ struct MmpcGenRic {
     static_assert(D::NV + 1 <= 16, "stage matrix over (x, 1, u) must fit one 16x16 tile");
     unsigned ab_o[NKB];                  // [A B c; 0 0 1] operand rows 4r+g, column j: LDS offset | stage stride << 16
     int p_o[4], p_s[4];                  // where register r of [P_k | p_k] is stored (offset at stage 0, stage stride; a dump slot otherwise)
+    unsigned fw_st, fw_in;               // forward roll-out, row `lane` of [A B]: up to four state terms (column 4 bits | coefficient id 4 bits each);
+                                         // input of the row + 1 | coefficient id << 8 | (this lane stores the input step) << 16
     unsigned bdA, bdB;                   // border columns: the <= 4 (row, coefficient id) pairs (4 + 4 bits each) of the dynamics column this lane
                                          // handles in the input part (lane = c NU + a) and in the state part (lane = c NX + i) of their recursion
     unsigned st_o[4][4];                 // stage-matrix entry of register r = sum of up to four LDS words: offset | stage stride << 16 | (only at the last stage) << 31
@@ -800,6 +802,22 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                 if (lane < MMPC_NBC * NX) wb |= ((unsigned)TB::crow(colB, q) | ((unsigned)TB::ccv(colB, q) << 4)) << (8 * q);
             }
             ls.bdA = wa; ls.bdB = wb;
+        }
+        {
+            unsigned st = 0, fi = 0;
+            if (lane < NX) {
+                int ns = 0, na = -1, ida = 0;
+                for (int q = 0; q < 5; q++) {
+                    const int c = TB::rcol(lane, q), id = TB::rcv(lane, q);
+                    if (id == 0) continue;
+                    if (c < NX) { st |= ((unsigned)c | ((unsigned)id << 4)) << (8 * ns); ns++; }
+                    else { na = c - NX; ida = id; }
+                }
+                bool writer = na >= 0;
+                for (int l2 = 0; l2 < lane; l2++) for (int q = 0; q < 5; q++) if (TB::rcv(l2, q) != 0 && TB::rcol(l2, q) == NX + na) writer = false;
+                fi = (unsigned)(na + 1) | ((unsigned)ida << 8) | ((writer ? 1u : 0u) << 16);
+            }
+            ls.fw_st = st; ls.fw_in = fi;
         }
         for (int l = 0; l < NLEG; l++) {
             // entry of the normalised pivot row(s) of leg l this lane holds: gain row (column < NX), feed-forward (column NX),
@@ -1771,6 +1789,29 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
         LANES_BEGIN
         for (int j = lane; j < NX; j += MMPC_WAVE) DX[j] = 0.0;
         LANES_END
+#if MMPC_GEN_TILE
+        // (one phase per stage: the lane of row i forms the input step its row needs itself - nine products - instead of waiting for
+        //  another lane's through LDS, and takes its row of [A B] from two packed words set once: the table look-ups by lane index
+        //  were vector loads from constant memory in every stage)
+        for (int k = 0; k < N; k++) {
+            LANES_BEGIN
+            if (lane < NX) {
+                const unsigned st = MMPC_LS.fw_st, fi = MMPC_LS.fw_in;
+                const int a = (int)(fi & 255u) - 1;
+                const double *cv = CV + k * MMPC_NCV, *dx = DX + k * NX;
+                double v = CD[k * NX + lane];
+                for (int q = 0; q < 4; q++) v += cv[(st >> (8 * q + 4)) & 15u] * dx[(st >> (8 * q)) & 15u];
+                if (a >= 0) {
+                    double du = KF[k * NU + a];
+                    for (int j = 0; j < NX; j++) du += KK[(k * NU + a) * NX + j] * dx[j];
+                    v += cv[(fi >> 8) & 255u] * du;
+                    if ((fi >> 16) & 1u) DU[k * NU + a] = du;
+                }
+                DX[(k + 1) * NX + lane] = v;
+            }
+            LANES_END
+        }
+#else
         for (int k = 0; k < N; k++) {
             LANES_BEGIN
             if (lane < NU) {
@@ -1791,6 +1832,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
             }
             LANES_END
         }
+#endif
         MMPC_GS(4)
         // ---- D1: multiplier step and slack-variable step
         LANES_BEGIN
