@@ -546,6 +546,7 @@ struct MmpcGenRic {
     int p_o[4], p_s[4];                  // where register r of [P_k | p_k] is stored (offset at stage 0, stage stride; a dump slot otherwise)
     unsigned fw_st, fw_in;               // forward roll-out, row `lane` of [A B]: up to four state terms (column 4 bits | coefficient id 4 bits each);
                                          // input of the row + 1 | coefficient id << 8 | (this lane stores the input step) << 16
+    unsigned fwb_st, fwb_in;             // the same for row `lane % NX` (roll-out of the border columns: lane = c NX + i)
     unsigned bdA, bdB;                   // border columns: the <= 4 (row, coefficient id) pairs (4 + 4 bits each) of the dynamics column this lane
                                          // handles in the input part (lane = c NU + a) and in the state part (lane = c NX + i) of their recursion
     unsigned st_o[4][4];                 // stage-matrix entry of register r = sum of up to four LDS words: offset | stage stride << 16 | (only at the last stage) << 31
@@ -818,6 +819,19 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                 fi = (unsigned)(na + 1) | ((unsigned)ida << 8) | ((writer ? 1u : 0u) << 16);
             }
             ls.fw_st = st; ls.fw_in = fi;
+            unsigned stb = 0, fib = 0;
+            {
+                const int ib = lane % NX;
+                int ns = 0, na = -1, ida = 0;
+                for (int q = 0; q < 5; q++) {
+                    const int c = TB::rcol(ib, q), id = TB::rcv(ib, q);
+                    if (id == 0) continue;
+                    if (c < NX) { stb |= ((unsigned)c | ((unsigned)id << 4)) << (8 * ns); ns++; }
+                    else { na = c - NX; ida = id; }
+                }
+                fib = (unsigned)(na + 1) | ((unsigned)ida << 8);
+            }
+            ls.fwb_st = stb; ls.fwb_in = fib;
         }
         for (int l = 0; l < NLEG; l++) {
             // entry of the normalised pivot row(s) of leg l this lane holds: gain row (column < NX), feed-forward (column NX),
@@ -1702,6 +1716,18 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                         const double *cv = CV + k * MMPC_NCV;
                         const double *d = src + c * NX;
                         double v = c == 0 ? CD[k * NX + i] : 0.0;
+#if MMPC_GEN_TILE
+                        {   // (row i of [A B] from the two packed words of the lane: state terms, then the input term - the tables' order)
+                            const unsigned st = MMPC_LS.fwb_st, fi = MMPC_LS.fwb_in;
+                            const int a = (int)(fi & 255u) - 1;
+                            for (int q = 0; q < 4; q++) v += cv[(st >> (8 * q + 4)) & 15u] * d[(st >> (8 * q)) & 15u];
+                            if (a >= 0) {
+                                double x = c == 0 ? KF[k * NU + a] : KFV[(k * NU + a) * MMPC_NBC + c - 1];
+                                for (int j = 0; j < NX; j++) x += KK[(k * NU + a) * NX + j] * d[j];
+                                v += cv[(fi >> 8) & 255u] * x;
+                            }
+                        }
+#else
                         for (int q = 0; q < 5; q++) {
                             const int col = TB::rcol(i, q);
                             double x;
@@ -1713,6 +1739,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                             }
                             v += cv[TB::rcv(i, q)] * x;
                         }
+#endif
                         dst[c * NX + i] = v;
                     }
                     LANES_END
