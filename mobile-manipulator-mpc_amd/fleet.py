@@ -98,7 +98,7 @@ class DeviceFleet:
             yield t
 
     # ---- groups in lock step, out of phase
-    def run_groups(self, T, groups=2):
+    def run_groups(self, T, groups=2, priority=True):
         """The fleet as `groups` contiguous groups of robots, each in lock step on its own HIP stream and handle, the streams at
         descending priority: the workgroup dispatcher serves the first group's launch first and fills the slots its tail leaves
         empty - a tick lasts as long as its slowest robot, 200-450 iterations against a mean of 34 - with the other group's
@@ -106,7 +106,8 @@ class DeviceFleet:
         robot's numbers are those of run_lockstep (tests/test_gpu_parity.py).  Same reference protocol per robot."""
         torch = self.torch
         G = int(groups)
-        if not hasattr(self, "_groups") or len(self._groups) != G:
+        if not hasattr(self, "_groups") or len(self._groups) != G or getattr(self, "_groups_pr", True) != bool(priority):
+            self._groups_pr = bool(priority)
             from . import sharding
             import sys
             mm = sys.modules[__package__]
@@ -117,7 +118,7 @@ class DeviceFleet:
                 sub = DeviceFleet(mm, self.x0[lo:hi], self.glob[lo:hi], self.obs0[lo:hi], self.vel[lo:hi], N=self.N, device=self.dev.index, dt=self.dt,
                                   handles=1)
                 # (priority: lower number = served first; the last group runs at the default priority)
-                pr = max(hi_pr, min(lo_pr, 0 - (G - 1 - g))) if hi_pr < 0 else 0
+                pr = (max(hi_pr, min(lo_pr, 0 - (G - 1 - g))) if hi_pr < 0 else 0) if priority else 0
                 self._groups.append((lo, hi, sub, torch.cuda.Stream(device=self.dev, priority=pr)))
         main = torch.cuda.current_stream(self.dev)
         ev0 = torch.cuda.Event(); ev0.record(main)
