@@ -62,10 +62,16 @@ __device__ unsigned long long mmpc_gstamp_acc[16];
 // (slots 10..15: pieces of the Riccati pass - the terminal block R0, the two MFMA chains, the hand-over of the next stage's operands, the
 //  elimination legs, the P store, gains + border columns; they are INSIDE slot 3's interval and subtract from it)
 #define MMPC_G2() unsigned long long h_prev_ = __builtin_readcyclecounter(), h_now_;
-#ifdef MMPC_STAMP_GEN_A   // (slots 10..15 = pieces of the assembly instead: cost + dynamics curvature, box rows, circle + self rows, half-space rows, rows as written, A2)
+#if defined(MMPC_STAMP_GEN_E)   // (slots 10..15 = pieces of the evaluation E1: cost + dynamics, box rows, circle rows, self rows, half-space rows, rows as written + tail)
 #define MMPC_GS2(i)
+#define MMPC_GSA(i)
+#define MMPC_GSE(i) { h_now_ = __builtin_readcyclecounter(); g_acc2_[i] += h_now_ - h_prev_; h_prev_ = h_now_; }
+#elif defined(MMPC_STAMP_GEN_A)   // (slots 10..15 = pieces of the assembly instead: cost + dynamics curvature, box rows, circle + self rows, half-space rows, rows as written, A2)
+#define MMPC_GS2(i)
+#define MMPC_GSE(i)
 #define MMPC_GSA(i) { h_now_ = __builtin_readcyclecounter(); g_acc2_[i] += h_now_ - h_prev_; h_prev_ = h_now_; }
 #else
+#define MMPC_GSE(i)
 #define MMPC_GS2(i) { h_now_ = __builtin_readcyclecounter(); g_acc2_[i] += h_now_ - h_prev_; h_prev_ = h_now_; }
 #define MMPC_GSA(i)
 #endif
@@ -76,6 +82,7 @@ __device__ unsigned long long mmpc_gstamp_acc[16];
 #define MMPC_G2()
 #define MMPC_GS2(i)
 #define MMPC_GSA(i)
+#define MMPC_GSE(i)
 #define MMPC_GEND()
 #endif
 
@@ -864,6 +871,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
     for (it = 0; it <= P.max_iter; it++) {
         MMPC_GS(0)
         // ============================================================ E1: evaluation + KKT partials
+        MMPC_G2()
         LANES_BEGIN
         double e_d = 0.0, e_p = 0.0, tzmax = 0.0, tzmin = 1e300, zsum = 0.0;
         // the merit function at this point (what the line search compares its trials with) falls out of the same evaluation:
@@ -922,19 +930,21 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                     if (j < NX) rdx[j] -= v; else rdu[j - NX] -= v;
                 }
             }
-            // box rows
-            for (int r = 0; r < SL_C; r++) {
-                double b;
-                if (!box_bound(k, r, b)) continue;
-                const double t = T[k * R + r], z = Z[k * R + r];
-                double h;
-                if (r < NU) { h = b - U[k * NU + r]; rdu[r] -= z; }
-                else if (r < SL_XLO) { h = U[k * NU + r - NU] - b; rdu[r - NU] += z; }
-                else if (r < SL_XHI) { h = b - xk[r - SL_XLO]; rdx[r - SL_XLO] -= z; }
-                else { h = xk[r - SL_XHI] - b; rdx[r - SL_XHI] += z; }
+            MMPC_GSE(0)
+            // box rows, in the order of the slots (input lower / upper, state lower / upper); loops with compile-time bounds: the
+            // residual entries a row adds to are then registers (indexed by a run-time row number they were a select chain per row)
+            auto box_row = [&](int r, double h, double z) {
+                const double t = T[k * R + r];
                 e_p = mmpc_max_err(e_p, fabs(h + t)); m_th += fabs(h + t); acc(t);
                 tzmax = mmpc_max(tzmax, t * z); tzmin = mmpc_min(tzmin, t * z); zsum += z;
+            };
+            if (k < N) {
+                for (int a = 0; a < NU; a++) { double b; if (box_bound(k, a, b)) { const double z = Z[k * R + a]; rdu[a] -= z; box_row(a, b - U[k * NU + a], z); } }
+                for (int a = 0; a < NU; a++) { double b; if (box_bound(k, NU + a, b)) { const double z = Z[k * R + NU + a]; rdu[a] += z; box_row(NU + a, U[k * NU + a] - b, z); } }
             }
+            for (int j = 0; j < NX; j++) { double b; if (box_bound(k, SL_XLO + j, b)) { const double z = Z[k * R + SL_XLO + j]; rdx[j] -= z; box_row(SL_XLO + j, b - xk[j], z); } }
+            for (int j = 0; j < NX; j++) { double b; if (box_bound(k, SL_XHI + j, b)) { const double z = Z[k * R + SL_XHI + j]; rdx[j] += z; box_row(SL_XHI + j, xk[j] - b, z); } }
+            MMPC_GSE(1)
             // circle rows: value, gradient, Hessian (mpc_wholebody_qref.py:49-54)
             double rds = 2 * Sw * S[k], selfz = 0.0;
             for (int m = 0; m < M; m++) {
@@ -951,6 +961,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                 e_p = mmpc_max_err(e_p, fabs(h + t)); m_th += fabs(h + t); acc(t);
                 tzmax = mmpc_max(tzmax, t * z); tzmin = mmpc_min(tzmin, t * z); zsum += z;
             }
+            MMPC_GSE(2)
             if (NSELF) {
                 double dr[3], dz[3];
                 mmpc_arm_segments(xk[NX - 3], xk[NX - 2], xk[NX - 1], dr, dz);
@@ -965,6 +976,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                     e_p = mmpc_max_err(e_p, fabs(h + t)); m_th += fabs(h + t); acc(t);
                     tzmax = mmpc_max(tzmax, t * z); tzmin = mmpc_min(tzmin, t * z); zsum += z;
                 }
+                MMPC_GSE(3)
                 for (int i = 0; i < NHS; i++) {   // half-space rows, bound to s_k (s_N at the end, :268)
                     double g6[6];
                     const double h = mmpc_hs_row(P, i, xk[0], xk[1], cs, sn, dr, dz, g6) - S[k];
@@ -975,6 +987,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                     e_p = mmpc_max_err(e_p, fabs(h + t)); m_th += fabs(h + t); acc(t);
                     tzmax = mmpc_max(tzmax, t * z); tzmin = mmpc_min(tzmin, t * z); zsum += z;
                 }
+                MMPC_GSE(4)
                 if (NQ) {   // rows of the NLP as written (quirk Q8): planes 0..j at x_k, planes j+1.. at x_{k-1}
                     double rq[6] = {0, 0, 0, 0, 0, 0};
                     if (k >= 1) {
@@ -1016,6 +1029,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
             else if (k >= 1) for (int i = 0; i < NX; i++) e_d = mmpc_max_err(e_d, fabs(rdx[i]));
             if (k < N) for (int a = 0; a < NU; a++) e_d = mmpc_max_err(e_d, fabs(rdu[a]));
             m_lg += log(mant) + (double)ex * 0.69314718055994530942;
+            MMPC_GSE(5)
         }
         RED[6 * MMPC_WAVE + lane] = m_f; RED[7 * MMPC_WAVE + lane] = m_th; PF[lane] = m_lg;   // (PF, with TT behind it: >= 64 doubles, not in use before the backward pass)
         RED[0 * MMPC_WAVE + lane] = e_d; RED[1 * MMPC_WAVE + lane] = e_p; RED[2 * MMPC_WAVE + lane] = tzmax;
