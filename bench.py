@@ -878,6 +878,10 @@ def run_c5(args, torch, mm, dist, rank, world, dev, local_dev, steps, warmup, cp
                         "value": B * T * steps / fa[mode][0], "ms_per_step": fa[mode][0] / steps * 1e3, "all_converged": bool(fa[mode][1]["all_converged"]),
                         "bitwise_equal_to_lockstep": bool(torch.equal(fa["lockstep"][1]["u0"], fa[mode][1]["u0"]) and torch.equal(fa["lockstep"][1]["x"], fa[mode][1]["x"])
                                                           and torch.equal(fa["lockstep"][1]["iters"], fa[mode][1]["iters"]))}
+            gv = {k: v["value"] for k, v in res["groups_out_of_phase"].items() if isinstance(v, dict)}
+            if gv:
+                best = max(gv, key=gv.get)
+                res["groups_out_of_phase"]["best"] = {"groups": int(best), "value": gv[best]}
             del fleet, fa
         except Exception as e:
             import traceback
