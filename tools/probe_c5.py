@@ -5,7 +5,7 @@ import mmpc_loader; mm = mmpc_loader.load()
 from oracle import synth
 dev = torch.device("cuda", 0)
 N, M, B, T = 30, 8, 8192, 10
-d = synth.make_batch(B, N=N, M=M, config_id=5, moving=True)
+d = synth.make_batch(B, N=N, M=M, config_id=int(os.environ.get("C5_SEED", 5)), moving=True)
 ctrl = mm.MPCWholeBody(mm.MobileManipulator(0.1), [], [], N=N, max_batch=B, n_obstacles=M, obs_per_stage=True)
 eng = ctrl._engine
 f64 = dict(dtype=torch.float64, device=dev)
