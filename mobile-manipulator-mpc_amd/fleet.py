@@ -134,6 +134,9 @@ class DeviceFleet:
                     next(gens[g])
         for g, (lo, hi, sub, st) in enumerate(self._groups):
             ev = torch.cuda.Event(); ev.record(st); main.wait_event(ev)
+            for v in res[g].values():        # (allocated on the group's stream, read on the caller's from here on)
+                if torch.is_tensor(v):
+                    v.record_stream(main)
         ok = res[0]["all_converged"]
         for r_ in res[1:]:
             ok = ok & r_["all_converged"]
