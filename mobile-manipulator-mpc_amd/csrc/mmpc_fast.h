@@ -830,6 +830,19 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
         auto &ls = MMPC_LS;
         double e_d = 0.0, e_p = MMPC_WR(1), tzmax = MMPC_WR(2), tzmin = MMPC_WR(3), zsum = MMPC_WR(4), phi = MMPC_WR(5), th = MMPC_WR(6);
         MmpcLogAcc la; la.init();
+        // long horizons read the references and the previous inputs from HBM / L2: the loads of ALL passes ahead of the loop (one
+        // exposed round trip instead of one per pass - the scheduler fences below keep the compiler from doing that itself)
+        double g_ref[SLIM ? NPASS : 1], g_ul[SLIM ? NPASS : 1];
+        if (SLIM) {
+#pragma unroll
+            for (int p = 0; p < NPASS; p++) {
+                const int idx = lane + MMPC_WAVE * p, ii = idx < NPAIR ? idx : 0;
+                const int k = ii / NV, v = ii % NV;
+                const bool isu = v >= NX && k < N;
+                g_ref[p] = ref_at(ii, k, v);
+                g_ul[p] = ulast_at(isu ? k : 0, isu ? v - NX : 0);
+            }
+        }
 #pragma unroll
         for (int p = 0; p < NPASS; p++) {
             mmpc_sched_fence();
@@ -842,8 +855,8 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                 // the input-only terms read a valid dummy address for state variables and carry weight 0 there
                 const bool isu = v >= NX && k < N;
                 const int au = isu ? v - NX : 0;
-                const double val = XU[idx], ref = ref_at(idx, k, v), rb0 = RB[idx];
-                const double ul = ulast_at(isu ? k : 0, au), ww0 = CST[MMPC_C_WW + au];
+                const double val = XU[idx], ref = SLIM ? g_ref[SLIM ? p : 0] : ref_at(idx, k, v), rb0 = RB[idx];
+                const double ul = SLIM ? g_ul[SLIM ? p : 0] : ulast_at(isu ? k : 0, au), ww0 = CST[MMPC_C_WW + au];
                 const double wq = CST[v < NX ? (k < N ? MMPC_C_WQ : MMPC_C_WP) + v : MMPC_C_WR + v - NX];
                 mmpc_sched_fence();
                 // cost gradient / value (diagonal weights): mpc_wholebody_qref.py:192-201,240-242
