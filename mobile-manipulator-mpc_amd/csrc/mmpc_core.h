@@ -191,6 +191,9 @@ struct MmpcDims {
 #define MMPC_W_ULIM 255  // [2][5]
 #define MMPC_W_DULIM 265 // [2][5]
 #define MMPC_W_SIZE 276
+#ifndef MMPC_GEN_FWD_UNROLL
+#define MMPC_GEN_FWD_UNROLL 2   // (static shapes; 1 / 2 / 4: C4 batch 30.5 / 29.9 / 29.8 ms)
+#endif
 #ifndef MMPC_GEN_RIC_UNROLL
 #define MMPC_GEN_RIC_UNROLL 2
 #endif
@@ -1841,6 +1844,8 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
         // (one phase per stage: the lane of row i forms the input step its row needs itself - nine products - instead of waiting for
         //  another lane's through LDS, and takes its row of [A B] from two packed words set once: the table look-ups by lane index
         //  were vector loads from constant memory in every stage)
+        constexpr int FWDU = NC > 0 ? MMPC_GEN_FWD_UNROLL : 1;
+#pragma unroll FWDU
         for (int k = 0; k < N; k++) {
             LANES_BEGIN
             if (lane < NX) {
