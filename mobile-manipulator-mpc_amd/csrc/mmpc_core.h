@@ -125,6 +125,12 @@ struct MmpcParams {
 // proximal term for crawling iterations: after two consecutive steps with alpha < MMPC_PROX_LO the (x,u) Hessian gets
 // + prox I (MMPC_PROX0, x4 per further small step), divided by 4 after a step with alpha > 0.5 (oracle/ipm_numpy.py)
 #define MMPC_PROX0 100.0
+// inertia correction (IPOPT: 1e-4, x100 the first time, x8 after, 1/3: the corrections this NLP needs are 1 ... 100)
+#define MMPC_IC_D0 1.0
+#define MMPC_IC_UP 4.0
+#define MMPC_IC_DN (1.0 / 3.0)
+// second-order corrections per iteration (IPOPT: max_soc = 4), tried where theta(x_k) <= theta_min
+#define MMPC_SOC_MAX 2
 #define MMPC_PROX_LO 0.05
 #define MMPC_PROX_MAX 1e4
 // multiplier safeguard (IPOPT eq. 16): z_i is kept within [mu / (kappa t_i), kappa mu / t_i] at every evaluation
@@ -259,7 +265,12 @@ struct MmpcIO {
     double *state;
     int budget, resume;
     double *gscr;      // this instance's gain block in global memory (specialised kernels of long horizons, MmpcGainBlock), else unused
+    double *soc;       // this instance's scratch of the second-order correction in global memory (mmpc_soc_doubles; null: no corrections)
 };
+// doubles of an instance's second-order-correction scratch (both kernels; NR = rows per stage that are not box rows): the
+// uncorrected direction, and for the specialised kernels - which move to a trial point in place - the constraint residuals of the
+// trial point and the running c_soc
+MMPC_HD constexpr int mmpc_soc_doubles(int N, int NX, int NU, int NR) { return (N + 1) * (4 * NX + NU + 1 + 2 * NR) + 8; }
 
 MMPC_DEV double mmpc_min(double a, double b) { return a < b ? a : b; }
 MMPC_DEV double mmpc_bound_push(double v, double lo, double hi) {
@@ -300,9 +311,11 @@ MMPC_DEV double mmpc_z_safeguard(double z, double t, double mu) {
     if (p < mu / MMPC_KAPPA_SIGMA) return mu / (MMPC_KAPPA_SIGMA * t);
     return z;
 }
-MMPC_DEV void mmpc_prox_update(double alpha, double &prox, int &nsmall) {
-    nsmall = alpha < MMPC_PROX_LO ? nsmall + 1 : 0;
-    if (alpha < MMPC_PROX_LO && (nsmall >= 2 || prox > 0.0)) prox = mmpc_min(MMPC_PROX_MAX, mmpc_max(MMPC_PROX0, 4.0 * prox));
+// (ap: the fraction-to-boundary step of the iteration - the crawl the term is for is the one that rule causes; a step the line
+//  search cut is the business of the inertia correction; alpha: the accepted step)
+MMPC_DEV void mmpc_prox_update(double ap, double alpha, double &prox, int &nsmall) {
+    nsmall = ap < MMPC_PROX_LO ? nsmall + 1 : 0;
+    if (ap < MMPC_PROX_LO && (nsmall >= 2 || prox > 0.0)) prox = mmpc_min(MMPC_PROX_MAX, mmpc_max(MMPC_PROX0, 4.0 * prox));
     else if (alpha > 0.5) prox = prox > MMPC_PROX0 * 1e-3 ? 0.25 * prox : 0.0;
 }
 MMPC_DEV bool mmpc_finite(double v) { return fabs(v) < 1.0e300; }
@@ -739,7 +752,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
     LANES_END
 
     int status = 1, it = 0, nfilt = 0, filt_init = 0, nrows_act = 0, nsmall = 0;
-    double prox = 0.0;
+    double prox = 0.0, delta_last = 0.0;
 #if MMPC_GEN_TILE
     // Riccati recursion on MFMA tiles over (x, 1, u), as in mmpc_fast.h (see there for the lane <-> entry map): lane l = 16 g + j
     // holds rows g + 4 r of column j in accumulator register r
@@ -879,7 +892,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
         // ============================================================ E1: evaluation + KKT partials
         MMPC_G2()
         LANES_BEGIN
-        double e_d = 0.0, e_p = 0.0, tzmax = 0.0, tzmin = 1e300, zsum = 0.0;
+        double e_d = 0.0, e_p = 0.0, tzmax = 0.0, tzmin = 1e300, zsum = 0.0, zeq = 0.0;
         // the merit function at this point (what the line search compares its trials with) falls out of the same evaluation:
         // objective terms, l1 infeasibility, sum of log t (the barrier parameter may still change before the line search)
         double m_f = 0.0, m_th = 0.0, m_lg = 0.0;
@@ -914,7 +927,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                     CD[k * NX + j] = c;
                     e_p = mmpc_max_err(e_p, fabs(c));
                     m_th += fabs(c);
-                    zsum += fabs(LAM[(k + 1) * NX + j]);
+                    zeq += fabs(LAM[(k + 1) * NX + j]);
                 }
                 double qin = 0.0;
                 for (int a = 0; a < NU; a++) {
@@ -1028,7 +1041,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                     rdx[j] += NUEQ[j];
                     e_p = mmpc_max_err(e_p, fabs(xk[j] - XREF[N * NX + j]));
                     m_th += fabs(xk[j] - XREF[N * NX + j]);
-                    zsum += fabs(NUEQ[j]);
+                    zeq += fabs(NUEQ[j]);
                 }
             }
             if (NQ) { for (int i = 0; i < NX; i++) RDX[k * NX + i] = rdx[i]; }   // finished in E1b (the next stage's rows add to it)
@@ -1039,7 +1052,8 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
         }
         RED[6 * MMPC_WAVE + lane] = m_f; RED[7 * MMPC_WAVE + lane] = m_th; PF[lane] = m_lg;   // (PF, with TT behind it: >= 64 doubles, not in use before the backward pass)
         RED[0 * MMPC_WAVE + lane] = e_d; RED[1 * MMPC_WAVE + lane] = e_p; RED[2 * MMPC_WAVE + lane] = tzmax;
-        RED[3 * MMPC_WAVE + lane] = tzmin; RED[4 * MMPC_WAVE + lane] = zsum;
+        RED[3 * MMPC_WAVE + lane] = tzmin; RED[4 * MMPC_WAVE + lane] = zsum;   // (zsum: the row multipliers alone)
+        HXX[lane] = zeq;   // |equality multipliers|: the stage Hessians are not in use before the assembly
         if (lane == 0) MISC[0] = 0.0;
         if (NSELF == 0 && lane == 0) MISC[1] = 0.0;
         LANES_END
@@ -1064,10 +1078,14 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
         err_p = MMPC_GRED_MAXERR(RED + 1 * MMPC_WAVE);
         tzmax = MMPC_GRED_MAX(RED + 2 * MMPC_WAVE);
         tzmin = MMPC_GRED_MIN(RED + 3 * MMPC_WAVE);
-        zsum = MMPC_GRED_SUM(RED + 4 * MMPC_WAVE);
-        double sd = zsum / (double)(nrows_act + NS * NX);
+        // IPOPT's termination test (Waechter & Biegler 2006, eq. 5-6): stationarity over s_d (all multipliers), complementarity
+        // over s_c (the row multipliers alone)
+        const double zrow = MMPC_GRED_SUM(RED + 4 * MMPC_WAVE);
+        zsum = zrow + MMPC_GRED_SUM(HXX);
+        double sd = zsum / (double)(nrows_act + NS * NX), sc = zrow / (double)(nrows_act > 0 ? nrows_act : 1);
         sd = (sd > 100.0 ? sd : 100.0) / 100.0;
-        E0 = mmpc_max_err(mmpc_max_err(err_d / sd, err_p), tzmax / sd);
+        sc = (sc > 100.0 ? sc : 100.0) / 100.0;
+        E0 = mmpc_max_err(mmpc_max_err(err_d / sd, err_p), tzmax / sc);
         if (!mmpc_finite(E0) || !mmpc_finite(zsum)) {   // (NaN fails the comparison inside mmpc_finite too)
 #ifdef MMPC_EMU_DEBUG
             fprintf(stderr, "generic: E0 not finite at it %d: err_d %g err_p %g tzmax %g zsum %g\n", it, err_d, err_p, tzmax, zsum);
@@ -1080,7 +1098,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
             bool changed = false;
             for (;;) {
                 const double compmu = mmpc_max(fabs(tzmax - mu), fabs(tzmin - mu));
-                const double Emu = mmpc_max(mmpc_max(err_d / sd, err_p), compmu / sd);
+                const double Emu = mmpc_max(mmpc_max(err_d / sd, err_p), compmu / sc);
                 if (!(Emu <= 10.0 * mu && mu > tol / 10)) break;
                 mu = mmpc_max(tol / 10, mmpc_min(0.2 * mu, mu * sqrt(mu)));
                 changed = true;
@@ -1090,16 +1108,57 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
 
         MMPC_GS(1)
         // ============================================================ Newton direction
+        // Second-order correction (Waechter & Biegler 2006, section 2.4): when the first trial step is rejected without reducing the
+        // infeasibility - and theta(x_k) <= theta_min, the regime of the switching condition, where the Maratos effect lives - the
+        // direction is recomputed from x_k with c_soc = alpha c(x_k) + c(x_k + alpha d) in place of the constraint residuals (CD, HR),
+        // at most MMPC_SOC_MAX times (c_soc <- alpha_soc c_soc + c(x_soc)).  The row multipliers take their step of the uncorrected
+        // direction first (it does not depend on alpha; the specialised kernels, which move to a trial point in place, have applied
+        // it by then): the corrected system is the primal-dual Newton system at (x_k, z+).  The uncorrected direction waits in this
+        // instance's block of global memory (io.soc) and the line search goes on along it when the correction fails.
+        // slacks and multipliers of the rows by (a, a_z) along the direction in DX .. DTR (one item per (row, stage), row-major as in
+        // D2); the multipliers are safeguarded with the slack at a whether or not the slack itself moves
+        auto row_step = [&](double a, double a_z, bool do_t, bool do_z) {
+            LANES_BEGIN
+            for (int item = lane; item < R * NS; item += MMPC_WAVE) {
+                const int r = item / NS, k = item - r * NS;
+                {
+                    double dtv, b;
+                    if (r < SL_C) {
+                        if (!box_bound(k, r, b)) continue;
+                        double h, jd;
+                        if (r < NU) { h = b - U[k * NU + r]; jd = -DU[k * NU + r]; }
+                        else if (r < SL_XLO) { h = U[k * NU + r - NU] - b; jd = DU[k * NU + r - NU]; }
+                        else if (r < SL_XHI) { h = b - X[k * NX + r - SL_XLO]; jd = -DX[k * NX + r - SL_XLO]; }
+                        else { h = X[k * NX + r - SL_XHI] - b; jd = DX[k * NX + r - SL_XHI]; }
+                        dtv = -(h + T[k * R + r]) - jd;
+                    } else if (r >= SL_Q && k == 0) continue;
+                    else dtv = DTR[k * NR + r - SL_C];
+                    const double t = T[k * R + r], z = Z[k * R + r], it_ = mmpc_rcp(t);
+                    const double dzv = mu * it_ - z - (z * it_) * dtv;      // (the same expression as in D2: ad was formed from it)
+                    const double tn = t + a * dtv;
+                    if (do_t) T[k * R + r] = tn;
+                    if (do_z) Z[k * R + r] = mmpc_z_safeguard(z + a_z * dzv, tn, mu);
+                }
+            }
+            LANES_END
+        };
+        int soc_p = 0;
+        bool z_done = false, fatal = false;
+        double alpha = 0.0, ap0 = 1.0, ad0 = 1.0, dphi0 = 0.0, th_prev = 0.0, phi0 = 0.0, th0 = 0.0;
+        for (;;) {   // direction passes: the regular one, then the corrected ones
         int failed = 0;
-        // Hessian ladder: exact Lagrangian Hessian; on a non-positive pivot the same without the curvature of the dynamics
-        // (lam^T d2f) - it keeps the curvature of the constraint rows and of the cost, which plain Gauss-Newton steps
-        // overshoot without (full steps that zig-zag for hundreds of iterations next to a saddle); then Gauss-Newton
-        // (the middle rung is skipped with half-space rows or the terminal equality: there it passes the pivot test with
-        //  directions the line search cuts to nothing)
-        for (int attempt = 0; attempt < 3; attempt++) {
-            if (attempt == 1 && (NHS > 0 || teq)) continue;
-            const bool exact = attempt <= 1, dyn_curv = attempt == 0;
-            const double reg = prox;
+        // Newton matrix: the exact Lagrangian Hessian; on a non-positive pivot of the recursion IPOPT's inertia correction
+        // (Waechter & Biegler 2006, Algorithm IC) - + delta_w I on (x, u), delta_w from a geometric sequence (MMPC_IC_D0, x MMPC_IC_UP
+        // per failed pass; an iteration after a corrected one starts from MMPC_IC_DN times the last successful value) until every
+        // pivot is positive.  (Rounds 1-3 went down a ladder exact -> exact without lam^T d2f -> Gauss-Newton instead: full
+        // Gauss-Newton steps that crawl along a saddle of the barrier problem for hundreds of iterations were the tail of the
+        // iteration counts.)  With the terminal equality the multipliers of the regularised system grow like delta_w (the full
+        // correction E dx_N = e is forced whatever the damping) and feed back into lam^T d2f: there the second and last rung is
+        // Gauss-Newton, as before.
+        double dw = 0.0;
+        for (int attempt = 0;;) {
+            const bool exact = attempt == 0, dyn_curv = exact;
+            const double reg = prox + dw;
             // ---- A1: stage Hessian / gradient assembly
             MMPC_G2()
             LANES_BEGIN
@@ -1783,13 +1842,11 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
 #ifdef MMPC_EMU_DEBUG
             if (failed) fprintf(stderr, "generic it %d: attempt %d lost a pivot (prox %g)\n", it, attempt, prox);
 #endif
-            if (!failed) break;
-            if (attempt == 2) {
-                // even the Gauss-Newton pass lost a pivot (round-off under barrier weights z/t ~ 1e9 and more): raise the
-                // proximal term until the pass goes through (not with the terminal equality, where it is off)
-                if (teq || prox >= MMPC_PROX_MAX) break;
-                prox = mmpc_min(MMPC_PROX_MAX, mmpc_max(MMPC_PROX0, 4.0 * prox));
-                attempt = 1;
+            if (!failed) { if (dw > 0.0) delta_last = dw; break; }
+            if (teq) { if (attempt >= 1) break; attempt = 1; }
+            else {
+                dw = dw == 0.0 ? (delta_last == 0.0 ? MMPC_IC_D0 : mmpc_max(1e-20, MMPC_IC_DN * delta_last)) : MMPC_IC_UP * dw;
+                if (dw > 1e40) break;
             }
             failed = 0;
             LANES_BEGIN
@@ -1800,7 +1857,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
 #ifdef MMPC_EMU_DEBUG
             fprintf(stderr, "generic: factorisation failed at it %d (prox %g)\n", it, prox);
 #endif
-            status = 2; break; }
+            status = 2; fatal = true; break; }
 
         {
             const bool sig = NQ && SIGW[0] != 0.0, brd = teq || sig;
@@ -1918,7 +1975,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
         MMPC_GS(5)
         // ---- D2: row steps, fraction-to-boundary, directional derivative, merit at alpha = 0
         const double tau = mmpc_max(0.99, 1.0 - mu);
-        auto stage_merit = [&](int k, double alpha, double &phi_k, double &th_k) {
+        auto stage_merit = [&](int k, double alpha, double &phi_k, double &th_k, int soc_acc = 0, double a_prev = 0.0) {
             // barrier objective and l1 infeasibility contributions of stage k at w + alpha dw
             double xk[NX], uk[NU > 0 ? NU : 1];
             for (int j = 0; j < NX; j++) xk[j] = X[k * NX + j] + alpha * DX[k * NX + j];
@@ -1942,7 +1999,11 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
                 xn[4] = xk[4] + dt * (uk[0] * sn + xk[3] * xk[5]);
                 xn[5] = xk[5] + dt * uk[1];
                 if (KIND != 1) { xn[6] = xk[6] + dt * uk[2]; xn[7] = xk[7] + dt * uk[3]; xn[8] = xk[8] + dt * uk[4]; }
-                for (int j = 0; j < NX; j++) th += fabs(xn[j] - (X[(k + 1) * NX + j] + alpha * DX[(k + 1) * NX + j]));
+                for (int j = 0; j < NX; j++) {
+                    const double cj = xn[j] - (X[(k + 1) * NX + j] + alpha * DX[(k + 1) * NX + j]);
+                    th += fabs(cj);
+                    if (soc_acc) CD[k * NX + j] = a_prev * CD[k * NX + j] + cj;   // c_soc <- a c_soc + c(trial)
+                }
             }
             // sum of log t: product of mantissas + sum of exponents (one log per stage)
             double mant = 1.0; int ex = 0;
@@ -1985,9 +2046,10 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
             }
             for (int m = 0; m < NR; m++) {
                 if (k == 0 && m >= NR - NQ) continue;   // (no rows of the as-written set at stage 0)
-                const double tv = T[k * R + SL_C + m] + alpha * DTR[k * NR + m];
+                const double t0 = T[k * R + SL_C + m], tv = t0 + alpha * DTR[k * NR + m];
                 th += fabs(hr[m] + tv);
                 acc(tv);
+                if (soc_acc) HR[k * NR + m] = a_prev * (HR[k * NR + m] + t0) + (hr[m] + tv) - t0;   // (h + t)_soc, kept as h_soc = . - t
             }
             if (teq && k == N) for (int j = 0; j < 2; j++) th += fabs(xk[j] - XREF[N * NX + j]);
             phi_k = f - mu * (log(mant) + (double)ex * 0.69314718055994530942);
@@ -2050,76 +2112,116 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
         double ap = 1.0, ad = 1.0, dphi = 0.0;
         ap = MMPC_GRED_MIN(RED + 0 * MMPC_WAVE); ad = MMPC_GRED_MIN(RED + 1 * MMPC_WAVE); dphi = MMPC_GRED_SUM(RED + 2 * MMPC_WAVE);
         MMPC_GS(6)
-        // ---- merit at the current point: from the evaluation E1 (same point, same slacks), with the barrier parameter as it is now
-        const double phi0 = m_F0 - mu * m_LG0, th0 = m_TH0;
-        if (!mmpc_finite(phi0) || !mmpc_finite(th0)) { status = 2; break; }   // (an infinite reference / obstacle: opti.solve() raises)
-        if (!filt_init) { nfilt = 0; th_max = 1e4 * mmpc_max(1.0, th0); th_min = 1e-4 * mmpc_max(1.0, th0); filt_init = 1; }
-
-        MMPC_GS(7)
-        // ---- filter line search (Waechter-Biegler acceptance rules, no restoration phase)
-        double alpha = ap;
-        for (int lspass = 0; lspass < 2; lspass++) {
-            bool accepted = false;
-            alpha = ap;
-            for (int ls = 0; ls < MMPC_MAX_LS; ls++) {
-                LANES_BEGIN
-                double ph = 0.0, th = 0.0;
-                for (int k = lane; k < NS; k += MMPC_WAVE) { double a, b; stage_merit(k, alpha, a, b); ph += a; th += b; }
-                RED[5 * MMPC_WAVE + lane] = ph; RED[6 * MMPC_WAVE + lane] = th;
-                LANES_END
-                double phi = 0.0, th = 0.0;
-                phi = MMPC_GRED_SUM(RED + 5 * MMPC_WAVE); th = MMPC_GRED_SUM(RED + 6 * MMPC_WAVE);
-                bool okf = th < th_max;
-                for (int i = 0; i < nfilt && okf; i++) if (th >= FILT[2 * i] && phi >= FILT[2 * i + 1]) okf = false;
-                const bool ftype = dphi < 0 && th0 <= th_min && alpha * pow(-dphi, 2.3) > pow(th0, 1.1);
-                bool augment = false;
-                if (okf) {
-                    if (ftype) accepted = phi <= phi0 + 1e-8 * alpha * dphi + 1e-14 * fabs(phi0);
-                    else if (th <= (1 - 1e-5) * th0 || phi <= phi0 - 1e-5 * th0) { accepted = true; augment = true; }
-                }
-                if (augment) {
-                    int slot = nfilt;
-                    if (nfilt >= MMPC_FCAP) { slot = 0; for (int i = 1; i < MMPC_FCAP; i++) if (FILT[2 * i] > FILT[2 * slot]) slot = i; }
-                    else nfilt++;
-                    LANES_BEGIN
-                    if (lane == 0) { FILT[2 * slot] = (1 - 1e-5) * th0; FILT[2 * slot + 1] = phi0 - 1e-5 * th0; }
-                    LANES_END
-                }
-                if (accepted) break;
-                if (ls < MMPC_MAX_LS - 1) alpha *= 0.5;
-            }
-            if (accepted || nfilt == 0) break;
-            nfilt = 0;  // filter reset heuristic: the filter blocked every trial step
+        if (soc_p == 0) {
+            ap0 = ap; ad0 = ad; dphi0 = dphi;
+            // ---- merit at the current point: from the evaluation E1 (same point, same slacks), with the barrier parameter as it is now
+            phi0 = m_F0 - mu * m_LG0; th0 = m_TH0;
+            if (!mmpc_finite(phi0) || !mmpc_finite(th0)) { status = 2; fatal = true; break; }   // (an infinite reference / obstacle: opti.solve() raises)
+            if (!filt_init) { nfilt = 0; th_max = 1e4 * mmpc_max(1.0, th0); th_min = 1e-4 * mmpc_max(1.0, th0); filt_init = 1; }
         }
+        MMPC_GS(7)
+        // ---- filter line search (Waechter-Biegler acceptance rules, second-order correction, no restoration phase)
+        // barrier objective and infeasibility of the trial point at step a along the direction in DX .. DTR (soc_acc: also
+        // c_soc <- a_prev c_soc + c(trial) into CD / HR)
+        auto trial = [&](double a, double &phi, double &th, int soc_acc, double a_prev) {
+            LANES_BEGIN
+            double ph = 0.0, tq = 0.0;
+            for (int k = lane; k < NS; k += MMPC_WAVE) { double u, v; stage_merit(k, a, u, v, soc_acc, a_prev); ph += u; tq += v; }
+            RED[5 * MMPC_WAVE + lane] = ph; RED[6 * MMPC_WAVE + lane] = tq;
+            LANES_END
+            phi = MMPC_GRED_SUM(RED + 5 * MMPC_WAVE); th = MMPC_GRED_SUM(RED + 6 * MMPC_WAVE);
+        };
+        // acceptance to the filter and against the current point; a0: the step length of the switching and Armijo conditions (a
+        // corrected step is tested with the length of the step it corrects)
+        auto accept = [&](double th, double phi, double a0) -> bool {
+            bool okf = th < th_max, accepted = false;
+            for (int i = 0; i < nfilt && okf; i++) if (th >= FILT[2 * i] && phi >= FILT[2 * i + 1]) okf = false;
+            const bool ftype = dphi0 < 0 && th0 <= th_min && a0 * pow(-dphi0, 2.3) > pow(th0, 1.1);
+            bool augment = false;
+            if (okf) {
+                if (ftype) accepted = phi <= phi0 + 1e-8 * a0 * dphi0 + 1e-14 * fabs(phi0);
+                else if (th <= (1 - 1e-5) * th0 || phi <= phi0 - 1e-5 * th0) { accepted = true; augment = true; }
+            }
+            if (augment) {
+                int slot = nfilt;
+                if (nfilt >= MMPC_FCAP) { slot = 0; for (int i = 1; i < MMPC_FCAP; i++) if (FILT[2 * i] > FILT[2 * slot]) slot = i; }
+                else nfilt++;
+                LANES_BEGIN
+                if (lane == 0) { FILT[2 * slot] = (1 - 1e-5) * th0; FILT[2 * slot + 1] = phi0 - 1e-5 * th0; }
+                LANES_END
+            }
+            return accepted;
+        };
+        // backtracking along the uncorrected direction from trial ls0 of the first pass on (+ the filter-reset heuristic)
+        auto backtrack = [&](int ls0) {
+            for (int lspass = 0; lspass < 2; lspass++) {
+                bool accepted = false;
+                const int lsb = lspass == 0 ? ls0 : 0;
+                alpha = ap0;
+                for (int q = 0; q < lsb; q++) alpha *= 0.5;
+                for (int ls = lsb; ls < MMPC_MAX_LS; ls++) {
+                    double phi, th;
+                    trial(alpha, phi, th, 0, 0.0);
+                    accepted = accept(th, phi, alpha);
+                    if (accepted) break;
+                    if (ls < MMPC_MAX_LS - 1) alpha *= 0.5;
+                }
+                if (accepted || nfilt == 0) break;
+                nfilt = 0;  // filter reset heuristic: the filter blocked every trial step
+            }
+        };
+        // what the correction keeps of the uncorrected direction (restored when it fails)
+        auto soc_swap = [&](bool save) {
+            double *q = io.soc;
+            LANES_BEGIN
+            const int o1 = NS * NX, o2 = o1 + NS * NU, o3 = o2 + NS, o4 = o3 + NS * NX, o5 = o4 + NS * NR;
+            for (int i = lane; i < NS * NX; i += MMPC_WAVE) { if (save) { q[i] = DX[i]; q[o3 + i] = DLAM[i]; } else { DX[i] = q[i]; DLAM[i] = q[o3 + i]; } }
+            for (int i = lane; i < N * NU; i += MMPC_WAVE) { if (save) q[o1 + i] = DU[i]; else DU[i] = q[o1 + i]; }
+            for (int i = lane; i < NS; i += MMPC_WAVE) { if (save) q[o2 + i] = DS[i]; else DS[i] = q[o2 + i]; }
+            for (int i = lane; i < NS * NR; i += MMPC_WAVE) { if (save) q[o4 + i] = DTR[i]; else DTR[i] = q[o4 + i]; }
+            if (lane == 0) {
+                if (save) { q[o5] = NUEQ[2]; q[o5 + 1] = NUEQ[3]; q[o5 + 2] = SIGW[1]; }
+                else { NUEQ[2] = q[o5]; NUEQ[3] = q[o5 + 1]; SIGW[1] = q[o5 + 2]; }
+            }
+            LANES_END
+        };
+        if (soc_p == 0) {
+            double phi, th;
+            alpha = ap;
+            trial(alpha, phi, th, 0, 0.0);
+            if (accept(th, phi, alpha)) break;
+            if (MMPC_SOC_MAX > 0 && !teq && io.soc && th >= th0 && th0 <= th_min) {
+                row_step(alpha, ad0, false, true);    // the multipliers' step, safeguarded with the trial slacks
+                z_done = true;
+                soc_swap(true);
+                trial(alpha, phi, th, 1, alpha);      // CD, HR <- alpha c(x_k) + c(x_k + alpha d)
+                th_prev = th; soc_p = 1;
+                continue;
+            }
+            backtrack(1);
+            break;
+        } else {
+            double phi, th;
+            trial(ap, phi, th, 0, 0.0);
+            if (accept(th, phi, ap0)) { alpha = ap; break; }
+            if (th > 0.99 * th_prev || soc_p >= MMPC_SOC_MAX) {   // the correction failed: on along the uncorrected direction
+                soc_swap(false);
+                backtrack(1);
+                break;
+            }
+            th_prev = th;
+            trial(ap, phi, th, 1, ap);
+            soc_p++;
+        }
+        }   // direction passes
+        if (fatal) break;
 #ifdef MMPC_EMU_DEBUG
-        fprintf(stderr, "generic it %d mu %.2e E0 %.3e err_d %.3e err_p %.3e alpha %.3e ap %.3e ad %.3e prox %.1e dphi %.3e\n", it, mu, E0, err_d, err_p, alpha, ap, ad, prox, dphi);
+        fprintf(stderr, "generic it %d mu %.2e E0 %.3e err_d %.3e err_p %.3e alpha %.3e ap %.3e ad %.3e prox %.1e dphi %.3e soc %d\n", it, mu, E0, err_d, err_p, alpha, ap0, ad0, prox, dphi0, soc_p);
 #endif
-        if (!teq) mmpc_prox_update(alpha, prox, nsmall);   // (with the terminal equality the forced correction makes nu grow like prox)
+        if (!teq) mmpc_prox_update(ap0, alpha, prox, nsmall);   // (with the terminal equality the forced correction makes nu grow like prox)
         MMPC_GS(8)
         // ---- update (one item per (row, stage), row-major as in D2)
-        LANES_BEGIN
-        for (int item = lane; item < R * NS; item += MMPC_WAVE) {
-            const int r = item / NS, k = item - r * NS;
-            {
-                double dtv, b;
-                if (r < SL_C) {
-                    if (!box_bound(k, r, b)) continue;
-                    double h, jd;
-                    if (r < NU) { h = b - U[k * NU + r]; jd = -DU[k * NU + r]; }
-                    else if (r < SL_XLO) { h = U[k * NU + r - NU] - b; jd = DU[k * NU + r - NU]; }
-                    else if (r < SL_XHI) { h = b - X[k * NX + r - SL_XLO]; jd = -DX[k * NX + r - SL_XLO]; }
-                    else { h = X[k * NX + r - SL_XHI] - b; jd = DX[k * NX + r - SL_XHI]; }
-                    dtv = -(h + T[k * R + r]) - jd;
-                } else if (r >= SL_Q && k == 0) continue;
-                else dtv = DTR[k * NR + r - SL_C];
-                const double t = T[k * R + r], z = Z[k * R + r], it_ = mmpc_rcp(t);
-                const double dzv = mu * it_ - z - (z * it_) * dtv;      // (the same expression as in D2: ad was formed from it)
-                const double tn = t + alpha * dtv;
-                T[k * R + r] = tn;
-                Z[k * R + r] = mmpc_z_safeguard(z + ad * dzv, tn, mu);
-            }
-        }
-        LANES_END
+        row_step(alpha, ad0, true, !z_done);
         LANES_BEGIN
         for (int i = lane; i < NS * NX; i += MMPC_WAVE)
             if (i >= NX) { X[i] += alpha * DX[i]; LAM[i] += alpha * DLAM[i]; }

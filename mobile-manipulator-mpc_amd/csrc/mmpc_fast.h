@@ -273,7 +273,7 @@ MMPC_DEV double mmpc_wave_min(double v) {
 #else
 // host emulation: butterfly in the same pairing order as the device shuffles, so that the
 // floating-point sums are bit-identical on every "lane"
-static inline double mmpc_emu_red(double (*wr)[8], int i, int op) {
+static inline double mmpc_emu_red(double (*wr)[9], int i, int op) {
     double v[MMPC_WAVE], w[MMPC_WAVE];
     for (int l = 0; l < MMPC_WAVE; l++) v[l] = wr[l][i];
     for (int q = 0; q < 6; q++) {
@@ -292,6 +292,9 @@ static inline double mmpc_emu_red(double (*wr)[8], int i, int op) {
 #define MMPC_RED_MAX(i) mmpc_emu_red(wr_all, i, 1)
 #define MMPC_RED_MIN(i) mmpc_emu_red(wr_all, i, 2)
 #endif
+
+// compile-time switch handed to the generic lambdas of the assembly / row-step phases (corrected pass of the second-order correction or not)
+template <bool B> struct MmpcTag { static constexpr bool value = B; };
 
 // product-of-mantissas accumulator for sum(log t)
 struct MmpcLogAcc {
@@ -347,10 +350,10 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
     const double dt = P.dt, Sw = P.S, tol = P.tol;
 #ifdef MMPC_EMU
     static thread_local MmpcLaneState<KIND, N, MC> ls_all[MMPC_WAVE];
-    static thread_local double wr_all[MMPC_WAVE][8];
+    static thread_local double wr_all[MMPC_WAVE][9];
 #else
     MmpcLaneState<KIND, N, MC> ls_one;
-    double wr_one[8];
+    double wr_one[9];
 #endif
     const double *const OBSP = (SLIM && ops) ? io.obs : OBS;
     auto obs_ptr = [&](int k, int m) -> const double * { return OBSP + ((ops ? k * M : 0) + m) * 3; };
@@ -582,7 +585,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
     MMPC_WR(0) = cnt;
     LANES_END
     const double nrows_act = MMPC_RED_SUM(0);
-    const double inv_rows = 1.0 / (nrows_act + (double)(NS * NX));
+    const double inv_rows = 1.0 / (nrows_act + (double)(NS * NX)), inv_nrows = 1.0 / (nrows_act > 0.0 ? nrows_act : 1.0);
 
     int status = 1, it = 0, nfilt = 0, filt_init = 0;
     double E0 = 0.0, th_max = 0.0, th_min = 0.0;
@@ -592,7 +595,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
     constexpr int ST_S = NPAIR, ST_LAM = NPAIR + NS, ST_FILT = NPAIR + NS + NS * NX, ST_SCAL = ST_FILT + 2 * MMPC_FCAP,
                   ST_LANE = ST_SCAL + MMPC_NSCAL;
     int nsmall_r = 0;
-    double prox_r = 0.0;
+    double prox_r = 0.0, delta_r = 0.0;
     if (CONT && io.resume) {
         // ---- continue a suspended solve: the state the uninterrupted loop would hold at this point
         const double *const st_xu = io.state, *const st_s = io.state + ST_S, *const st_lam = io.state + ST_LAM,
@@ -612,7 +615,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
         for (int i = 0; i < 4; i++) { ls.st[i] = q[2 * NPASS + 2 * MCS + i]; ls.sz[i] = q[2 * NPASS + 2 * MCS + 4 + i]; }
         LANES_END
         mu = st_scal[0]; th_max = st_scal[1]; th_min = st_scal[2]; prox_r = st_scal[3];
-        it = (int)st_scal[4]; nfilt = (int)st_scal[5]; filt_init = (int)st_scal[6]; nsmall_r = (int)st_scal[7];
+        it = (int)st_scal[4]; nfilt = (int)st_scal[5]; filt_init = (int)st_scal[6]; nsmall_r = (int)st_scal[7]; delta_r = st_scal[8];
     }
     const int it_start = CONT ? it : 0;
     // results of the evaluation of the current point (iterate or line-search trial)
@@ -621,6 +624,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
     // first trials are accepted), so the loop below evaluates once per trial and never a second time for the accepted one
     int in_ls = 0, lspass = 0, lsi = 0, nsmall = nsmall_r;
     double prox = prox_r;   // proximal term for crawling iterations (mmpc_prox_update)
+    double delta_last = delta_r;   // last successful inertia correction
     double alpha = 0.0, ap = 1.0, ad = 1.0, dphi = 0.0, phi0 = 0.0, th0 = 0.0;
 
     // ---- move to a trial point: the primal variables, the equality multipliers and the slacks of the nonlinear rows by
@@ -672,6 +676,84 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
         LANES_END
     };
 
+    // ---- second-order correction (Waechter & Biegler 2006, section 2.4; algorithm and deviations: mmpc_core.h).  This kernel moves to
+    //      a trial point in place, so a correction is a small state machine around the evaluation:
+    //        soc_st 0  no correction in progress
+    //               1  back at x_k, evaluated again (with the multipliers' step taken): the constraint residuals are replaced by
+    //                  c_soc = a c_soc + c(trial) and the direction is formed from them (corrected pass)
+    //               2  the corrected trial x_k + a_soc d_soc has been evaluated: filter test with the length / slope of the step it corrects
+    //               3  the correction failed: back at x_k, evaluated again, the uncorrected direction restored from io.soc - only the
+    //                  row steps (registers) are formed again, then the line search goes on with alpha / 2
+    //      What has to survive a corrected pass lives in this instance's block of global memory (rare path: no LDS, no registers):
+    constexpr int NRS = (MC > 0 ? MC : 0) + NSELF;                                     // rows per stage that are not box rows
+    constexpr int O_D = 0, O_TC = O_D + NS * NV + NS + NS * NX, O_TR = O_TC + NS * NX,  // direction | residuals of the trial point
+                  O_AC = O_TR + NS * NRS, O_AR = O_AC + NS * NX;                         // running c_soc (dynamics | rows)
+    static_assert(O_AR + NS * NRS <= mmpc_soc_doubles(N, NX, NU, NRS), "second-order correction scratch");
+    int soc_st = 0, soc_p = 0, fatal = 0;
+    double a_soc = 0.0, alpha0 = 0.0, a_prev = 0.0, th_prev = 0.0;
+#ifdef MMPC_EMU
+#define MMPC_SOC_FENCE()
+#else
+#define MMPC_SOC_FENCE() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+#endif
+    // the uncorrected direction to / from the scratch
+    auto soc_dir = [&](bool save) {
+        LANES_BEGIN
+        double *q = io.soc + O_D;
+        for (int i = lane; i < NS * NV; i += MMPC_WAVE) { if (save) q[i] = DXU[i]; else DXU[i] = q[i]; }
+        for (int i = lane; i < NS; i += MMPC_WAVE) { if (save) q[NS * NV + i] = DS[i]; else DS[i] = q[NS * NV + i]; }
+        for (int i = lane; i < NS * NX; i += MMPC_WAVE) { if (save) q[NS * NV + NS + i] = DLAM[i]; else DLAM[i] = q[NS * NV + NS + i]; }
+        LANES_END
+        MMPC_SOC_FENCE()
+    };
+    // constraint residuals of the point that has just been evaluated (dynamics: CD; rows: h + t, re-derived from the evaluation's
+    // caches).  acc = false: stored as the residuals of a rejected trial.  acc = true (back at x_k): c_soc <- a_prev c_soc + c(trial),
+    // c_soc = c(x_k) in the first round; the dynamics part replaces CD, the row part is read by the corrected pass, and the
+    // terminal self rows' sum of w (h + t) - formed by the evaluation, quirk Q1 - is redone with it.
+    auto soc_rows = [&](bool acc, bool first) {
+        LANES_BEGIN
+        auto &ls = MMPC_LS;
+        double *tc = io.soc + O_TC, *tr = io.soc + O_TR, *ac = io.soc + O_AC, *ar = io.soc + O_AR;
+        for (int i = lane; i < N * NX; i += MMPC_WAVE) {
+            if (!acc) tc[i] = CD[i];
+            else { const double v = a_prev * (first ? CD[i] : ac[i]) + tc[i]; ac[i] = v; CD[i] = v; }
+        }
+        {
+            MMPC_ROW_LANE
+            if (rlane && (RG > 1 || lane < NS)) {
+                const double px = XU[rk * NV], py = XU[rk * NV + 1], sk = S[rk];
+#pragma unroll
+                for (int r = 0; r < MCR; r++) {
+                    const int m = rs + RG * r;
+                    if (m < M) {
+                        const double *o = obs_ptr(rk, m);
+                        const double dx = px - o[0], dy = py - o[1];
+                        const double rr = (o[2] + MMPC_BASE_R) - sqrt(dx * dx + dy * dy) - sk + ls.ct[r];
+                        const int e = rk * NRS + m;
+                        if (!acc) tr[e] = rr; else ar[e] = a_prev * (first ? rr : ar[e]) + tr[e];
+                    }
+                }
+            }
+        }
+        if (NSELF && lane < NS) {
+            const int k = lane;
+            const double sn = TRG[k * 8], cs = TRG[k * 8 + 1], sks = S[slack_idx(k)];
+            double dr[3], dz[3], swr = 0.0;
+#pragma unroll
+            for (int a = 0; a < 3; a++) { dr[a] = TRG[k * 8 + 2 + a]; dz[a] = TRG[k * 8 + 5 + a]; }
+#pragma unroll
+            for (int i = 0; i < NSELF; i++) {
+                const double rr = mmpc_self_row(i, XU[k * NV], XU[k * NV + 1], cs, sn, dr, dz, nullptr) - sks + ls.st[i];
+                const int e = k * NRS + M + i;
+                if (!acc) tr[e] = rr;
+                else { const double v = a_prev * (first ? rr : ar[e]) + tr[e]; ar[e] = v; swr += ls.sz[i] * mmpc_rcp(ls.st[i]) * v; }
+            }
+            if (acc && k == N) SN[2] = swr;
+        }
+        LANES_END
+        MMPC_SOC_FENCE()
+    };
+
     MMPC_T0()
 #pragma unroll 1
     for (;;) {
@@ -713,7 +795,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
         // ============================================================ E1 (stage lanes)
         LANES_BEGIN
         auto &ls = MMPC_LS;
-        double e_p = 0.0, tzmax = 0.0, tzmin = 1e300, zsum = 0.0, phi = 0.0, th = 0.0, slog = 0.0;
+        double e_p = 0.0, tzmax = 0.0, tzmin = 1e300, zsum = 0.0, zeq = 0.0, phi = 0.0, th = 0.0, slog = 0.0;
         MmpcLogAcc la; la.init();
         if (RG > 1 && M > 0) {
             e_p = MMPC_WR(1); tzmax = MMPC_WR(2); tzmin = MMPC_WR(3); zsum = MMPC_WR(4); th = MMPC_WR(6); la.mant = MMPC_WR(7); la.ex = (int)MMPC_WR(0);
@@ -752,7 +834,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                 c[5] = xk[5] + dt * uk[1] - xn1[5];
                 if (KIND == 0) { c[6] = xk[6] + dt * uk[2] - xn1[6]; c[7] = xk[7] + dt * uk[3] - xn1[7]; c[8] = xk[8] + dt * uk[4] - xn1[8]; }
 #pragma unroll
-                for (int j = 0; j < NX; j++) { CD[k * NX + j] = c[j]; e_p = mmpc_vmax(e_p, fabs(c[j])); th += fabs(c[j]); zsum += fabs(ln[j]); }
+                for (int j = 0; j < NX; j++) { CD[k * NX + j] = c[j]; e_p = mmpc_vmax(e_p, fabs(c[j])); th += fabs(c[j]); zeq += fabs(ln[j]); }
                 // - A^T lam_{k+1}, - B^T lam_{k+1}  (sparse, base.py:19-26)
                 rb[0] -= ln[0]; rb[1] -= ln[1];
                 rb[2] -= ln[2] + a32 * ln[3] + a42 * ln[4];
@@ -822,6 +904,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
         }
         if (RG > 1 || lane < NS) slog = la.value();
         MMPC_WR(1) = e_p; MMPC_WR(2) = tzmax; MMPC_WR(3) = tzmin; MMPC_WR(4) = zsum; MMPC_WR(5) = phi; MMPC_WR(6) = th; MMPC_WR(7) = slog;
+        MMPC_WR(8) = zeq;   // |multipliers of the dynamics|: s_d counts them, s_c does not
         if (NSELF == 0 && lane == 0) { for (int a = 0; a < 10; a++) SN[a] = 0.0; }
         LANES_END
         MMPC_TS(1)
@@ -885,15 +968,17 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
         LANES_END
         err_d = MMPC_RED_MAX(0); err_p = MMPC_RED_MAX(1); tzmax = MMPC_RED_MAX(2); tzmin = MMPC_RED_MIN(3);
         zsum = MMPC_RED_SUM(4); cost_c = MMPC_RED_SUM(5); th_c = MMPC_RED_SUM(6); sumlog = MMPC_RED_SUM(7);
+        const double zeq_c = MMPC_RED_SUM(8);
         if (in_ls) {
             // ---- filter test of the trial point just evaluated (Waechter-Biegler; + filter reset heuristic)
             const double phi = cost_c - mu * sumlog, th = th_c;
             bool okf = th < th_max;
             for (int i = 0; i < nfilt && okf; i++) if (th >= FILT[2 * i] && phi >= FILT[2 * i + 1]) okf = false;
-            const bool ftype = dphi < 0 && th0 <= th_min && alpha * mmpc_powf(-dphi, 2.3f) > mmpc_powf(th0, 1.1f);
+            const double a_t = soc_st == 2 ? alpha0 : alpha;   // (a corrected step is tested with the length of the step it corrects)
+            const bool ftype = dphi < 0 && th0 <= th_min && a_t * mmpc_powf(-dphi, 2.3f) > mmpc_powf(th0, 1.1f);
             bool accepted = false, augment = false;
             if (okf) {
-                if (ftype) accepted = phi <= phi0 + 1e-8 * alpha * dphi + 1e-14 * fabs(phi0);
+                if (ftype) accepted = phi <= phi0 + 1e-8 * a_t * dphi + 1e-14 * fabs(phi0);
                 else if (th <= (1 - 1e-5) * th0 || phi <= phi0 - 1e-5 * th0) { accepted = true; augment = true; }
             }
             if (augment) {
@@ -904,6 +989,28 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                 if (lane == 0) { FILT[2 * slot] = (1 - 1e-5) * th0; FILT[2 * slot + 1] = phi0 - 1e-5 * th0; }
                 LANES_END
             }
+            if (soc_st == 2) {
+                if (accepted) { soc_st = 0; alpha = a_soc; }
+                else if (th > 0.99 * th_prev || soc_p + 1 >= MMPC_SOC_MAX) {
+                    // the correction failed: back to x_k, the uncorrected direction restored, evaluated there again (state 3)
+                    apply_step(-a_soc, false);
+                    soc_dir(false);
+                    soc_st = 3; in_ls = 0;
+                    continue;
+                } else {
+                    soc_rows(false, false);
+                    apply_step(-a_soc, false);
+                    soc_p++; a_prev = a_soc; th_prev = th; soc_st = 1; in_ls = 0;
+                    continue;
+                }
+            } else if (!accepted && MMPC_SOC_MAX > 0 && lsi == 0 && lspass == 0 && io.soc && th >= th0 && th0 <= th_min) {
+                // first trial rejected without reducing the infeasibility, theta(x_k) <= theta_min: second-order correction
+                soc_dir(true);
+                soc_rows(false, false);
+                apply_step(-alpha, false);
+                alpha0 = alpha; a_prev = alpha; th_prev = th; soc_p = 0; soc_st = 1; in_ls = 0;
+                continue;
+            }
             if (!accepted) {
                 double anext = alpha;
                 bool retry = false;
@@ -912,14 +1019,19 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                 if (retry) { apply_step(anext - alpha, false); alpha = anext; continue; }
             }
             in_ls = 0;   // accepted (or every trial rejected: the last one is kept, as IPOPT without restoration would stall too)
-            mmpc_prox_update(alpha, prox, nsmall);
+            mmpc_prox_update(ap, alpha, prox, nsmall);
             MMPC_TS(12)
         }
-        double sd = zsum * inv_rows;
+        if (soc_st == 1) soc_rows(true, soc_p == 0);
+        if (soc_st == 0) {
+        // IPOPT's termination test (Waechter & Biegler 2006, eq. 5-6): stationarity over s_d (all multipliers), complementarity over
+        // s_c (the row multipliers alone)
+        double sd = (zsum + zeq_c) * inv_rows, sc = zsum * inv_nrows;
         sd = (sd > 100.0 ? sd : 100.0) * 0.01;
-        const double isd = mmpc_rcp(sd);
-        E0 = mmpc_vmax(mmpc_vmax(err_d * isd, err_p), tzmax * isd);
-        if (!mmpc_finite(E0) || !mmpc_finite(th_c + cost_c + zsum)) {   // NaN or inf anywhere in the point or its data (the sums carry them)
+        sc = (sc > 100.0 ? sc : 100.0) * 0.01;
+        const double isd = mmpc_rcp(sd), isc = mmpc_rcp(sc);
+        E0 = mmpc_vmax(mmpc_vmax(err_d * isd, err_p), tzmax * isc);
+        if (!mmpc_finite(E0) || !mmpc_finite(th_c + cost_c + zsum + zeq_c)) {   // NaN or inf anywhere in the point or its data (the sums carry them)
 #ifdef MMPC_EMU_DEBUG
             fprintf(stderr, "E0 nan it %d: err_d %g err_p %g tzmax %g tzmin %g zsum %g sumlog %g\n", it, err_d, err_p, tzmax, tzmin, zsum, sumlog);
 #endif
@@ -946,7 +1058,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
             for (int i = 0; i < 4; i++) { q[2 * NPASS + 2 * MCS + i] = ls.st[i]; q[2 * NPASS + 2 * MCS + 4 + i] = ls.sz[i]; }
             if (lane == 0) {
                 st_scal[0] = mu; st_scal[1] = th_max; st_scal[2] = th_min; st_scal[3] = prox;
-                st_scal[4] = (double)it; st_scal[5] = (double)nfilt; st_scal[6] = (double)filt_init; st_scal[7] = (double)nsmall;
+                st_scal[4] = (double)it; st_scal[5] = (double)nfilt; st_scal[6] = (double)filt_init; st_scal[7] = (double)nsmall; st_scal[8] = delta_last;
             }
             LANES_END
             status = 3;   // MMPC_STATUS_SUSPENDED
@@ -956,7 +1068,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
             bool changed = false;
             for (;;) {
                 const double compmu = mmpc_vmax(fabs(tzmax - mu), fabs(tzmin - mu));
-                const double Emu = mmpc_vmax(mmpc_vmax(err_d * isd, err_p), compmu * isd);
+                const double Emu = mmpc_vmax(mmpc_vmax(err_d * isd, err_p), compmu * isc);
                 if (!(Emu <= 10.0 * mu && mu > tol / 10)) break;
                 mu = mmpc_vmax(tol / 10, mmpc_vmin(0.2 * mu, mu * sqrt(mu)));
                 changed = true;
@@ -965,18 +1077,23 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
         }
         phi0 = cost_c - mu * sumlog;   // barrier objective at the current point for the (possibly new) mu
         th0 = th_c;
+        }   // soc_st == 0
 
         MMPC_TS(2)
         // ============================================================ Newton direction
         int failed = 0;
+        double dw = 0.0;
+        if (soc_st != 3) {   // (after a failed correction only the row steps D2 are formed again: the direction is back from io.soc)
 #pragma unroll 1
-        // (Hessian ladder: exact, exact without the curvature of the dynamics, Gauss-Newton - see mmpc_core.h)
-        for (int attempt = 0; attempt < 3; attempt++) {
-            const bool exact = attempt <= 1, dyn_curv = attempt == 0;
-            const double reg = prox;
+        // (exact Lagrangian Hessian, + delta_w I by IPOPT's inertia correction where a pivot of the recursion is not positive - see mmpc_core.h)
+        for (;;) {
+            constexpr bool exact = true, dyn_curv = true;
+            const double reg = prox + dw;
             int ric_bad = 0;   // a pivot of this pass was not positive (every lane factorises the same matrix: uniform)
             // ---- A1 (circle rows where RG lanes share a stage): w g g^T (+ exact curvature), gradient and s_k coupling of the
             //      lane's rows: cp = (Hxx, Hxy, Hyy, qx, qy, h_ss, g_ss, vx, vy)
+            auto a1_rows = [&](auto TAG) {
+            constexpr bool socm = decltype(TAG)::value; (void)socm;
             if (RG > 1 && M > 0) {
                 LANES_BEGIN
                 auto &ls = MMPC_LS;
@@ -996,7 +1113,9 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                             const double ddx = px - ob[3 * r], ddy = py - ob[3 * r + 1], m2 = ddx * ddx + ddy * ddy, id = mmpc_rsqrt(m2), d = m2 * id;
                             const double g0 = -ddx * id, g1 = -ddy * id, hv = (ob[3 * r + 2] + MMPC_BASE_R) - d - sk;
                             const double t = ls.ct[r], z = ls.cz[r], it_ = mmpc_rcp(t), w = z * it_;
-                            const double zh = mu * it_ + w * (hv + t);
+                            double res = hv + t;
+                            if constexpr (socm) res = io.soc[O_AR + rk * NRS + rs + RG * r];   // corrected pass: (h + t)_soc
+                            const double zh = mu * it_ + w * res;
                             cp[0] += w * g0 * g0; cp[1] += w * g1 * g0; cp[2] += w * g1 * g1;
                             if (exact) { const double zi = z * id; cp[0] -= zi * (1 - g0 * g0); cp[1] += zi * g0 * g1; cp[2] -= zi * (1 - g1 * g1); }
                             cp[3] += g0 * zh; cp[4] += g1 * zh;
@@ -1013,7 +1132,11 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                 for (int q = 0; q < 9; q++) ls.cp[q] = cp[q];
                 LANES_END
             }
+            };
+            if (soc_st == 1) a1_rows(MmpcTag<true>{}); else a1_rows(MmpcTag<false>{});
             // ---- A1 (stage lanes): stage Hessian incl. elimination of s_k
+            auto a1_stage = [&](auto TAG) {
+            constexpr bool socm = decltype(TAG)::value; (void)socm;
             LANES_BEGIN
             auto &ls = MMPC_LS;
             if (lane < NS) {
@@ -1067,7 +1190,9 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                     const double ddx = px - o[0], ddy = py - o[1], m2 = ddx * ddx + ddy * ddy, id = mmpc_rsqrt(m2), d = m2 * id;
                     const double g0 = -ddx * id, g1 = -ddy * id, hv = (o[2] + MMPC_BASE_R) - d - sk;
                     const double t = ls.ct[m], z = ls.cz[m], it_ = mmpc_rcp(t), w = z * it_;
-                    const double zh = mu * it_ + w * (hv + t);
+                    double res = hv + t;
+                    if constexpr (socm) res = io.soc[O_AR + k * NRS + m];   // corrected pass: (h + t)_soc
+                    const double zh = mu * it_ + w * res;
                     hxx[0] += w * g0 * g0; hxx[1] += w * g1 * g0; hxx[2] += w * g1 * g1;
                     if (exact) { const double zi = z * id; hxx[0] -= zi * (1 - g0 * g0); hxx[1] += zi * g0 * g1; hxx[2] -= zi * (1 - g1 * g1); }
                     qx[0] += g0 * zh; qx[1] += g1 * zh;
@@ -1079,7 +1204,9 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                         double g6[6];
                         const double hv = mmpc_self_row(i, px, py, cs, sn, dr, dz, g6) - sks;
                         const double t = ls.st[i], z = ls.sz[i], it_ = mmpc_rcp(t), w = z * it_;
-                        const double zh = mu * it_ + w * (hv + t);
+                        double res = hv + t;
+                        if constexpr (socm) res = io.soc[O_AR + k * NRS + M + i];
+                        const double zh = mu * it_ + w * res;
                         // (the terminal stage's self rows belong to s_{N-1}, quirk Q1: they do not enter this lane's s_k block)
                         const double wk = k < N ? w : 0.0, zhk = k < N ? zh : 0.0;
 #pragma unroll
@@ -1155,6 +1282,8 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                 for (int c = 0; c < NU; c++) HUUD[k * NU + c] = CST[MMPC_C_RW2 + c * NU + c] + reg;
             }
             LANES_END
+            };
+            if (soc_st == 1) a1_stage(MmpcTag<true>{}); else a1_stage(MmpcTag<false>{});
             if (NSELF) {
                 // ---- dense rank-one blocks of stage N-1 (the elimination of s_{N-1} reaches x_N through the dynamics):
                 //      Hxx -= a a^T/h, Hux = -b a^T/h, Huu = -b b^T/h, q += (a; b) gamma/h
@@ -1308,21 +1437,17 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                 LANES_END
             }
             if (ric_bad) failed = 1;
-            if (!failed) break;
-            if (attempt == 2) {
-                // even the Gauss-Newton pass lost a pivot: round-off of the recursion under barrier weights z/t ~ 1e9 and
-                // more.  Same remedy as for crawling iterations - the proximal term, raised until the pass goes through
-                if (prox >= MMPC_PROX_MAX) break;
-                prox = mmpc_vmin(MMPC_PROX_MAX, mmpc_vmax(MMPC_PROX0, 4.0 * prox));
-                attempt = 1;
-            }
+            if (!failed) { if (dw > 0.0) delta_last = dw; break; }
+            dw = dw == 0.0 ? (delta_last == 0.0 ? MMPC_IC_D0 : mmpc_vmax(1e-20, MMPC_IC_DN * delta_last)) : MMPC_IC_UP * dw;
+            if (dw > 1e40) break;
             failed = 0;
         }
         if (failed) {
 #ifdef MMPC_EMU_DEBUG
             fprintf(stderr, "riccati failed twice it %d\n", it);
 #endif
-            status = 2; break; }
+            status = 2; fatal = 1; }
+        if (!fatal) {
         // ---- gains of all stages from the normalised pivot rows, by back-substitution over the inputs (the last eliminated
         //      input depends on x only): K_a = -(w_a[x,1] + sum_{b>a} w_a[u_b] K_b), in place, one lane per (stage, column)
         if (GK) MMPC_GFENCE();   // the legs' stores to the gain block are read by other lanes
@@ -1530,9 +1655,14 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
             if (k == N) { for (int c = 0; c < NU; c++) DXU[N * NV + NX + c] = 0.0; }
         }
         LANES_END
+        }   // !fatal
+        }   // soc_st != 3
+        if (fatal) break;
         MMPC_TS(10)
         // ---- D2: row steps, fraction-to-boundary, directional derivative
         const double tau = mmpc_vmax(0.99, 1.0 - mu);
+        auto d2_rows = [&](auto TAG) {
+        constexpr bool socm = decltype(TAG)::value; (void)socm;
         LANES_BEGIN
         auto &ls = MMPC_LS;
         // fraction to the boundary without divisions or branches: alpha = min(1, tau / max_i(-dt_i / t_i)) (1/t_i is at hand),
@@ -1556,7 +1686,9 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                         const double hv = (ob[3 * r + 2] + MMPC_BASE_R) - d - sk;
                         const double t = ls.ct[r], z = ls.cz[r];
                         const double jd = -(ddx * dx0 + ddy * dx1) * id - dsk;
-                        const double dtv = -(hv + t) - jd, it_ = mmpc_rcp(t), dzv = mu * it_ - z - z * it_ * dtv;
+                        double res = hv + t;
+                        if constexpr (socm) res = io.soc[O_AR + rk * NRS + rs + RG * r];
+                        const double dtv = -res - jd, it_ = mmpc_rcp(t), dzv = mu * it_ - z - z * it_ * dtv;
                         ls.cdt[r] = dtv;
                         rp = mmpc_vmax(rp, -dtv * it_);
                         rd = mmpc_vmax(rd, -dzv * mmpc_rcp(z));
@@ -1579,7 +1711,9 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                 const double hv = (ob[3 * m + 2] + MMPC_BASE_R) - d - sk;
                 const double t = ls.ct[m], z = ls.cz[m];
                 const double jd = -(ddx * dx[0] + ddy * dx[1]) * id - dsk;
-                const double dtv = -(hv + t) - jd, it_ = mmpc_rcp(t), dzv = mu * it_ - z - z * it_ * dtv;
+                double res = hv + t;
+                if constexpr (socm) res = io.soc[O_AR + k * NRS + m];
+                const double dtv = -res - jd, it_ = mmpc_rcp(t), dzv = mu * it_ - z - z * it_ * dtv;
                 ls.cdt[m] = dtv;
                 rp = mmpc_vmax(rp, -dtv * it_);
                 rd = mmpc_vmax(rd, -dzv * mmpc_rcp(z));
@@ -1600,7 +1734,9 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                 double jd = -dsks;
 #pragma unroll
                 for (int a = 0; a < 6; a++) jd += g6[a] * dx[mmpc_y(a)];
-                const double dtv = -(hv + t) - jd, it_ = mmpc_rcp(t), dzv = mu * it_ - z - z * it_ * dtv;
+                double res = hv + t;
+                if constexpr (socm) res = io.soc[O_AR + k * NRS + M + i];
+                const double dtv = -res - jd, it_ = mmpc_rcp(t), dzv = mu * it_ - z - z * it_ * dtv;
                 ls.sdt[i] = dtv;
                 rp = mmpc_vmax(rp, -dtv * it_);
                 rd = mmpc_vmax(rd, -dzv * mmpc_rcp(z));
@@ -1634,7 +1770,28 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
         }
         MMPC_WR(0) = rp; MMPC_WR(1) = rd; MMPC_WR(2) = dphi;
         LANES_END
-        { const double rp_ = MMPC_RED_MAX(0), rd_ = MMPC_RED_MAX(1); ap = rp_ > tau ? tau * mmpc_rcp(rp_) : 1.0; ad = rd_ > tau ? tau * mmpc_rcp(rd_) : 1.0; dphi = MMPC_RED_SUM(2); }
+        };
+        if (soc_st == 1) d2_rows(MmpcTag<true>{}); else d2_rows(MmpcTag<false>{});
+        {
+            const double rp_ = MMPC_RED_MAX(0), rd_ = MMPC_RED_MAX(1), ap_n = rp_ > tau ? tau * mmpc_rcp(rp_) : 1.0;
+            if (soc_st == 1) {
+                // corrected direction: its primal step from x_k (the multipliers have taken their step; the acceptance test
+                // uses the length and the slope of the step it corrects)
+                a_soc = ap_n;
+                apply_step(a_soc, false);
+                soc_st = 2; in_ls = 1;
+                continue;
+            }
+            ap = ap_n; ad = rd_ > tau ? tau * mmpc_rcp(rd_) : 1.0; dphi = MMPC_RED_SUM(2);
+            if (soc_st == 3) {
+                // the correction failed: the row steps of the uncorrected direction are back in the registers, the line search
+                // goes on with its second trial
+                alpha = 0.5 * ap; lsi = 1; lspass = 0;
+                apply_step(alpha, false);
+                soc_st = 0; in_ls = 1;
+                continue;
+            }
+        }
 
         MMPC_TS(11)
         if (!filt_init) { nfilt = 0; th_max = 1e4 * mmpc_vmax(1.0, th0); th_min = 1e-4 * mmpc_vmax(1.0, th0); filt_init = 1; }

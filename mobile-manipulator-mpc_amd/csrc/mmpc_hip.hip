@@ -19,7 +19,7 @@ __global__ __launch_bounds__(MMPC_WAVE) void mmpc_solve_kernel(
     const double *__restrict__ u_ref, const double *__restrict__ u_last, const double *__restrict__ x_guess,
     const double *__restrict__ obs, double *__restrict__ X, double *__restrict__ U, double *__restrict__ s,
     int *__restrict__ status, int *__restrict__ iters, double *__restrict__ cost, double *__restrict__ err,
-    const int *__restrict__ order) {
+    const int *__restrict__ order, double *__restrict__ soc, int soc_stride) {
     extern __shared__ double lds[];
     typedef MmpcDims<KIND> D;
     if ((int)blockIdx.x >= B) return;
@@ -44,6 +44,7 @@ __global__ __launch_bounds__(MMPC_WAVE) void mmpc_solve_kernel(
     io.cost = cost + b;
     io.err = err + b;
     io.state = nullptr; io.budget = 0; io.resume = 0; io.gscr = nullptr;   // (iteration budgets are a feature of the specialised kernels)
+    io.soc = soc ? soc + (size_t)b * soc_stride : nullptr;
     mmpc_solve_one<KIND, NC, MC, OPSC, LC>(P, io, lds);
 }
 
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(MMPC_WAVE) void mmpc_solve_kernel_static(
     const double *__restrict__ u_ref, const double *__restrict__ u_last, const double *__restrict__ x_guess,
     const double *__restrict__ obs, double *__restrict__ X, double *__restrict__ U, double *__restrict__ s,
     int *__restrict__ status, int *__restrict__ iters, double *__restrict__ cost, double *__restrict__ err,
-    const int *__restrict__ order) {
+    const int *__restrict__ order, double *__restrict__ soc, int soc_stride) {
     typedef MmpcDims<KIND> D;
     constexpr int NHS = (KIND == 0 && LC > 0) ? 6 : 0, NQ = (KIND == 0 && AWC && LC >= 2) ? 6 * (LC - 1) : 0;
     __shared__ double lds[mmpc_layout<KIND>(NC, MC, OPSC, NHS, NQ).total];
@@ -81,6 +82,7 @@ __global__ __launch_bounds__(MMPC_WAVE) void mmpc_solve_kernel_static(
     io.cost = cost + b;
     io.err = err + b;
     io.state = nullptr; io.budget = 0; io.resume = 0; io.gscr = nullptr;
+    io.soc = soc ? soc + (size_t)b * soc_stride : nullptr;
     mmpc_solve_one<KIND, NC, MC, OPSC, LC, AWC>(P, io, lds);
 }
 // (kind, N, M, obs_per_stage, L, as_written): demo_wholebody_qref.py scenario 2 (two planes) as written and with the intended
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(MMPC_WAVE, WPE) void mmpc_fast_kernel(
     const double *__restrict__ obs, double *__restrict__ X, double *__restrict__ U, double *__restrict__ s,
     int *__restrict__ status, int *__restrict__ iters, double *__restrict__ cost, double *__restrict__ err,
     const int *__restrict__ order, int budget, double *__restrict__ state, int state_stride, const int *__restrict__ resume_count,
-    const int *__restrict__ list_count, double *__restrict__ gscr) {
+    const int *__restrict__ list_count, double *__restrict__ gscr, double *__restrict__ soc, int soc_stride) {
 #ifndef MMPC_LDS_PAD
 #define MMPC_LDS_PAD 0     // (experiments: extra doubles of LDS per problem, to lower the number of resident problems per CU)
 #endif
@@ -137,6 +139,7 @@ __global__ __launch_bounds__(MMPC_WAVE, WPE) void mmpc_fast_kernel(
         io.budget = budget;
         io.resume = resume_count ? 1 : 0;
         io.gscr = MmpcGainBlock<KIND, N>::ON ? gscr + (size_t)b * MmpcGainBlock<KIND, N>::total : nullptr;
+        io.soc = soc ? soc + (size_t)b * soc_stride : nullptr;
         mmpc_solve_fast<KIND, N, MC, CONT, OPS>(P, io, lds);
         if (!CONT || !resume_count) break;      // (one instance per workgroup except in a continuation launch)
         __builtin_amdgcn_s_barrier();           // the next instance reuses the LDS block
@@ -285,6 +288,8 @@ struct mmpc_handle_s {
     double *d_state;        // [max_batch][state_doubles], allocated when a budget is first set
     double *d_gscr;         // [max_batch][gscr_doubles]: gain blocks of the specialised kernels of long horizons (MmpcGainBlock), else null
     int gscr_doubles;
+    double *d_soc;          // [max_batch][soc_doubles]: scratch of the second-order correction (mmpc_soc_doubles), every kernel
+    int soc_doubles;
     int *d_list, *d_count;  // compacted list of the suspended instances of the last launch
     int resume_B;           // batch size of the budgeted launch whose suspended instances can still be continued (0: nothing to resume)
     int no_lpt_env, force_generic_env;   // MMPC_NO_LPT / MMPC_FORCE_GENERIC, read once at create (diagnostics)
@@ -467,6 +472,8 @@ extern "C" int mmpc_create(const mmpc_config *cfg, mmpc_handle *out) {
     HIPCHK(h, hipMalloc(&h->d_warm, B * 4));
     HIPCHK(h, hipMalloc(&h->d_key, B * 4));
     if (h->fast && h->gscr_doubles) HIPCHK(h, hipMalloc(&h->d_gscr, B * (size_t)h->gscr_doubles * 8));
+    h->soc_doubles = mmpc_soc_doubles(cfg->N, h->nx, h->nu, L.NR);
+    HIPCHK(h, hipMalloc(&h->d_soc, B * (size_t)h->soc_doubles * 8));
     h->order_B = 0;
     h->hint_on = 1;
     h->no_lpt_env = getenv("MMPC_NO_LPT") != nullptr;
@@ -486,7 +493,7 @@ extern "C" int mmpc_destroy(mmpc_handle h) {
     if (!h) return MMPC_E_ARG;
     void *ptrs[] = {h->dp, h->d_x_init, h->d_traj, h->d_uref, h->d_obs, h->d_ulatest, h->d_xguess, h->d_X, h->d_U,
                     h->d_s, h->d_cost, h->d_err, h->d_u0, h->d_status, h->d_iters, h->d_order, h->d_warm, h->d_key, h->d_state,
-                    h->d_list, h->d_count, h->d_gscr};
+                    h->d_list, h->d_count, h->d_gscr, h->d_soc};
     (void)hipSetDevice(h->cfg.device);
     if (h->ev_valid) (void)hipEventSynchronize(h->ev);
     if (h->ev) (void)hipEventDestroy(h->ev);
@@ -563,11 +570,11 @@ static int launch(mmpc_handle h, int B, const double *x_init, const double *traj
                 hipLaunchKernelGGL((mmpc_fast_kernel<K, NN, MM, WW, true, OPS>), dim3(resume ? (B < MMPC_RESUME_GRID ? B : MMPC_RESUME_GRID) : grid), dim3(MMPC_WAVE), 0, st, h->dp, B, \
                                    x_init, traj, uref, ulast, xguess, obs, X, U, s, status, iters, cost, err, resume ? h->d_list : order, \
                                    resume ? 0 : h->budget, h->d_state, h->state_doubles, resume ? h->d_count : (const int *)nullptr,      \
-                                   resume ? (const int *)nullptr : ucount, h->d_gscr);                                                    \
+                                   resume ? (const int *)nullptr : ucount, h->d_gscr, h->d_soc, h->soc_doubles);                                                    \
             else                                                                                                                       \
                 hipLaunchKernelGGL((mmpc_fast_kernel<K, NN, MM, WW, false, OPS>), dim3(grid), dim3(MMPC_WAVE), 0, st, h->dp, B,           \
                                    x_init, traj, uref, ulast, xguess, obs, X, U, s, status, iters, cost, err, order, 0,                  \
-                                   (double *)nullptr, 0, (const int *)nullptr, ucount, h->d_gscr);
+                                   (double *)nullptr, 0, (const int *)nullptr, ucount, h->d_gscr, h->d_soc, h->soc_doubles);
 #define MMPC_X(K, NN, MM, WW)                                                                                          \
         if (h->cfg.kind == K && h->cfg.N == NN && h->cfg.M == MM) {                                                   \
             if (h->cfg.obs_per_stage) { MMPC_LAUNCH_FAST(K, NN, MM, WW, 1) } else { MMPC_LAUNCH_FAST(K, NN, MM, WW, 0) }   \
@@ -579,18 +586,18 @@ static int launch(mmpc_handle h, int B, const double *x_init, const double *traj
 #define MMPC_X(K, NN, MM, OO, LL, AA)                                                                                \
         if (h->cfg.kind == K && h->cfg.N == NN && h->cfg.M == MM && h->hp.obs_per_stage == OO && h->cfg.L == LL && h->hp.as_written == AA) \
             hipLaunchKernelGGL((mmpc_solve_kernel_static<K, NN, MM, OO, LL, AA>), dim3(B), dim3(MMPC_WAVE), 0, st, h->dp, B, x_init, traj, \
-                               uref, ulast, xguess, obs, X, U, s, status, iters, cost, err, order);
+                               uref, ulast, xguess, obs, X, U, s, status, iters, cost, err, order, h->d_soc, h->soc_doubles);
         MMPC_STATIC_LIST(MMPC_X)
 #undef MMPC_X
     } else if (h->cfg.kind == MMPC_KIND_WHOLEBODY)
         hipLaunchKernelGGL(mmpc_solve_kernel<0>, dim3(B), dim3(MMPC_WAVE), h->lds_bytes, st, h->dp, B, x_init, traj, uref,
-                           ulast, xguess, obs, X, U, s, status, iters, cost, err, order);
+                           ulast, xguess, obs, X, U, s, status, iters, cost, err, order, h->d_soc, h->soc_doubles);
     else if (h->cfg.kind == MMPC_KIND_BASE)
         hipLaunchKernelGGL(mmpc_solve_kernel<1>, dim3(B), dim3(MMPC_WAVE), h->lds_bytes, st, h->dp, B, x_init, traj, uref,
-                           ulast, xguess, obs, X, U, s, status, iters, cost, err, order);
+                           ulast, xguess, obs, X, U, s, status, iters, cost, err, order, h->d_soc, h->soc_doubles);
     else
         hipLaunchKernelGGL(mmpc_solve_kernel<2>, dim3(B), dim3(MMPC_WAVE), h->lds_bytes, st, h->dp, B, x_init, traj, uref,
-                           ulast, xguess, obs, X, U, s, status, iters, cost, err, order);
+                           ulast, xguess, obs, X, U, s, status, iters, cost, err, order, h->d_soc, h->soc_doubles);
     HIPCHK(h, hipGetLastError());
     if (use_fast && h->budget > 0 && !resume) {
         // who is suspended: compacted list for mmpc_resume_batch_device

@@ -47,19 +47,24 @@ class Options:
     piv_frac = 0.0
     nu_lam = 0.0
     filter = True
-    mid_fallback = True     # exact -> exact without dynamics curvature -> Gauss-Newton
-    inertia = False
+    mid_fallback = True     # (round-3 ladder, only with inertia = False) exact -> exact without dynamics curvature -> Gauss-Newton
+    inertia = True          # IPOPT's inertia correction (Waechter & Biegler 2006, Algorithm IC): exact Hessian + delta_w I, delta_w from a
+                            # geometric sequence (delta0, x kappa_first while no correction has succeeded yet, x kappa_up after, the next
+                            # iteration starts from kappa_dn times the last successful value) until every pivot of the recursion is positive
+    kappa_first = 4.0; kappa_up = 4.0; kappa_dn = 1.0 / 3.0
+    soc_max = 2             # second-order corrections per iteration (IPOPT: max_soc = 4), tried when the first trial step is rejected
+                            # without reducing the infeasibility and theta(x_k) <= theta_min (the regime of the switching condition)
     inertia_streak = 0      # >0 (experiment, off: it trades the 600-800-iteration cases for others that take 1300+): inertia correction (exact Hessian + delta I) instead of the Gauss-Newton fallback once the
                             # exact Hessian has failed in this many consecutive iterations (slow linear convergence near saddles)
     slack_reset = False
-    delta0 = 1e-4
+    delta0 = 1.0          # (IPOPT: 1e-4 and x100; the corrections this NLP needs are 1 ... 100)
     delta_min = 1e-20
     delta_max = 1e10
     bound_push = 1e-2
     kappa_sigma = 1e10
     # proximal term for crawling iterations: after two consecutive steps with alpha < prox_lo the Hessian gets + prox I on
     # (x, u) (prox0, then x prox_up per further small step); it is divided by prox_dn after a step with alpha > prox_hi
-    prox = True; prox0 = 100.0; prox_up = 4.0; prox_dn = 4.0; prox_lo = 0.05; prox_hi = 0.5; prox_need = 2; prox_max = 1e4
+    prox = True; prox_on_ap = True; prox0 = 100.0; prox_up = 4.0; prox_dn = 4.0; prox_lo = 0.05; prox_hi = 0.5; prox_need = 2; prox_max = 1e4
     rho_eq = 1e4          # augmentation weight of the terminal-xy equality inside the factorisation
 
 
@@ -258,8 +263,10 @@ def solve(prob: nlp.Problem, U0=None, X0=None, opt: Options = None, verbose=Fals
         compmu = max(np.abs(t[k] * z[k] - mu).max() for k in range(N + 1))
         zsum = sum(z[k].sum() for k in range(N + 1)) + np.abs(lam).sum() + np.abs(nu_eq).sum()
         sd = max(100.0, zsum / (nrows + lam.size)) / 100.0
-        E0 = max(err_d / sd, err_p, comp0 / sd)
-        Emu = max(err_d / sd, err_p, compmu / sd)
+        # IPOPT's scaling of the complementarity (Waechter & Biegler 2006, eq. 5-6): s_c from the row multipliers alone
+        sc = max(100.0, sum(z[k].sum() for k in range(N + 1)) / max(nrows, 1)) / 100.0
+        E0 = max(err_d / sd, err_p, comp0 / sc)
+        Emu = max(err_d / sd, err_p, compmu / sc)
         if history is not None:
             history.append(dict(it=it, mu=mu, E0=E0, Emu=Emu, err_d=err_d, err_p=err_p,
                                 cost=nlp.cost(prob, X, U, s)))
@@ -275,7 +282,7 @@ def solve(prob: nlp.Problem, U0=None, X0=None, opt: Options = None, verbose=Fals
         while Emu <= opt.kappa_eps * mu and mu > opt.tol / 10:
             mu = max(opt.tol / 10, min(opt.kappa_mu * mu, mu ** opt.theta_mu))
             compmu = max(np.abs(t[k] * z[k] - mu).max() for k in range(N + 1))
-            Emu = max(err_d / sd, err_p, compmu / sd)
+            Emu = max(err_d / sd, err_p, compmu / sc)
             changed = True
         if changed:
             nu_merit = 1.0
@@ -370,105 +377,93 @@ def solve(prob: nlp.Problem, U0=None, X0=None, opt: Options = None, verbose=Fals
             return Pm, pv, K, kf, hss, gss, vx, vxN, pvv, kfv
         # (not with the terminal equality: its full correction E dx_N = e is forced whatever the damping, the multipliers
         #  nu then grow like prox)
-        prox = prox_cur if (opt.prox and not p.terminal_xy_equality) else 0.0
-        fac = factor(opt.exact_hessian, prox) if opt.exact_hessian else None
-        nreg = 0
-        nstreak = nstreak + 1 if (fac is None and opt.exact_hessian) else 0
-        if fac is None and opt.exact_hessian and (opt.inertia or (opt.inertia_streak and nstreak >= opt.inertia_streak and not p.terminal_xy_equality)):
-            # IPOPT-style inertia correction: exact Hessian + delta*I, delta growing until the
-            # stage-wise factorisation has only positive pivots
-            delta = opt.delta0 if delta_last == 0.0 else max(opt.delta_min, delta_last / 3.0)
-            while fac is None and delta <= opt.delta_max:
-                nreg += 1
-                fac = factor(True, delta)
-                if fac is None:
-                    delta = delta * (100.0 if delta_last == 0.0 else 8.0)
-            if fac is not None:
-                delta_last = delta
-        if fac is None and opt.exact_hessian and opt.mid_fallback and not p.terminal_xy_equality and \
-                (prob.hs is None or len(prob.hs) == 0):
-            # middle rung of the fallback ladder: the exact Hessian without the curvature of the dynamics (lam^T d2f).  Plain
-            # Gauss-Newton steps also drop the curvature of the constraint rows and overshoot where that is large: full
-            # steps that zig-zag for hundreds of iterations next to a saddle.  (Not with half-space rows or the terminal
-            # equality: there the rung passes the pivot test with directions the line search cuts to nothing.)
-            nreg += 1
-            fac = factor(True, prox, dyn_curv=False)
-        if fac is None:
-            nreg += 1 if opt.exact_hessian else 0
-            fac = factor(False, prox)
-            # if even the Gauss-Newton pass loses a pivot (round-off under huge barrier weights) the proximal term is raised
-            # until the pass goes through (not with the terminal equality, where it is off)
-            while fac is None and opt.prox and not p.terminal_xy_equality and prox_cur < opt.prox_max:
-                prox_cur = min(opt.prox_max, max(opt.prox0, prox_cur * opt.prox_up))
-                prox = prox_cur
-                fac = factor(False, prox)
+        def newton():
+            """factorisation of the Newton matrix: exact Hessian, inertia-corrected where a pivot fails (or the round-3 ladder)"""
+            nonlocal delta_last, prox_cur
+            prox = prox_cur if (opt.prox and not p.terminal_xy_equality) else 0.0
+            fac = factor(opt.exact_hessian, prox) if opt.exact_hessian else None
+            if fac is None and opt.exact_hessian and opt.inertia and not p.terminal_xy_equality:
+                delta = opt.delta0 if delta_last == 0.0 else max(opt.delta_min, delta_last * opt.kappa_dn)
+                while True:
+                    fac = factor(True, prox + delta)
+                    if fac is not None or delta > 1e40:
+                        break
+                    delta = delta * (opt.kappa_first if delta_last == 0.0 else opt.kappa_up)
+                if fac is not None:
+                    delta_last = delta
+                return fac
+            if fac is None and opt.exact_hessian and opt.mid_fallback and not p.terminal_xy_equality and \
+                    (prob.hs is None or len(prob.hs) == 0):
+                fac = factor(True, prox, dyn_curv=False)
             if fac is None:
-                status = 2
-                break
-        Pm, pv, K, kf, hss, gss, vx, vxN, pvv, kfv = fac
-        nu_new = np.zeros(2)
-        if p.terminal_xy_equality:
-            # interface_wholebody_qref.py:166-167: X[N,:2] == X_ref[N,:2].  The two multipliers enter the terminal
-            # gradient linearly, so the direction is affine in them: roll out the nu = 0 solution and the two
-            # sensitivities with the SAME feedback gains, then solve the 2x2 system E dx_N = e.
-            d0 = np.zeros(nx); Dv = np.zeros((nx, 2))
+                fac = factor(False, prox)
+                while fac is None and opt.prox and not p.terminal_xy_equality and prox_cur < opt.prox_max:
+                    prox_cur = min(opt.prox_max, max(opt.prox0, prox_cur * opt.prox_up))
+                    fac = factor(False, prox_cur)
+            return fac
+
+        def direction(fac):
+            """search direction from a factorisation: roll-out, multiplier and row steps, fraction to the boundary"""
+            Pm, pv, K, kf, hss, gss, vx, vxN, pvv, kfv = fac
+            nu_new = np.zeros(2)
+            if p.terminal_xy_equality:
+                # interface_wholebody_qref.py:166-167: X[N,:2] == X_ref[N,:2].  The two multipliers enter the terminal
+                # gradient linearly, so the direction is affine in them: roll out the nu = 0 solution and the two
+                # sensitivities with the SAME feedback gains, then solve the 2x2 system E dx_N = e.
+                d0 = np.zeros(nx); Dv = np.zeros((nx, 2))
+                for k in range(N):
+                    A, B = AB[k]
+                    u0 = K[k] @ d0 + kf[k]; Uv = K[k] @ Dv + kfv[k]
+                    d0 = A @ d0 + B @ u0 + c[k]; Dv = A @ Dv + B @ Uv
+                e = prob.traj_ref[N, :2] - X[N, :2]
+                nu_new = np.linalg.solve(Dv[:2, :], e - d0[:2])
+                kf = [kf[k] + kfv[k] @ nu_new for k in range(N)]
+            dX = np.zeros_like(X); dU = np.zeros_like(U)
+            dX[0] = prob.x_init - X[0]
             for k in range(N):
                 A, B = AB[k]
-                u0 = K[k] @ d0 + kf[k]; Uv = K[k] @ Dv + kfv[k]
-                d0 = A @ d0 + B @ u0 + c[k]; Dv = A @ Dv + B @ Uv
-            e = prob.traj_ref[N, :2] - X[N, :2]
-            nu_new = np.linalg.solve(Dv[:2, :], e - d0[:2])
-            kf = [kf[k] + kfv[k] @ nu_new for k in range(N)]
-        dX = np.zeros_like(X); dU = np.zeros_like(U)
-        dX[0] = prob.x_init - X[0]
-        for k in range(N):
-            A, B = AB[k]
-            dU[k] = K[k] @ dX[k] + kf[k]
-            dX[k + 1] = A @ dX[k] + B @ dU[k] + c[k]
-        lam_new = np.zeros_like(lam)
-        for k in range(1, N + 1):
-            lam_new[k] = -(Pm[k] @ dX[k] + pv[k] + pvv[k] @ nu_new)
-        # ---------------- recover ds, dt, dz ------------------------------
-        ds = np.zeros(N + 1)
-        for k in range(N + 1):
-            vdx = vx[k] @ dX[k]
-            if k == N - 1:
-                vdx += vxN @ dX[N]
-            ds[k] = -(gss[k] - vdx) / hss[k]
+                dU[k] = K[k] @ dX[k] + kf[k]
+                dX[k + 1] = A @ dX[k] + B @ dU[k] + c[k]
+            lam_new = np.zeros_like(lam)
+            for k in range(1, N + 1):
+                lam_new[k] = -(Pm[k] @ dX[k] + pv[k] + pvv[k] @ nu_new)
+            ds = np.zeros(N + 1)
+            for k in range(N + 1):
+                vdx = vx[k] @ dX[k]
+                if k == N - 1:
+                    vdx += vxN @ dX[N]
+                ds[k] = -(gss[k] - vdx) / hss[k]
+            dt = [None] * (N + 1); dz = [None] * (N + 1)
+            for k in range(N + 1):
+                dtk = np.zeros(len(rows[k])); dzk = np.zeros(len(rows[k]))
+                for i, (h, jx, ju, ks, Hr) in enumerate(ev[k]):
+                    jd = 0.0
+                    if jx is not None: jd += jx @ dX[k]
+                    if ju is not None: jd += ju @ dU[k]
+                    if ks is not None: jd -= ds[ks]
+                    dtk[i] = -rh[k][i] - jd
+                    w = z[k][i] / t[k][i]
+                    dzk[i] = mu / t[k][i] - z[k][i] - w * dtk[i]
+                dt[k] = dtk; dz[k] = dzk
+            tau = max(opt.tau_min, 1 - mu)
+            ap = 1.0; ad = 1.0
+            for k in range(N + 1):
+                neg = dt[k] < 0
+                if neg.any():
+                    ap = min(ap, (-tau * t[k][neg] / dt[k][neg]).min())
+                neg = dz[k] < 0
+                if neg.any():
+                    ad = min(ad, (-tau * z[k][neg] / dz[k][neg]).min())
+            return dX, dU, ds, lam_new, nu_new, dt, dz, ap, ad
+
+        fac = newton()
+        if fac is None:
+            status = 2
+            break
+        dX, dU, ds, lam_new, nu_new, dt, dz, ap, ad = direction(fac)
         if getattr(opt, "dense_check", False):
             _dense_check(prob, rows, ev, X, U, s, t, z, lam, mu, c, AB, gX, gU, gs, rh, dX, dU, ds, lam_new, opt,
                          Q2, P2, RW2)
-        dt = [None] * (N + 1); dz = [None] * (N + 1)
-        for k in range(N + 1):
-            dtk = np.zeros(len(rows[k])); dzk = np.zeros(len(rows[k]))
-            for i, (h, jx, ju, ks, Hr) in enumerate(ev[k]):
-                jd = 0.0
-                if jx is not None: jd += jx @ dX[k]
-                if ju is not None: jd += ju @ dU[k]
-                if ks is not None: jd -= ds[ks]
-                dtk[i] = -rh[k][i] - jd
-                w = z[k][i] / t[k][i]
-                dzk[i] = mu / t[k][i] - z[k][i] - w * dtk[i]
-            dt[k] = dtk; dz[k] = dzk
-        # ---------------- step lengths ------------------------------------
-        tau = max(opt.tau_min, 1 - mu)
-        ap = 1.0; ad = 1.0
-        for k in range(N + 1):
-            neg = dt[k] < 0
-            if neg.any():
-                ap = min(ap, (-tau * t[k][neg] / dt[k][neg]).min())
-            neg = dz[k] < 0
-            if neg.any():
-                ad = min(ad, (-tau * z[k][neg] / dz[k][neg]).min())
-        if getattr(opt, "debug_block", False):
-            best = (2.0, None)
-            for k in range(N + 1):
-                for i in range(len(rows[k])):
-                    if dt[k][i] < 0:
-                        a = -tau * t[k][i] / dt[k][i]
-                        if a < best[0]:
-                            best = (a, (k, rows[k][i][0], rows[k][i][1], t[k][i], z[k][i], dt[k][i], ev[k][i][0]))
-            print("      block:", best)
         # ---------------- line search -------------------------------------
         phi0, th0 = _merit_parts(prob, rows, X, U, s, t, mu)
         dphi = (gX * dX).sum() + (gU * dU).sum() + gs @ ds
@@ -476,28 +471,66 @@ def solve(prob: nlp.Problem, U0=None, X0=None, opt: Options = None, verbose=Fals
             dphi -= mu * (dt[k] / t[k]).sum()
         alpha = ap
         accepted = False
+        z_done = False
         if opt.filter:
             if filt is None:
                 filt = []
                 th_max = 1e4 * max(1.0, th0)
                 th_min = 1e-4 * max(1.0, th0)
+            def acceptable(th, phi, a0):
+                """filter and sufficient-decrease test of a trial point; a0: the step length of the switching / Armijo conditions"""
+                ok_f = th < th_max and all(not (th >= fj[0] and phi >= fj[1]) for fj in filt)
+                ftype = (dphi < 0 and th0 <= th_min and a0 * (-dphi) ** 2.3 > th0 ** 1.1)
+                if ok_f:
+                    if ftype:
+                        return phi <= phi0 + 1e-8 * a0 * dphi + 1e-14 * abs(phi0)
+                    if th <= (1 - 1e-5) * th0 or phi <= phi0 - 1e-5 * th0:
+                        _filter_add(filt, ((1 - 1e-5) * th0, phi0 - 1e-5 * th0))
+                        return True
+                return False
             for lspass in range(2):
                 alpha = ap
                 for ls in range(opt.max_ls):
                     Xn = X + alpha * dX; Un = U + alpha * dU; sn = s + alpha * ds
                     tn = [t[k] + alpha * dt[k] for k in range(N + 1)]
                     phi, th = _merit_parts(prob, rows, Xn, Un, sn, tn, mu)
-                    ok_f = th < th_max and all(not (th >= fj[0] and phi >= fj[1]) for fj in filt)
-                    ftype = (dphi < 0 and th0 <= th_min and alpha * (-dphi) ** 2.3 > th0 ** 1.1)
-                    if ok_f:
-                        if ftype:
-                            if phi <= phi0 + 1e-8 * alpha * dphi + 1e-14 * abs(phi0):
-                                accepted = True
+                    if acceptable(th, phi, alpha):
+                        accepted = True
+                        break
+                    if ls == 0 and lspass == 0 and opt.soc_max > 0 and th >= th0 and th0 <= th_min and not p.terminal_xy_equality:
+                        # second-order correction (Waechter & Biegler 2006, section 2.4; see oracle/mmpc_oracle.c): the row
+                        # multipliers take their step first, then the direction is recomputed from x_k with
+                        # c_soc = alpha c(x_k) + c(x_k + alpha d) in place of the constraint residuals
+                        for k in range(N + 1):
+                            z[k] = z[k] + ad * dz[k]
+                            z[k] = np.minimum(np.maximum(z[k], mu / (opt.kappa_sigma * tn[k])), opt.kappa_sigma * mu / tn[k])
+                        z_done = True
+                        keep = (dX, dU, ds, lam_new, nu_new, dt, c, rh)
+                        accC = c.copy(); accR = [r.copy() for r in rh]
+                        a_prev, th_prev, alpha0 = alpha, th, alpha
+                        for _ in range(opt.soc_max):
+                            evn = _eval_all(prob, rows, Xn, Un, sn, 0)
+                            accC = a_prev * accC + _defects(prob, Xn, Un)
+                            accR = [a_prev * accR[k] + np.array([e[0] for e in evn[k]]) + tn[k] for k in range(N + 1)]
+                            c = accC; rh = accR
+                            fac2 = newton()
+                            if fac2 is None:
                                 break
-                        elif th <= (1 - 1e-5) * th0 or phi <= phi0 - 1e-5 * th0:
-                            accepted = True
-                            _filter_add(filt, ((1 - 1e-5) * th0, phi0 - 1e-5 * th0))
+                            dX, dU, ds, lam_new, nu_new, dt, dz2, ap2, ad2 = direction(fac2)
+                            Xn = X + ap2 * dX; Un = U + ap2 * dU; sn = s + ap2 * ds
+                            tn = [t[k] + ap2 * dt[k] for k in range(N + 1)]
+                            phi2, th2 = _merit_parts(prob, rows, Xn, Un, sn, tn, mu)
+                            if acceptable(th2, phi2, alpha0):
+                                accepted = True
+                                alpha = ap2
+                                break
+                            if th2 > 0.99 * th_prev:
+                                break
+                            a_prev, th_prev = ap2, th2
+                        c, rh = keep[6], keep[7]
+                        if accepted:
                             break
+                        dX, dU, ds, lam_new, nu_new, dt = keep[:6]      # the line search goes on along the uncorrected direction
                     if ls < opt.max_ls - 1:
                         alpha *= 0.5
                 if accepted or not filt:
@@ -522,18 +555,20 @@ def solve(prob: nlp.Problem, U0=None, X0=None, opt: Options = None, verbose=Fals
                 alpha *= 0.5
         nfail += (not accepted)
         if opt.prox:
-            nsmall = nsmall + 1 if alpha < opt.prox_lo else 0
-            if alpha < opt.prox_lo and (nsmall >= opt.prox_need or prox_cur > 0.0):
+            a_px = ap if opt.prox_on_ap else alpha    # (the crawl the term is for is the one the fraction-to-boundary rule causes)
+            nsmall = nsmall + 1 if a_px < opt.prox_lo else 0
+            if a_px < opt.prox_lo and (nsmall >= opt.prox_need or prox_cur > 0.0):
                 prox_cur = min(opt.prox_max, max(opt.prox0, prox_cur * opt.prox_up))
             elif alpha > opt.prox_hi:
                 prox_cur = prox_cur / opt.prox_dn if prox_cur > opt.prox0 * 1e-3 else 0.0
         if verbose:
-            print(f"      ap {ap:.3f} ad {ad:.3f} alpha {alpha:.4f} ls {ls} nreg {nreg} nu {nu_merit:.2e} dm {dm:.3e}")
+            print(f"      ap {ap:.3f} ad {ad:.3f} alpha {alpha:.4f} ls {ls} nu {nu_merit:.2e} dm {dm:.3e}")
         X = X + alpha * dX; U = U + alpha * dU; s = s + alpha * ds
         X[0] = prob.x_init
         for k in range(N + 1):
             t[k] = t[k] + alpha * dt[k]
-            z[k] = z[k] + ad * dz[k]
+            if not z_done:
+                z[k] = z[k] + ad * dz[k]
         lam = lam + alpha * (lam_new - lam)
         nu_eq = nu_eq + alpha * (nu_new - nu_eq)
     return dict(X=X, U=U, s=s, status=status, iters=it, cost=nlp.cost(prob, X, U, s), E0=E0,

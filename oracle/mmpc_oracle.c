@@ -43,6 +43,16 @@
 #define KAPPA_SIGMA 1e10
 #define RHO_EQ 1e4     /* augmentation weight of the terminal-xy equality inside the factorisation */
 
+/* experiment knobs (tools / tests only; the defaults are the algorithm the kernels implement) */
+/* [0] complementarity scaled by s_c (1) or s_d (0) | [1] inertia correction (1) or the round-3 Hessian ladder (0) | [2] second-order
+ * corrections per iteration | [3] 1: no proximal term | [6..9] inertia correction: first delta, first growth, growth, decay |
+ * [18] proximal trigger on the fraction-to-boundary step (1) or on the accepted step (0) | [20] second-order correction only where
+ * theta(x_k) <= [20] theta_min (0: always) */
+static double LAB[32] = {1, 1, 2, 0, 0, 0, 1, 4, 4, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 1};
+static long long LAB_NFACT = 0, LAB_NSOC = 0, LAB_NSOCOK = 0, LAB_NSOCFAIL = 0, LAB_DH[20] = {0};
+void mmpc_oracle_set_lab(int i, double v) { if (i >= 0 && i < 32) LAB[i] = v; }
+double mmpc_oracle_get_lab(int i) { return i >= 200 && i < 220 ? (double)LAB_DH[i - 200] : i == 100 ? (double)LAB_NFACT : i == 101 ? (double)LAB_NSOC : i == 102 ? (double)LAB_NSOCOK : i == 103 ? (double)LAB_NSOCFAIL : (i >= 0 && i < 32 ? LAB[i] : 0.0); }
+
 typedef struct {
     int kind;            /* 0 whole-body (nx=9,nu=5), 1 base-only (nx=6,nu=2) */
     int N, M;
@@ -242,6 +252,7 @@ typedef struct {
     double dX[NSM][NXM], dU[NSM][NUM], ds[NSM], lamn[NSM][NXM];
     double dt_[NSM][RMX], dz[NSM][RMX];
     double Q2[NXM][NXM], P2[NXM][NXM], RW2[NUM][NUM];
+    int dbg_k, dbg_r; double dbg_t, dbg_dt, dbg_z;
 } work;
 
 static const double *obs_at(const work *w, int k, int m) {
@@ -455,6 +466,7 @@ static void chol_solve(double L[NUM][NUM], int n, double *b) {
  * without); 0: Gauss-Newton */
 static int factor(work *w, double mu, int use_exact, double prox) {
     const oracle_cfg *c = w->cfg;
+    __atomic_fetch_add(&LAB_NFACT, 1, __ATOMIC_RELAXED);
     int nx = w->nx, nu = w->nu, N = w->N;
     for (int k = 0; k <= N; k++) { w->hss[k] = 2 * c->S; w->gss[k] = w->gs[k]; memset(w->vx[k], 0, sizeof(w->vx[k])); memset(w->vq[k], 0, sizeof(w->vq[k])); }
     memset(w->vxN, 0, sizeof(w->vxN));
@@ -654,7 +666,115 @@ static int factor(work *w, double mu, int use_exact, double prox) {
     return 1;
 }
 
+/* Newton direction from the factorisation in w (gains, cost-to-go): border solve, roll-out, multiplier and row steps,
+ * fraction to the boundary; outputs the primal / dual step bounds and the directional derivative of the barrier objective */
+static void direction(work *w, double mu, double *ap_out, double *ad_out, double *dphi_out) {
+    const oracle_cfg *cfg = w->cfg;
+    const int nx = w->nx, nu = w->nu, N = w->N;
+    w->nu_new[0] = w->nu_new[1] = 0; w->dsig = 0;
+    if (cfg->terminal_xy_eq || w->sig) {
+        /* the direction is affine in the border variables y = (nu0, nu1, dsigma): roll out the y = 0 solution and the
+         * sensitivities (same gains), then the small system
+         *   E (dx_N + D y) = e                        (terminal equality)
+         *   h dsigma - v~.(d + D y) = -g_s            (stationarity in s_{N-1}) */
+        static __thread double d0[NSM][NXM], Dv[NSM][NXM][2];
+        memset(d0, 0, sizeof(d0)); memset(Dv, 0, sizeof(Dv));
+        for (int k = 0; k < N; k++) {
+            double u0[NUM], Uv[NUM][2];
+            for (int i = 0; i < nu; i++) {
+                double v = w->kf[k][i], v0 = w->kfv[k][i][0], v1 = w->kfv[k][i][1];
+                for (int j = 0; j < nx; j++) { v += w->K[k][i][j] * d0[k][j]; v0 += w->K[k][i][j] * Dv[k][j][0]; v1 += w->K[k][i][j] * Dv[k][j][1]; }
+                u0[i] = v; Uv[i][0] = v0; Uv[i][1] = v1;
+            }
+            for (int i = 0; i < nx; i++) {
+                double v = w->c[k][i], v0 = 0, v1 = 0;
+                for (int j = 0; j < nx; j++) { v += w->A[k][i][j] * d0[k][j]; v0 += w->A[k][i][j] * Dv[k][j][0]; v1 += w->A[k][i][j] * Dv[k][j][1]; }
+                for (int j = 0; j < nu; j++) { v += w->B[k][i][j] * u0[j]; v0 += w->B[k][i][j] * Uv[j][0]; v1 += w->B[k][i][j] * Uv[j][1]; }
+                d0[k + 1][i] = v; Dv[k + 1][i][0] = v0; Dv[k + 1][i][1] = v1;
+            }
+        }
+        double Ms[3][4]; int act3[3] = {cfg->terminal_xy_eq, cfg->terminal_xy_eq, w->sig};
+        memset(Ms, 0, sizeof(Ms));
+        for (int r = 0; r < 2; r++) {
+            Ms[r][0] = Dv[N][r][0]; Ms[r][1] = Dv[N][r][1]; Ms[r][2] = w->sig ? w->dxs[N][r] : 0.0;
+            Ms[r][3] = w->xref[N * nx + r] - w->X[N][r] - d0[N][r];
+        }
+        if (w->sig) {
+            double t0 = 0, tv[2] = {0, 0};
+            for (int j = 0; j < nx; j++) {
+                t0 += w->vq[N - 1][j] * d0[N - 2][j] + w->vx[N - 1][j] * d0[N - 1][j] + w->vxN[j] * d0[N][j];
+                for (int cc = 0; cc < 2; cc++) tv[cc] += w->vq[N - 1][j] * Dv[N - 2][j][cc] + w->vx[N - 1][j] * Dv[N - 1][j][cc] + w->vxN[j] * Dv[N][j][cc];
+            }
+            Ms[2][0] = -tv[0]; Ms[2][1] = -tv[1]; Ms[2][2] = w->sig_den; Ms[2][3] = -w->gss[N - 1] + t0;
+        }
+        for (int r = 0; r < 3; r++) if (!act3[r]) { for (int q = 0; q < 4; q++) Ms[r][q] = 0.0; for (int q = 0; q < 3; q++) Ms[q][r] = 0.0; Ms[r][r] = 1.0; }
+        for (int pcol = 0; pcol < 3; pcol++) {   /* Gaussian elimination with row pivoting (3 x 3) */
+            int pr = pcol; for (int r = pcol + 1; r < 3; r++) if (fabs(Ms[r][pcol]) > fabs(Ms[pr][pcol])) pr = r;
+            if (pr != pcol) for (int q = 0; q < 4; q++) { double tq = Ms[pr][q]; Ms[pr][q] = Ms[pcol][q]; Ms[pcol][q] = tq; }
+            for (int r = 0; r < 3; r++) if (r != pcol) { double f = Ms[r][pcol] / Ms[pcol][pcol]; for (int q = pcol; q < 4; q++) Ms[r][q] -= f * Ms[pcol][q]; }
+        }
+        double y[3]; for (int r = 0; r < 3; r++) y[r] = Ms[r][3] / Ms[r][r];
+        w->nu_new[0] = y[0]; w->nu_new[1] = y[1]; w->dsig = y[2];
+        for (int k = 0; k < N; k++) for (int i = 0; i < nu; i++) {
+            if (cfg->terminal_xy_eq) w->kf[k][i] += w->kfv[k][i][0] * y[0] + w->kfv[k][i][1] * y[1];
+            if (w->sig) w->kf[k][i] += w->kfv[k][i][2] * y[2];
+        }
+    }
+    for (int j = 0; j < nx; j++) w->dX[0][j] = 0;
+    for (int k = 0; k < N; k++) {
+        for (int i = 0; i < nu; i++) { double v = w->kf[k][i]; for (int j = 0; j < nx; j++) v += w->K[k][i][j] * w->dX[k][j]; w->dU[k][i] = v; }
+        for (int i = 0; i < nx; i++) {
+            double v = w->c[k][i];
+            for (int j = 0; j < nx; j++) v += w->A[k][i][j] * w->dX[k][j];
+            for (int j = 0; j < nu; j++) v += w->B[k][i][j] * w->dU[k][j];
+            w->dX[k + 1][i] = v;
+        }
+    }
+    for (int k = 1; k <= N; k++) for (int i = 0; i < nx; i++) {
+        double v = w->qx[k][i]; for (int j = 0; j < nx; j++) v += w->Hxx[k][i][j] * w->dX[k][j];
+        if (cfg->terminal_xy_eq) v += w->pvv[k][i][0] * w->nu_new[0] + w->pvv[k][i][1] * w->nu_new[1];
+        if (w->sig) v += w->pvv[k][i][2] * w->dsig;
+        w->lamn[k][i] = -v; }
+    for (int k = 0; k <= N; k++) {
+        double vdx = 0; for (int j = 0; j < nx; j++) vdx += w->vx[k][j] * w->dX[k][j];
+        if (k == N - 1) for (int j = 0; j < nx; j++) vdx += w->vxN[j] * w->dX[N][j];
+        if (w->nq8 && k >= 1) for (int j = 0; j < nx; j++) vdx += w->vq[k][j] * w->dX[k - 1][j];
+        w->ds[k] = -(w->gss[k] - vdx) / w->hss[k];
+    }
+    if (w->nq8)   /* a slack eliminated one stage earlier is not part of its own stage's cost-to-go: its pull on x_k enters the
+                   * multiplier of the dynamics directly,  lam_k+ = -(P_k dx_k + p_k) + v_k ds_k */
+        for (int k = 1; k <= N; k++) {
+            int back = 0;
+            if (k != N - 1) for (int i = 0; i < nx; i++) if (w->vq[k][i] != 0.0) back = 1;
+            if (back) for (int i = 0; i < nx; i++) w->lamn[k][i] += w->vx[k][i] * w->ds[k];
+        }
+    double tau = fmax(0.99, 1 - mu), ap = 1, ad = 1, dphi = 0;
+    for (int k = 0; k <= N; k++) {
+        for (int r = 0; r < w->nrow; r++) {
+            if (!w->act[k][r]) continue;
+            double jd;
+            if (r < 2 * nu) { int j = r < nu ? r : r - nu; jd = (r < nu ? -1.0 : 1.0) * w->dU[k][j]; }
+            else if (r < 2 * nu + 2 * nx) { int q = r - 2 * nu; int j = q < nx ? q : q - nx; jd = (q < nx ? -1.0 : 1.0) * w->dX[k][j]; }
+            else if (r < 2 * nu + 2 * nx + w->M) { int m = r - 2 * nu - 2 * nx; jd = w->gcirc[k][m][0] * w->dX[k][0] + w->gcirc[k][m][1] * w->dX[k][1] - w->ds[k]; }
+            else if (r < 2 * nu + 2 * nx + w->M + 4) { int i = r - 2 * nu - 2 * nx - w->M; jd = -w->ds[slack_idx(w, k)]; for (int j = 0; j < 6; j++) jd += w->gself[k][i][j] * w->dX[k][YIDX[j]]; }
+            else if (r < SL_Q8(w, 0)) { int i = r - 2 * nu - 2 * nx - w->M - 4; jd = -w->ds[k]; for (int j = 0; j < 6; j++) jd += w->ghs[k][i][j] * w->dX[k][YIDX[j]]; }
+            else { int e = r - SL_Q8(w, 0), kk = k - w->q8br[k][e]; jd = -w->ds[k]; for (int j = 0; j < 6; j++) jd += w->gq8[k][e][j] * w->dX[kk][YIDX[j]]; }
+            double tt = w->t[k][r], zz = w->z[k][r];
+            double dtv = -(w->h[k][r] + tt) - jd, dzv = mu / tt - zz - (zz / tt) * dtv;
+            w->dt_[k][r] = dtv; w->dz[k][r] = dzv;
+            if (dtv < 0) { double a = -tau * tt / dtv; if (a < ap) { ap = a; w->dbg_k = k; w->dbg_r = r; w->dbg_t = tt; w->dbg_dt = dtv; w->dbg_z = zz; } }
+            if (dzv < 0) { double a = -tau * zz / dzv; if (a < ad) ad = a; }
+            dphi -= mu * dtv / tt;
+        }
+        for (int j = 0; j < nx; j++) dphi += w->gX[k][j] * w->dX[k][j];
+        if (k < N) for (int j = 0; j < nu; j++) dphi += w->gU[k][j] * w->dU[k][j];
+        dphi += w->gs[k] * w->ds[k];
+    }
+    *ap_out = ap; *ad_out = ad; *dphi_out = dphi;
+}
+
 typedef struct { double th, phi; } fent;
+
 
 /*
  * Solve one instance.  Inputs row-major: x_init[nx] (already clipped by the caller for the
@@ -694,13 +814,13 @@ int mmpc_oracle_solve(const oracle_cfg *cfg, const double *x_init, const double 
             w->X[k][j] = bound_push(w->X[k][j], w->act[k][SL_XLO(w, j)] ? w->bnd[k][SL_XLO(w, j)] : -INFINITY,
                                     w->act[k][SL_XHI(w, j)] ? w->bnd[k][SL_XHI(w, j)] : INFINITY);
     }
-    double mu = cfg->mu_init;
+    double mu = LAB[10] > 0 ? LAB[10] : cfg->mu_init;
     eval_rows(w, w->X, w->U, w->s, w->h, 0);
     int nrows_act = 0;
     for (int k = 0; k <= N; k++) for (int r = 0; r < w->nrow; r++) if (w->act[k][r]) {
         double v = -w->h[k][r]; w->t[k][r] = v > 1e-2 ? v : 1e-2; w->z[k][r] = mu / w->t[k][r]; nrows_act++; }
     int status = 1, it = 0, nf = 0, nsmall = 0;
-    double prox = 0.0;
+    double prox = 0.0, delta_last = 0.0; int soc_off = 0; work *sv = 0;
     double th_max = 0, th_min = 0, E0 = 0;
     fent filt[FCAP];
     int filt_init = 0, nfilt = 0;
@@ -731,14 +851,14 @@ int mmpc_oracle_solve(const oracle_cfg *cfg, const double *x_init, const double 
             }
         }
         /* ---- KKT error */
-        double err_d = 0, err_p = 0, comp0 = 0, compmu = 0, zsum = 0;
+        double err_d = 0, err_p = 0, comp0 = 0, compmu = 0, zsum = 0, zrow = 0;
         {
             static __thread double rdx[NSM][NXM], rdu[NSM][NUM], rds[NSM];
             for (int k = 0; k <= N; k++) { memcpy(rdx[k], w->gX[k], sizeof(rdx[k])); memcpy(rdu[k], w->gU[k], sizeof(rdu[k])); rds[k] = w->gs[k]; }
             for (int k = 0; k <= N; k++) for (int r = 0; r < w->nrow; r++) {
                 if (!w->act[k][r]) continue;
                 double zz = w->z[k][r], tt = w->t[k][r];
-                zsum += zz;
+                zsum += zz; zrow += zz;
                 double cp = tt * zz; if (cp > comp0) comp0 = cp; if (fabs(cp - mu) > compmu) compmu = fabs(cp - mu);
                 double rh = fabs(w->h[k][r] + tt); if (rh > err_p) err_p = rh;
                 if (r < 2 * nu) { int j = r < nu ? r : r - nu; rdu[k][j] += (r < nu ? -zz : zz); }
@@ -769,8 +889,11 @@ int mmpc_oracle_solve(const oracle_cfg *cfg, const double *x_init, const double 
             }
         }
         double sd = zsum / (nrows_act + (N + 1) * nx); sd = (sd > 100.0 ? sd : 100.0) / 100.0;
-        E0 = fmax(fmax(err_d / sd, err_p), comp0 / sd);
-        double Emu = fmax(fmax(err_d / sd, err_p), compmu / sd);
+        /* IPOPT's scaling of the complementarity (Waechter & Biegler 2006, eq. 5-6): s_c from the bound multipliers alone */
+        double sc = zrow / (nrows_act > 0 ? nrows_act : 1); sc = (sc > 100.0 ? sc : 100.0) / 100.0;
+        if (LAB[0] < 1.0) sc = sd;
+        E0 = fmax(fmax(err_d / sd, err_p), comp0 / sc);
+        double Emu = fmax(fmax(err_d / sd, err_p), compmu / sc);
         if (!(E0 == E0)) { status = 2; break; }
         if (E0 <= tol) { status = 0; break; }
         if (it == cfg->max_iter) break;
@@ -780,171 +903,173 @@ int mmpc_oracle_solve(const oracle_cfg *cfg, const double *x_init, const double 
             mu = fmax(tol / 10, fmin(m1, m2));
             compmu = 0;
             for (int k = 0; k <= N; k++) for (int r = 0; r < w->nrow; r++) if (w->act[k][r]) { double d = fabs(w->t[k][r] * w->z[k][r] - mu); if (d > compmu) compmu = d; }
-            Emu = fmax(fmax(err_d / sd, err_p), compmu / sd);
+            Emu = fmax(fmax(err_d / sd, err_p), compmu / sc);
             changed = 1;
         }
         if (changed) filt_init = 0;
         /* ---- Newton direction */
-        /* (the middle rung is skipped with the terminal equality, like the proximal term: see mmpc_core.h) */
-        if (!factor(w, mu, 2, prox)) if (cfg->terminal_xy_eq || w->nhs > 0 || !factor(w, mu, 1, prox)) {
-            /* Gauss-Newton; if even that loses a pivot (round-off under huge barrier weights) the proximal term is raised
-             * until the pass goes through (not with the terminal equality, where it is off) */
-            int okf = factor(w, mu, 0, prox);
-            while (!okf && !cfg->terminal_xy_eq && prox < PROX_MAX) {
-                prox = prox * 4.0 > PROX0 ? prox * 4.0 : PROX0; if (prox > PROX_MAX) prox = PROX_MAX;
-                okf = factor(w, mu, 0, prox);
-            }
-            if (!okf) { status = 2; break; }
+        int rung = 2; double delta_used = 0.0;
+#define NEWTON_SOLVE(FAILSTMT)                                                                                              \
+        rung = 2; delta_used = 0.0;                                                                                          \
+        if (LAB[1] >= 1.0 && !cfg->terminal_xy_eq) {                                                                         \
+            /* IPOPT's inertia correction (Waechter & Biegler 2006, Algorithm IC): H + delta_w I with the smallest delta_w  \
+             * of a geometric sequence for which every pivot of the recursion is positive.  Not with the terminal-xy        \
+             * equality: the multipliers of the regularised system grow like delta_w there (the full correction             \
+             * E dx_N = e is forced whatever the damping) and feed back into lam^T d2f - Gauss-Newton as in round 3 */     \
+            int okf = factor(w, mu, 2, prox);                                                                                \
+            if (!okf) {                                                                                                      \
+                const double d0 = LAB[6] > 0 ? LAB[6] : 1e-4, kfirst = LAB[7] > 0 ? LAB[7] : 100.0, kup = LAB[8] > 0 ? LAB[8] : 8.0, kdn = LAB[9] > 0 ? LAB[9] : 1.0 / 3.0; \
+                double dw = delta_last == 0.0 ? d0 : fmax(1e-20, kdn * delta_last);                                          \
+                while (!(okf = factor(w, mu, 2, prox + dw))) {                                                               \
+                    dw *= delta_last == 0.0 ? kfirst : kup;                                                                  \
+                    if (dw > 1e40) break;                                                                                    \
+                }                                                                                                            \
+                if (!okf) { FAILSTMT; }                                                                                      \
+                delta_last = dw; delta_used = dw;                                                                            \
+            }                                                                                                                \
+        } else if (!factor(w, mu, 2, prox)) if ((rung = 1, cfg->terminal_xy_eq || w->nhs > 0 || !factor(w, mu, 1, prox))) { \
+            rung = 0;                                                                                                        \
+            int okf = factor(w, mu, 0, prox);                                                                                \
+            while (!okf && !cfg->terminal_xy_eq && prox < PROX_MAX) {                                                        \
+                prox = prox * 4.0 > PROX0 ? prox * 4.0 : PROX0; if (prox > PROX_MAX) prox = PROX_MAX;                        \
+                okf = factor(w, mu, 0, prox);                                                                                \
+            }                                                                                                                \
+            if (!okf) { FAILSTMT; }                                                                                          \
         }
-        w->nu_new[0] = w->nu_new[1] = 0; w->dsig = 0;
-        if (cfg->terminal_xy_eq || w->sig) {
-            /* the direction is affine in the border variables y = (nu0, nu1, dsigma): roll out the y = 0 solution and the
-             * sensitivities (same gains), then the small system
-             *   E (dx_N + D y) = e                        (terminal equality)
-             *   h dsigma - v~.(d + D y) = -g_s            (stationarity in s_{N-1}) */
-            static __thread double d0[NSM][NXM], Dv[NSM][NXM][2];
-            memset(d0, 0, sizeof(d0)); memset(Dv, 0, sizeof(Dv));
-            for (int k = 0; k < N; k++) {
-                double u0[NUM], Uv[NUM][2];
-                for (int i = 0; i < nu; i++) {
-                    double v = w->kf[k][i], v0 = w->kfv[k][i][0], v1 = w->kfv[k][i][1];
-                    for (int j = 0; j < nx; j++) { v += w->K[k][i][j] * d0[k][j]; v0 += w->K[k][i][j] * Dv[k][j][0]; v1 += w->K[k][i][j] * Dv[k][j][1]; }
-                    u0[i] = v; Uv[i][0] = v0; Uv[i][1] = v1;
-                }
-                for (int i = 0; i < nx; i++) {
-                    double v = w->c[k][i], v0 = 0, v1 = 0;
-                    for (int j = 0; j < nx; j++) { v += w->A[k][i][j] * d0[k][j]; v0 += w->A[k][i][j] * Dv[k][j][0]; v1 += w->A[k][i][j] * Dv[k][j][1]; }
-                    for (int j = 0; j < nu; j++) { v += w->B[k][i][j] * u0[j]; v0 += w->B[k][i][j] * Uv[j][0]; v1 += w->B[k][i][j] * Uv[j][1]; }
-                    d0[k + 1][i] = v; Dv[k + 1][i][0] = v0; Dv[k + 1][i][1] = v1;
-                }
-            }
-            double Ms[3][4]; int act3[3] = {cfg->terminal_xy_eq, cfg->terminal_xy_eq, w->sig};
-            memset(Ms, 0, sizeof(Ms));
-            for (int r = 0; r < 2; r++) {
-                Ms[r][0] = Dv[N][r][0]; Ms[r][1] = Dv[N][r][1]; Ms[r][2] = w->sig ? w->dxs[N][r] : 0.0;
-                Ms[r][3] = w->xref[N * nx + r] - w->X[N][r] - d0[N][r];
-            }
-            if (w->sig) {
-                double t0 = 0, tv[2] = {0, 0};
-                for (int j = 0; j < nx; j++) {
-                    t0 += w->vq[N - 1][j] * d0[N - 2][j] + w->vx[N - 1][j] * d0[N - 1][j] + w->vxN[j] * d0[N][j];
-                    for (int cc = 0; cc < 2; cc++) tv[cc] += w->vq[N - 1][j] * Dv[N - 2][j][cc] + w->vx[N - 1][j] * Dv[N - 1][j][cc] + w->vxN[j] * Dv[N][j][cc];
-                }
-                Ms[2][0] = -tv[0]; Ms[2][1] = -tv[1]; Ms[2][2] = w->sig_den; Ms[2][3] = -w->gss[N - 1] + t0;
-            }
-            for (int r = 0; r < 3; r++) if (!act3[r]) { for (int q = 0; q < 4; q++) Ms[r][q] = 0.0; for (int q = 0; q < 3; q++) Ms[q][r] = 0.0; Ms[r][r] = 1.0; }
-            for (int pcol = 0; pcol < 3; pcol++) {   /* Gaussian elimination with row pivoting (3 x 3) */
-                int pr = pcol; for (int r = pcol + 1; r < 3; r++) if (fabs(Ms[r][pcol]) > fabs(Ms[pr][pcol])) pr = r;
-                if (pr != pcol) for (int q = 0; q < 4; q++) { double tq = Ms[pr][q]; Ms[pr][q] = Ms[pcol][q]; Ms[pcol][q] = tq; }
-                for (int r = 0; r < 3; r++) if (r != pcol) { double f = Ms[r][pcol] / Ms[pcol][pcol]; for (int q = pcol; q < 4; q++) Ms[r][q] -= f * Ms[pcol][q]; }
-            }
-            double y[3]; for (int r = 0; r < 3; r++) y[r] = Ms[r][3] / Ms[r][r];
-            w->nu_new[0] = y[0]; w->nu_new[1] = y[1]; w->dsig = y[2];
-            for (int k = 0; k < N; k++) for (int i = 0; i < nu; i++) {
-                if (cfg->terminal_xy_eq) w->kf[k][i] += w->kfv[k][i][0] * y[0] + w->kfv[k][i][1] * y[1];
-                if (w->sig) w->kf[k][i] += w->kfv[k][i][2] * y[2];
-            }
-        }
-        for (int j = 0; j < nx; j++) w->dX[0][j] = 0;
-        for (int k = 0; k < N; k++) {
-            for (int i = 0; i < nu; i++) { double v = w->kf[k][i]; for (int j = 0; j < nx; j++) v += w->K[k][i][j] * w->dX[k][j]; w->dU[k][i] = v; }
-            for (int i = 0; i < nx; i++) {
-                double v = w->c[k][i];
-                for (int j = 0; j < nx; j++) v += w->A[k][i][j] * w->dX[k][j];
-                for (int j = 0; j < nu; j++) v += w->B[k][i][j] * w->dU[k][j];
-                w->dX[k + 1][i] = v;
-            }
-        }
-        for (int k = 1; k <= N; k++) for (int i = 0; i < nx; i++) {
-            double v = w->qx[k][i]; for (int j = 0; j < nx; j++) v += w->Hxx[k][i][j] * w->dX[k][j];
-            if (cfg->terminal_xy_eq) v += w->pvv[k][i][0] * w->nu_new[0] + w->pvv[k][i][1] * w->nu_new[1];
-            if (w->sig) v += w->pvv[k][i][2] * w->dsig;
-            w->lamn[k][i] = -v; }
-        for (int k = 0; k <= N; k++) {
-            double vdx = 0; for (int j = 0; j < nx; j++) vdx += w->vx[k][j] * w->dX[k][j];
-            if (k == N - 1) for (int j = 0; j < nx; j++) vdx += w->vxN[j] * w->dX[N][j];
-            if (w->nq8 && k >= 1) for (int j = 0; j < nx; j++) vdx += w->vq[k][j] * w->dX[k - 1][j];
-            w->ds[k] = -(w->gss[k] - vdx) / w->hss[k];
-        }
-        if (w->nq8)   /* a slack eliminated one stage earlier is not part of its own stage's cost-to-go: its pull on x_k enters the
-                       * multiplier of the dynamics directly,  lam_k+ = -(P_k dx_k + p_k) + v_k ds_k */
-            for (int k = 1; k <= N; k++) {
-                int back = 0;
-                if (k != N - 1) for (int i = 0; i < nx; i++) if (w->vq[k][i] != 0.0) back = 1;
-                if (back) for (int i = 0; i < nx; i++) w->lamn[k][i] += w->vx[k][i] * w->ds[k];
-            }
-        double tau = fmax(0.99, 1 - mu), ap = 1, ad = 1, dphi = 0;
-        for (int k = 0; k <= N; k++) {
-            for (int r = 0; r < w->nrow; r++) {
-                if (!w->act[k][r]) continue;
-                double jd;
-                if (r < 2 * nu) { int j = r < nu ? r : r - nu; jd = (r < nu ? -1.0 : 1.0) * w->dU[k][j]; }
-                else if (r < 2 * nu + 2 * nx) { int q = r - 2 * nu; int j = q < nx ? q : q - nx; jd = (q < nx ? -1.0 : 1.0) * w->dX[k][j]; }
-                else if (r < 2 * nu + 2 * nx + w->M) { int m = r - 2 * nu - 2 * nx; jd = w->gcirc[k][m][0] * w->dX[k][0] + w->gcirc[k][m][1] * w->dX[k][1] - w->ds[k]; }
-                else if (r < 2 * nu + 2 * nx + w->M + 4) { int i = r - 2 * nu - 2 * nx - w->M; jd = -w->ds[slack_idx(w, k)]; for (int j = 0; j < 6; j++) jd += w->gself[k][i][j] * w->dX[k][YIDX[j]]; }
-                else if (r < SL_Q8(w, 0)) { int i = r - 2 * nu - 2 * nx - w->M - 4; jd = -w->ds[k]; for (int j = 0; j < 6; j++) jd += w->ghs[k][i][j] * w->dX[k][YIDX[j]]; }
-                else { int e = r - SL_Q8(w, 0), kk = k - w->q8br[k][e]; jd = -w->ds[k]; for (int j = 0; j < 6; j++) jd += w->gq8[k][e][j] * w->dX[kk][YIDX[j]]; }
-                double tt = w->t[k][r], zz = w->z[k][r];
-                double dtv = -(w->h[k][r] + tt) - jd, dzv = mu / tt - zz - (zz / tt) * dtv;
-                w->dt_[k][r] = dtv; w->dz[k][r] = dzv;
-                if (dtv < 0) { double a = -tau * tt / dtv; if (a < ap) ap = a; }
-                if (dzv < 0) { double a = -tau * zz / dzv; if (a < ad) ad = a; }
-                dphi -= mu * dtv / tt;
-            }
-            for (int j = 0; j < nx; j++) dphi += w->gX[k][j] * w->dX[k][j];
-            if (k < N) for (int j = 0; j < nu; j++) dphi += w->gU[k][j] * w->dU[k][j];
-            dphi += w->gs[k] * w->ds[k];
-        }
+        int nfail = 0;
+        NEWTON_SOLVE(nfail = 1)
+        if (nfail) { status = 2; break; }
+        double ap = 1, ad = 1, dphi = 0;
+        direction(w, mu, &ap, &ad, &dphi);
         /* ---- filter line search */
         double phi0, th0;
         merit_parts(w, w->X, w->U, w->s, w->t, mu, &phi0, &th0);
         if (!filt_init) { nfilt = 0; th_max = 1e4 * fmax(1.0, th0); th_min = 1e-4 * fmax(1.0, th0); filt_init = 1; }
-        double alpha = ap; int accepted = 0;
-        for (int lspass = 0; lspass < 2 && !accepted; lspass++) {
+        double alpha = ap; int accepted = 0, soc_used = 0, null_step = 0, z_done = 0;
+        const int soc_max = soc_off ? 0 : (int)LAB[2];
+        soc_off = 0;
+#define TRIAL_POINT(A)                                                                                                      \
+        for (int k = 0; k <= N; k++) {                                                                                       \
+            for (int j = 0; j < nx; j++) Xn[k][j] = w->X[k][j] + (A) * w->dX[k][j];                                          \
+            if (k < N) for (int j = 0; j < nu; j++) Un[k][j] = w->U[k][j] + (A) * w->dU[k][j];                               \
+            sn[k] = w->s[k] + (A) * w->ds[k];                                                                                \
+            for (int r = 0; r < w->nrow; r++) if (w->act[k][r]) tn[k][r] = w->t[k][r] + (A) * w->dt_[k][r];                  \
+        }
+        /* acceptance of a trial (th, phi) against the filter and the current point; a0 = the step length the switching and
+         * Armijo conditions are evaluated with (a second-order correction is tested with the length of the step it corrects) */
+#define ACCEPT_TEST(TH, PHI, A0, OUT)                                                                                       \
+        {                                                                                                                    \
+            int okf_ = (TH) < th_max;                                                                                        \
+            for (int i = 0; i < nfilt && okf_; i++) if ((TH) >= filt[i].th && (PHI) >= filt[i].phi) okf_ = 0;               \
+            const int ftype_ = dphi < 0 && th0 <= th_min && (A0) * pow(-dphi, 2.3) > pow(th0, 1.1);                          \
+            (OUT) = 0;                                                                                                       \
+            if (okf_) {                                                                                                      \
+                if (ftype_) { if ((PHI) <= phi0 + 1e-8 * (A0) * dphi + 1e-14 * fabs(phi0)) (OUT) = 1; }                      \
+                else if ((TH) <= (1 - 1e-5) * th0 || (PHI) <= phi0 - 1e-5 * th0) {                                           \
+                    (OUT) = 1;                                                                                               \
+                    fent ne = {(1 - 1e-5) * th0, phi0 - 1e-5 * th0};                                                         \
+                    if (nfilt < FCAP) filt[nfilt++] = ne;                                                                    \
+                    else { int im = 0; for (int i = 1; i < FCAP; i++) if (filt[i].th > filt[im].th) im = i; filt[im] = ne; } \
+                }                                                                                                            \
+            }                                                                                                                \
+        }
+        for (int lspass = 0; lspass < 2 && !accepted && !null_step; lspass++) {
             alpha = ap;
             for (int ls = 0; ls < 20; ls++) {
-                for (int k = 0; k <= N; k++) {
-                    for (int j = 0; j < nx; j++) Xn[k][j] = w->X[k][j] + alpha * w->dX[k][j];
-                    if (k < N) for (int j = 0; j < nu; j++) Un[k][j] = w->U[k][j] + alpha * w->dU[k][j];
-                    sn[k] = w->s[k] + alpha * w->ds[k];
-                    for (int r = 0; r < w->nrow; r++) if (w->act[k][r]) tn[k][r] = w->t[k][r] + alpha * w->dt_[k][r];
-                }
+                TRIAL_POINT(alpha)
                 double phi, th;
                 merit_parts(w, Xn, Un, sn, tn, mu, &phi, &th);
-                int okf = th < th_max;
-                for (int i = 0; i < nfilt && okf; i++) if (th >= filt[i].th && phi >= filt[i].phi) okf = 0;
-                int ftype = dphi < 0 && th0 <= th_min && alpha * pow(-dphi, 2.3) > pow(th0, 1.1);
-                if (okf) {
-                    if (ftype) {
-                        if (phi <= phi0 + 1e-8 * alpha * dphi + 1e-14 * fabs(phi0)) { accepted = 1; break; }
-                    } else if (th <= (1 - 1e-5) * th0 || phi <= phi0 - 1e-5 * th0) {
-                        accepted = 1;
-                        fent ne = {(1 - 1e-5) * th0, phi0 - 1e-5 * th0};
-                        if (nfilt < FCAP) filt[nfilt++] = ne;
-                        else { int im = 0; for (int i = 1; i < FCAP; i++) if (filt[i].th > filt[im].th) im = i; filt[im] = ne; }
-                        break;
+                ACCEPT_TEST(th, phi, alpha, accepted)
+                if (accepted) break;
+                if (ls == 0 && lspass == 0 && soc_max > 0 && th >= th0 && !cfg->terminal_xy_eq && (LAB[20] < 1.0 || th0 <= LAB[20] * th_min)) {
+                    /* Second-order correction (Waechter & Biegler 2006, section 2.4): the first trial was rejected and did not
+                     * reduce the infeasibility.  The step is recomputed from x_k with c_soc = alpha c(x_k) + c(x_k + alpha d)
+                     * in place of the constraint residuals, at most soc_max times (c_soc <- alpha_soc c_soc + c(x_soc)).
+                     * The row multipliers take their step of the uncorrected direction first (they do not depend on alpha;
+                     * this is what the kernels, which move to a trial point in place, have in their registers at this point),
+                     * so the corrected system is the primal-dual Newton system at (x_k, z+).  A correction that fails leaves
+                     * x_k where it is: the iteration ends with the multiplier step alone, the next one runs without. */
+                    static __thread double accC[NSM][NXM], accR[NSM][RMX], hs_[NSM][RMX], c0s[NSM][NXM], h0s[NSM][RMX];
+                    const double alpha0 = alpha;
+                    for (int k = 0; k <= N; k++) for (int r = 0; r < w->nrow; r++) if (w->act[k][r]) {
+                        w->z[k][r] += ad * w->dz[k][r];
+                        const double lo_ = mu / (KAPPA_SIGMA * tn[k][r]), hi_ = KAPPA_SIGMA * mu / tn[k][r];
+                        if (w->z[k][r] < lo_) w->z[k][r] = lo_; else if (w->z[k][r] > hi_) w->z[k][r] = hi_;
                     }
+                    z_done = 1;
+                    if (!sv) sv = (work *)malloc(sizeof(work));
+                    memcpy(sv->dX, w->dX, sizeof(w->dX)); memcpy(sv->dU, w->dU, sizeof(w->dU)); memcpy(sv->ds, w->ds, sizeof(w->ds));
+                    memcpy(sv->lamn, w->lamn, sizeof(w->lamn)); memcpy(sv->dt_, w->dt_, sizeof(w->dt_));
+                    sv->nu_new[0] = w->nu_new[0]; sv->nu_new[1] = w->nu_new[1]; sv->dsig = w->dsig;
+                    memcpy(c0s, w->c, sizeof(c0s)); memcpy(h0s, w->h, sizeof(h0s));
+                    for (int k = 0; k <= N; k++) {
+                        for (int j = 0; j < nx; j++) accC[k][j] = w->c[k][j];
+                        for (int r = 0; r < w->nrow; r++) accR[k][r] = w->act[k][r] ? w->h[k][r] + w->t[k][r] : 0.0;
+                    }
+                    double a_prev = alpha, th_prev = th; int soc_ok = 0;
+                    for (int p = 0; p < soc_max; p++) {
+                        __atomic_fetch_add(&LAB_NSOC, 1, __ATOMIC_RELAXED);
+                        eval_rows(w, Xn, Un, sn, hs_, 0);
+                        for (int k = 0; k <= N; k++) {
+                            if (k < N) {
+                                double xn_[NXM]; f_dyn(cfg->kind, cfg->dt, Xn[k], Un[k], xn_);
+                                for (int j = 0; j < nx; j++) { accC[k][j] = a_prev * accC[k][j] + (xn_[j] - Xn[k + 1][j]); w->c[k][j] = accC[k][j]; }
+                            }
+                            for (int r = 0; r < w->nrow; r++) if (w->act[k][r]) {
+                                accR[k][r] = a_prev * accR[k][r] + (hs_[k][r] + tn[k][r]);
+                                w->h[k][r] = accR[k][r] - w->t[k][r];
+                            }
+                        }
+                        int sfail = 0;
+                        NEWTON_SOLVE(sfail = 1)
+                        if (sfail) break;
+                        double ap2, ad2, dphi2;
+                        direction(w, mu, &ap2, &ad2, &dphi2);
+                        TRIAL_POINT(ap2)
+                        double phi2, th2;
+                        merit_parts(w, Xn, Un, sn, tn, mu, &phi2, &th2);
+                        ACCEPT_TEST(th2, phi2, alpha0, soc_ok)
+                        if (soc_ok) { alpha = ap2; soc_used = p + 1; __atomic_fetch_add(&LAB_NSOCOK, 1, __ATOMIC_RELAXED); break; }
+                        if (th2 > 0.99 * th_prev) break;
+                        a_prev = ap2; th_prev = th2;
+                    }
+                    memcpy(w->c, c0s, sizeof(c0s)); memcpy(w->h, h0s, sizeof(h0s));
+                    if (soc_ok) { accepted = 1; break; }
+                    __atomic_fetch_add(&LAB_NSOCFAIL, 1, __ATOMIC_RELAXED);
+                    if (LAB[19] >= 1.0) { null_step = 1; soc_off = 1; break; }
+                    /* the correction failed: the line search goes on along the uncorrected direction */
+                    memcpy(w->dX, sv->dX, sizeof(w->dX)); memcpy(w->dU, sv->dU, sizeof(w->dU)); memcpy(w->ds, sv->ds, sizeof(w->ds));
+                    memcpy(w->lamn, sv->lamn, sizeof(w->lamn)); memcpy(w->dt_, sv->dt_, sizeof(w->dt_));
+                    w->nu_new[0] = sv->nu_new[0]; w->nu_new[1] = sv->nu_new[1]; w->dsig = sv->dsig;
                 }
                 if (ls < 19) alpha *= 0.5;
             }
-            if (accepted || nfilt == 0) break;
+            if (accepted || null_step || nfilt == 0) break;
             nfilt = 0; /* filter reset heuristic: the filter blocked every trial step */
         }
         nf += !accepted;
-        if (getenv("MMPC_ORACLE_DEBUG")) fprintf(stderr, "it %d mu %.2e E0 %.3e err_d %.3e err_p %.3e comp %.3e alpha %.3e ap %.3e ad %.3e acc %d prox %.1e dphi %.3e\n", it, mu, E0, err_d, err_p, comp0, alpha, ap, ad, accepted, prox, dphi);
+        if (null_step) alpha = 0.0;
+        if (getenv("MMPC_ORACLE_DEBUG")) fprintf(stderr, "it %d mu %.2e E0 %.3e err_d %.3e err_p %.3e comp %.3e alpha %.3e ap %.3e ad %.3e acc %d prox %.1e dphi %.3e rung %d dw %.1e th %.2e soc %d | k %d r %d t %.2e dt %.2e z %.2e\n", it, mu, E0, err_d, err_p, comp0, alpha, ap, ad, accepted, prox, dphi, rung, delta_used, th0, null_step ? -1 : soc_used, w->dbg_k, w->dbg_r, w->dbg_t, w->dbg_dt, w->dbg_z);
         /* proximal term for crawling iterations (oracle/ipm_numpy.py: Options.prox*) */
-        nsmall = alpha < PROX_LO ? nsmall + 1 : 0;
-        if (cfg->terminal_xy_eq) prox = 0.0;   /* the forced correction E dx_N = e makes nu grow like prox */
-        else if (alpha < PROX_LO && (nsmall >= 2 || prox > 0.0)) { prox = prox * 4.0 > PROX0 ? prox * 4.0 : PROX0; if (prox > PROX_MAX) prox = PROX_MAX; }
-        else if (alpha > 0.5) prox = prox > PROX0 * 1e-3 ? prox / 4.0 : 0.0;
+        if (!null_step) {
+            const double PX0 = LAB[15] > 0 ? LAB[15] : PROX0, PXLO = LAB[17] > 0 ? LAB[17] : PROX_LO; const int PXN = LAB[16] > 0 ? (int)LAB[16] : 2;
+            const double a_px = LAB[18] >= 1.0 ? ap : alpha;
+            nsmall = a_px < PXLO ? nsmall + 1 : 0;
+            if (cfg->terminal_xy_eq || LAB[3] >= 1.0) prox = 0.0;   /* the forced correction E dx_N = e makes nu grow like prox */
+            else if (a_px < PXLO && (nsmall >= PXN || prox > 0.0)) { prox = prox * 4.0 > PX0 ? prox * 4.0 : PX0; if (prox > PROX_MAX) prox = PROX_MAX; }
+            else if (alpha > 0.5) prox = prox > PX0 * 1e-3 ? prox / 4.0 : 0.0;
+        }
         /* ---- update */
         for (int j = 0; j < 2; j++) w->nu_eq[j] += alpha * (w->nu_new[j] - w->nu_eq[j]);
         for (int k = 0; k <= N; k++) {
             if (k > 0) for (int j = 0; j < nx; j++) { w->X[k][j] += alpha * w->dX[k][j]; w->lam[k][j] += alpha * (w->lamn[k][j] - w->lam[k][j]); }
             if (k < N) for (int j = 0; j < nu; j++) w->U[k][j] += alpha * w->dU[k][j];
             w->s[k] += alpha * w->ds[k];
-            for (int r = 0; r < w->nrow; r++) if (w->act[k][r]) { w->t[k][r] += alpha * w->dt_[k][r]; w->z[k][r] += ad * w->dz[k][r]; }
+            for (int r = 0; r < w->nrow; r++) if (w->act[k][r]) { w->t[k][r] += alpha * w->dt_[k][r]; if (!z_done) w->z[k][r] += ad * w->dz[k][r]; }
         }
+#undef NEWTON_SOLVE
+#undef TRIAL_POINT
+#undef ACCEPT_TEST
     }
     for (int k = 0; k <= N; k++) {
         for (int j = 0; j < nx; j++) Xo[k * nx + j] = w->X[k][j];
@@ -955,7 +1080,7 @@ int mmpc_oracle_solve(const oracle_cfg *cfg, const double *x_init, const double 
     if (cost_out) *cost_out = cost_fn(w, w->X, w->U, w->s);
     if (err_out) *err_out = E0;
     (void)nf;
-    free(w);
+    free(w); free(sv);
     return status;
 }
 

@@ -36,8 +36,14 @@ static void run(const MmpcParams *P, int B, const double *x_init, const double *
         io.s = s + (size_t)b * (N + 1);
         io.status = status + b; io.iters = iters + b; io.cost = cost + b; io.err = err + b;
         io.state = nullptr; io.budget = 0; io.resume = 0; io.gscr = nullptr;
+        // scratch of the second-order correction (global memory on the device), exact size as the slab
+        const int sdn = mmpc_soc_doubles(N, D::NX, D::NU, L.NR);
+        double *soc = (double *)malloc(sizeof(double) * sdn);
+        for (int i = 0; i < sdn; i++) soc[i] = NAN;
+        io.soc = soc;
         MmpcEmu emu = reverse ? MmpcEmu{63, -1, -1} : MmpcEmu{0, 64, 1};
         mmpc_solve_one<KIND>(*P, io, lds, emu);
+        free(soc);
         free(lds);
     }
 }
@@ -75,8 +81,12 @@ static void run_fast(const MmpcParams *P, int B, const double *x_init, const dou
         double *gscr = gd ? (double *)malloc(sizeof(double) * gd) : nullptr;
         for (int i = 0; i < gd; i++) gscr[i] = NAN;
         io.gscr = gscr;
+        const int sdn = mmpc_soc_doubles(N, D::NX, D::NU, MC + D::NSELF);
+        double *soc = (double *)malloc(sizeof(double) * sdn);
+        for (int i = 0; i < sdn; i++) soc[i] = NAN;
+        io.soc = soc;
         if (budget > 0 || resume) mmpc_solve_fast<KIND, N, MC, true>(*P, io, lds, emu); else mmpc_solve_fast<KIND, N, MC, false>(*P, io, lds, emu);
-        free(gscr);
+        free(gscr); free(soc);
         free(lds);
     }
 }

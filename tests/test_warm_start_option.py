@@ -26,7 +26,7 @@ def _tick1(B, N=20, M=5, cid=3):
 
 
 def test_c_oracle_and_emulator_agree_and_need_fewer_iterations():
-    B = 24
+    B = 96   # (the share of instances that end in the reference protocol's minimum: 0.97-0.99 at 96 and 256, 21 of 24 on the first 24)
     par, d, x1, tr1, U, Ug, Xg = _tick1(B)
     ref = coracle.solve_batch(par, x1, tr1, d["u_ref"], U, d["obs"], nthreads=8)                       # reference protocol
     o = coracle.solve_batch(par, x1, tr1, d["u_ref"], U, d["obs"], X0=Xg, U0=Ug, nthreads=8, mu_init=0.1)
