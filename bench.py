@@ -25,6 +25,12 @@ PROFILE_TAG = "r03"                               # PMC summaries of this build 
 SEED_BASE = 3                                     # weak scaling: rank r solves seed SEED_BASE + r of the C4 generator (no selection)
 
 
+
+def _synth():
+    """the package's seeded workload generator (numpy only): mobile-manipulator-mpc_amd/synth.py"""
+    import mmpc_loader
+    return mmpc_loader.load().synth
+
 def riccati_flops_per_iter(N, nx, nu, M, nself):
     """Algorithmic flops of ONE interior-point iteration of the stage-wise (Riccati) KKT
     factorisation, dense-block convention: per stage
@@ -86,7 +92,7 @@ def main():
     import torch
     import mmpc_loader
     mm = mmpc_loader.load()
-    from oracle import synth
+    synth = _synth()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -519,7 +525,7 @@ def stream_of_batches_extra(mm, robot, dev, local_dev, seed0, N, M, B, nu, xlim,
     """Eight different seeded batches solved in a stream, `rounds` times over: plain (one launch per batch, a-priori order) and
     with the iteration budget + pipelined continuation (as the multi-rank runs use it).  Every output is checked for status 0."""
     import torch
-    from oracle import synth
+    synth = _synth()
     data = []
     for q in range(nseeds):
         d = synth.make_batch(B, N=N, M=M, config_id=seed0 + q)
@@ -561,7 +567,7 @@ def stream_of_batches_extra(mm, robot, dev, local_dev, seed0, N, M, B, nu, xlim,
 def c1_shape_extra(mm, robot, dev, B=2048, N=20):
     """Generic kernel on the demo's shape (starts as in tests/test_gpu_certificates.py::test_as_written_halfspace_rows_batch)."""
     import torch
-    from oracle import synth
+    synth = _synth()
     x, tr, obs, hs = synth.make_c1_starts(B, N)
     oml = [(h[:3], h[3:].reshape(1, 3)) for h in hs]
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
@@ -682,7 +688,7 @@ def run_c5(args, torch, mm, dist, rank, world, dev, local_dev, steps, warmup, cp
     (seed 5 + rank), strong: one population of `--batch` robots in contiguous slices -, every rank keeps its slice of u_latest
     and of the robots' states resident, and the one exchange per tick is the all-gather of the first inputs u0 the closed loop
     applies (5 doubles per robot), asynchronous: it travels while the next tick is solved."""
-    from oracle import synth
+    synth = _synth()
     from mmpc_amd import sharding
     N, M, T = 30, 8, args.ticks
     Bg = args.batch * (world if args.scaling == "weak" else 1)

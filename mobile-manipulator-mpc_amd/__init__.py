@@ -18,10 +18,11 @@ from .controllers.mpc_wholebody_qref import MPCWholeBody
 from .controllers.mpc_base import MPCBase
 from .controllers.mpc_wholebody import MPCWholeBody as MPCWholeBodyPoseRef
 from . import _capi
+from . import synth
 from . import interface_wholebody_qref
 from .interface_wholebody_qref import BatchedRecedingHorizon, Interface
 from .fleet import DeviceFleet
 from .build import build_extension
 
 __all__ = ["Obstacles", "Base", "ManipulatorPanda3DoF", "MobileManipulator", "MPCWholeBody", "MPCBase", "MPCWholeBodyPoseRef",
-           "build_extension", "_capi", "BatchedRecedingHorizon", "Interface", "interface_wholebody_qref", "DeviceFleet"]
+           "build_extension", "_capi", "BatchedRecedingHorizon", "Interface", "interface_wholebody_qref", "DeviceFleet", "synth"]

@@ -6,7 +6,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(CSRC, "libmmpc.so")
 SOURCES = ["mmpc_hip.hip"]
-HEADERS = ["mmpc_core.h", "mmpc_tile.h", "mmpc_fast.h", "mmpc_ik.h", os.path.join("..", "..", "include", "mmpc.h")]
+HEADERS = ["mmpc_core.h", "mmpc_tile.h", "mmpc_fast.h", "mmpc_fast_iter.inc", "mmpc_fast_a1r.inc", "mmpc_fast_a1s.inc", "mmpc_fast_d2.inc", "mmpc_ik.h", os.path.join("..", "..", "include", "mmpc.h")]
 
 
 def _stale():

@@ -130,7 +130,9 @@ struct MmpcParams {
 #define MMPC_IC_UP 4.0
 #define MMPC_IC_DN (1.0 / 3.0)
 // second-order corrections per iteration (IPOPT: max_soc = 4), tried where theta(x_k) <= theta_min
+#ifndef MMPC_SOC_MAX
 #define MMPC_SOC_MAX 2
+#endif
 #define MMPC_PROX_LO 0.05
 #define MMPC_PROX_MAX 1e4
 // multiplier safeguard (IPOPT eq. 16): z_i is kept within [mu / (kappa t_i), kappa mu / t_i] at every evaluation

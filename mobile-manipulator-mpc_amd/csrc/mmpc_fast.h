@@ -755,1051 +755,32 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
     };
 
     MMPC_T0()
-#pragma unroll 1
+    bool leave = false;
     for (;;) {
-        MMPC_TS(0)
-        // ============================================================ E1 (circle rows where RG lanes share a stage)
-        if (RG > 1 && M > 0) {
-            LANES_BEGIN
-            auto &ls = MMPC_LS;
-            double e_p = 0.0, tzmax = 0.0, tzmin = 1e300, zsum = 0.0, th = 0.0, rb0 = 0.0, rb1 = 0.0, rz = 0.0;
-            MmpcLogAcc la; la.init();
-            MMPC_ROW_LANE
-            if (rlane) {
-                const double px = XU[rk * NV], py = XU[rk * NV + 1], sk = S[rk];
-                double ob[MCR * 3];
-#pragma unroll
-                for (int r = 0; r < MCR; r++) {
-                    const double *o = obs_ptr(rk, rs + RG * r < M ? rs + RG * r : 0);
-                    ob[3 * r] = o[0]; ob[3 * r + 1] = o[1]; ob[3 * r + 2] = o[2];
-                }
-#pragma unroll
-                for (int r = 0; r < MCR; r++) {
-                    if (rs + RG * r < M) {
-                        const double dx = px - ob[3 * r], dy = py - ob[3 * r + 1], m2 = dx * dx + dy * dy, id = mmpc_rsqrt(m2), d = m2 * id;
-                        const double nxv = dx * id, nyv = dy * id;
-                        const double h = (ob[3 * r + 2] + MMPC_BASE_R) - d - sk;
-                        const double t = ls.ct[r], z = ls.cz[r];
-                        rb0 -= nxv * z; rb1 -= nyv * z; rz += z;
-                        e_p = mmpc_vmax(e_p, fabs(h + t)); th += fabs(h + t); la.mul(t);
-                        tzmax = mmpc_vmax(tzmax, t * z); tzmin = mmpc_vmin(tzmin, t * z); zsum += z;
-                    }
-                }
-                // the stage lane (rs = 0) keeps its sums in registers, the others hand theirs over through the stage's Hessian block
-                if (rs > 0) { double *cpo = HXX + rk * NXX + (rs - 1) * 3; cpo[0] = rb0; cpo[1] = rb1; cpo[2] = rz; }
-            }
-            ls.cp[0] = rb0; ls.cp[1] = rb1; ls.cp[2] = rz;
-            MMPC_WR(1) = e_p; MMPC_WR(2) = tzmax; MMPC_WR(3) = tzmin; MMPC_WR(4) = zsum; MMPC_WR(6) = th; MMPC_WR(7) = la.mant; MMPC_WR(0) = (double)la.ex;
-            LANES_END
-        }
-        // ============================================================ E1 (stage lanes)
-        LANES_BEGIN
-        auto &ls = MMPC_LS;
-        double e_p = 0.0, tzmax = 0.0, tzmin = 1e300, zsum = 0.0, zeq = 0.0, phi = 0.0, th = 0.0, slog = 0.0;
-        MmpcLogAcc la; la.init();
-        if (RG > 1 && M > 0) {
-            e_p = MMPC_WR(1); tzmax = MMPC_WR(2); tzmin = MMPC_WR(3); zsum = MMPC_WR(4); th = MMPC_WR(6); la.mant = MMPC_WR(7); la.ex = (int)MMPC_WR(0);
-        }
-        if (lane < NS) {
-            const int k = lane, k1 = k < N ? k + 1 : k;
-            // every LDS word of this stage first (the stores below would otherwise pin each later load behind them)
-            // (ob: the obstacles of this stage where the stage lane owns all circle rows, else the sums of the other lanes' rows)
-            double xk[NV], xn1[NX], ln[NX], rb[NV], ob[RG > 1 ? (RG - 1) * 3 : (MC > 0 ? MC : 1) * 3];
-#pragma unroll
-            for (int j = 0; j < NV; j++) { xk[j] = XU[k * NV + j]; rb[j] = 0.0; }
-#pragma unroll
-            for (int j = 0; j < NX; j++) { xn1[j] = XU[k1 * NV + j]; ln[j] = LAM[k1 * NX + j]; rb[j] = k >= 1 ? LAM[k * NX + j] : 0.0; }
-            if (RG > 1) {
-#pragma unroll
-                for (int q = 0; q < (RG - 1) * 3; q++) ob[q] = M > 0 ? HXX[k * NXX + q] : 0.0;
-            } else {
-#pragma unroll
-                for (int m = 0; m < M; m++) { const double *o = obs_ptr(k, m); ob[3 * m] = o[0]; ob[3 * m + 1] = o[1]; ob[3 * m + 2] = o[2]; }
-            }
-            const double sk = S[k], sks_ld = S[slack_idx(k)];
-            mmpc_sched_fence();
-            double sn, cs;
-            mmpc_sincos(xk[2], &sn, &cs);
-            double *cv = CV + k * MMPC_NCV;
-            if (k < N) {
-                const double *uk = xk + NX;
-                const double a32 = -dt * uk[0] * sn, a42 = dt * uk[0] * cs, a43 = dt * xk[5], a34 = -dt * xk[5],
-                             a35 = -dt * xk[4], a45 = dt * xk[3], b30 = dt * cs, b40 = dt * sn;
-                cv[0] = 0.0; cv[1] = 1.0; cv[2] = dt; cv[3] = a32; cv[4] = a42; cv[5] = a43; cv[6] = a34; cv[7] = a35;
-                cv[8] = a45; cv[9] = b30; cv[10] = b40;
-                double c[NX];
-                c[0] = xk[0] + dt * xk[3] - xn1[0]; c[1] = xk[1] + dt * xk[4] - xn1[1]; c[2] = xk[2] + dt * xk[5] - xn1[2];
-                c[3] = xk[3] + dt * (uk[0] * cs - xk[4] * xk[5]) - xn1[3];
-                c[4] = xk[4] + dt * (uk[0] * sn + xk[3] * xk[5]) - xn1[4];
-                c[5] = xk[5] + dt * uk[1] - xn1[5];
-                if (KIND == 0) { c[6] = xk[6] + dt * uk[2] - xn1[6]; c[7] = xk[7] + dt * uk[3] - xn1[7]; c[8] = xk[8] + dt * uk[4] - xn1[8]; }
-#pragma unroll
-                for (int j = 0; j < NX; j++) { CD[k * NX + j] = c[j]; e_p = mmpc_vmax(e_p, fabs(c[j])); th += fabs(c[j]); zeq += fabs(ln[j]); }
-                // - A^T lam_{k+1}, - B^T lam_{k+1}  (sparse, base.py:19-26)
-                rb[0] -= ln[0]; rb[1] -= ln[1];
-                rb[2] -= ln[2] + a32 * ln[3] + a42 * ln[4];
-                rb[3] -= ln[3] + dt * ln[0] + a43 * ln[4];
-                rb[4] -= ln[4] + dt * ln[1] + a34 * ln[3];
-                rb[5] -= ln[5] + dt * ln[2] + a35 * ln[3] + a45 * ln[4];
-                rb[NX + 0] -= b30 * ln[3] + b40 * ln[4];
-                rb[NX + 1] -= dt * ln[5];
-                if (KIND == 0) {
-                    rb[6] -= ln[6]; rb[7] -= ln[7]; rb[8] -= ln[8];
-                    rb[NX + 2] -= dt * ln[6]; rb[NX + 3] -= dt * ln[7]; rb[NX + 4] -= dt * ln[8];
-                }
-            }
-            double rds = 2 * Sw * sk, selfz = 0.0;
-            phi += Sw * sk * sk;
-            if (RG > 1 && M > 0) {   // circle rows of this stage: own rows first, then the other lanes' sums in lane order
-                double c0 = ls.cp[0], c1 = ls.cp[1], c2 = ls.cp[2];
-#pragma unroll
-                for (int g = 0; g < RG - 1; g++) { c0 += ob[3 * g]; c1 += ob[3 * g + 1]; c2 += ob[3 * g + 2]; }
-                rb[0] += c0; rb[1] += c1; rds -= c2;
-            }
-#pragma unroll
-            for (int m = 0; m < (RG > 1 ? 0 : M); m++) {
-                const double dx = xk[0] - ob[3 * m], dy = xk[1] - ob[3 * m + 1], m2 = dx * dx + dy * dy, id = mmpc_rsqrt(m2), d = m2 * id;
-                const double nxv = dx * id, nyv = dy * id;
-                const double h = (ob[3 * m + 2] + MMPC_BASE_R) - d - sk;
-                const double t = ls.ct[m], z = ls.cz[m];
-                rb[0] -= nxv * z; rb[1] -= nyv * z; rds -= z;
-                e_p = mmpc_vmax(e_p, fabs(h + t)); th += fabs(h + t); la.mul(t);
-                tzmax = mmpc_vmax(tzmax, t * z); tzmin = mmpc_vmin(tzmin, t * z); zsum += z;
-            }
-            if (NSELF) {
-                double dr[3], dz[3];
-                mmpc_arm_segments_fast(xk[NX - 3], xk[NX - 2], xk[NX - 1], dr, dz);
-                TRG[k * 8 + 0] = sn; TRG[k * 8 + 1] = cs;
-#pragma unroll
-                for (int a = 0; a < 3; a++) { TRG[k * 8 + 2 + a] = dr[a]; TRG[k * 8 + 5 + a] = dz[a]; }
-                const double sks = sks_ld;
-                double sw = 0.0, sit = 0.0, swr = 0.0, swg[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-                for (int i = 0; i < NSELF; i++) {
-                    double g6[6];
-                    const double h = mmpc_self_row(i, xk[0], xk[1], cs, sn, dr, dz, g6) - sks;
-                    const double t = ls.st[i], z = ls.sz[i];
-#pragma unroll
-                    for (int a = 0; a < 6; a++) rb[mmpc_y(a)] += g6[a] * z;
-                    selfz += z;
-                    e_p = mmpc_vmax(e_p, fabs(h + t)); th += fabs(h + t); la.mul(t);
-                    tzmax = mmpc_vmax(tzmax, t * z); tzmin = mmpc_vmin(tzmin, t * z); zsum += z;
-                    if (k == N) {
-                        const double it_ = mmpc_rcp(t), w = z * it_;
-                        sw += w; sit += it_; swr += w * (h + t);
-#pragma unroll
-                        for (int a = 0; a < 6; a++) swg[a] += w * g6[a];
-                    }
-                }
-                if (k == N) {   // terminal self rows belong to s_{N-1} (Q1): hand their sums to lane N-1
-                    SN[0] = sw; SN[1] = sit; SN[2] = swr; SN[3] = selfz;
-#pragma unroll
-                    for (int a = 0; a < 6; a++) SN[4 + a] = swg[a];
-                }
-            }
-            if (k < N) rds -= selfz;
-            RDS[k] = rds;
-#pragma unroll
-            for (int j = 0; j < NV; j++) RB[k * NV + j] = rb[j];
-        }
-        if (RG > 1 || lane < NS) slog = la.value();
-        MMPC_WR(1) = e_p; MMPC_WR(2) = tzmax; MMPC_WR(3) = tzmin; MMPC_WR(4) = zsum; MMPC_WR(5) = phi; MMPC_WR(6) = th; MMPC_WR(7) = slog;
-        MMPC_WR(8) = zeq;   // |multipliers of the dynamics|: s_d counts them, s_c does not
-        if (NSELF == 0 && lane == 0) { for (int a = 0; a < 10; a++) SN[a] = 0.0; }
-        LANES_END
-        MMPC_TS(1)
-        // ============================================================ E1 (pair lanes) + s residual
-        LANES_BEGIN
-        auto &ls = MMPC_LS;
-        double e_d = 0.0, e_p = MMPC_WR(1), tzmax = MMPC_WR(2), tzmin = MMPC_WR(3), zsum = MMPC_WR(4), phi = MMPC_WR(5), th = MMPC_WR(6);
-        MmpcLogAcc la; la.init();
-        // long horizons read the references and the previous inputs from HBM / L2: the loads of ALL passes ahead of the loop (one
-        // exposed round trip instead of one per pass - the scheduler fences below keep the compiler from doing that itself)
-        double g_ref[SLIM ? NPASS : 1], g_ul[SLIM ? NPASS : 1];
-        if (SLIM) {
-#pragma unroll
-            for (int p = 0; p < NPASS; p++) {
-                const int idx = lane + MMPC_WAVE * p, ii = idx < NPAIR ? idx : 0;
-                const int k = ii / NV, v = ii % NV;
-                const bool isu = v >= NX && k < N;
-                g_ref[p] = ref_at(ii, k, v);
-                g_ul[p] = ulast_at(isu ? k : 0, isu ? v - NX : 0);
-            }
-        }
-#pragma unroll
-        for (int p = 0; p < NPASS; p++) {
-            mmpc_sched_fence();
-            const int idx = lane + MMPC_WAVE * p;
-            if (idx < NPAIR) {
-                const int k = idx / NV, v = idx % NV;
-                const double lo = ls.b_lo[p], hi = ls.b_hi[p];
-                const bool alo = lo > -1e299, ahi = hi < 1e299;
-                // every LDS word this pair needs, ahead of the arithmetic and of the per-side blocks (one round trip per pass);
-                // the input-only terms read a valid dummy address for state variables and carry weight 0 there
-                const bool isu = v >= NX && k < N;
-                const int au = isu ? v - NX : 0;
-                const double val = XU[idx], ref = SLIM ? g_ref[SLIM ? p : 0] : ref_at(idx, k, v), rb0 = RB[idx];
-                const double ul = SLIM ? g_ul[SLIM ? p : 0] : ulast_at(isu ? k : 0, au), ww0 = CST[MMPC_C_WW + au];
-                const double wq = CST[v < NX ? (k < N ? MMPC_C_WQ : MMPC_C_WP) + v : MMPC_C_WR + v - NX];
-                mmpc_sched_fence();
-                // cost gradient / value (diagonal weights): mpc_wholebody_qref.py:192-201,240-242
-                double e = val - ref;
-                if (KIND == 1 && v == 2) e = mmpc_angle_diff(val, ref);
-                const double wqe = (v < NX || k < N) ? wq : 0.0, ww = isu ? ww0 : 0.0, e2 = val - ul;
-                double g = wqe * e + ww * e2;
-                phi += 0.5 * wqe * e * e + 0.5 * ww * e2 * e2;
-                double r = rb0 + g;
-                {   // both sides without branches: an absent side has z = 0 and is given t = 1 (log 1 = 0)
-                    const double tl = alo ? mmpc_box_t(val - lo) : 1.0, zl = ls.lo_z[p], th_ = ahi ? mmpc_box_t(hi - val) : 1.0, zh = ls.hi_z[p];
-                    const double pl = tl * zl, ph = th_ * zh;
-                    r += zh - zl; la.mul(tl); la.mul(th_);
-                    tzmax = mmpc_vmax(tzmax, mmpc_vmax(pl, ph));
-                    tzmin = mmpc_vmin(tzmin, mmpc_vmin(alo ? pl : 1e300, ahi ? ph : 1e300));
-                    zsum += zl + zh;
-                }
-                RB[idx] = g;   // keep the plain cost gradient for the assembly / directional derivative
-                const bool isvar = v < NX ? (k >= 1) : (k < N);
-                if (isvar) e_d = mmpc_vmax(e_d, fabs(r));
-            }
-        }
-        MMPC_WR(7) += la.value();   // sum of log t over all rows (the barrier term is applied after the mu update)
-        if (lane < NS) e_d = mmpc_vmax(e_d, fabs(RDS[lane] - (lane == N - 1 ? SN[3] : 0.0)));
-        MMPC_WR(0) = e_d; MMPC_WR(1) = e_p; MMPC_WR(2) = tzmax; MMPC_WR(3) = tzmin; MMPC_WR(4) = zsum; MMPC_WR(5) = phi; MMPC_WR(6) = th;
-        LANES_END
-        err_d = MMPC_RED_MAX(0); err_p = MMPC_RED_MAX(1); tzmax = MMPC_RED_MAX(2); tzmin = MMPC_RED_MIN(3);
-        zsum = MMPC_RED_SUM(4); cost_c = MMPC_RED_SUM(5); th_c = MMPC_RED_SUM(6); sumlog = MMPC_RED_SUM(7);
-        const double zeq_c = MMPC_RED_SUM(8);
-        if (in_ls) {
-            // ---- filter test of the trial point just evaluated (Waechter-Biegler; + filter reset heuristic)
-            const double phi = cost_c - mu * sumlog, th = th_c;
-            bool okf = th < th_max;
-            for (int i = 0; i < nfilt && okf; i++) if (th >= FILT[2 * i] && phi >= FILT[2 * i + 1]) okf = false;
-            const double a_t = soc_st == 2 ? alpha0 : alpha;   // (a corrected step is tested with the length of the step it corrects)
-            const bool ftype = dphi < 0 && th0 <= th_min && a_t * mmpc_powf(-dphi, 2.3f) > mmpc_powf(th0, 1.1f);
-            bool accepted = false, augment = false;
-            if (okf) {
-                if (ftype) accepted = phi <= phi0 + 1e-8 * a_t * dphi + 1e-14 * fabs(phi0);
-                else if (th <= (1 - 1e-5) * th0 || phi <= phi0 - 1e-5 * th0) { accepted = true; augment = true; }
-            }
-            if (augment) {
-                int slot = nfilt;
-                if (nfilt >= MMPC_FCAP) { slot = 0; for (int i = 1; i < MMPC_FCAP; i++) if (FILT[2 * i] > FILT[2 * slot]) slot = i; }
-                else nfilt++;
-                LANES_BEGIN
-                if (lane == 0) { FILT[2 * slot] = (1 - 1e-5) * th0; FILT[2 * slot + 1] = phi0 - 1e-5 * th0; }
-                LANES_END
-            }
-            if (soc_st == 2) {
-                if (accepted) { soc_st = 0; alpha = a_soc; }
-                else if (th > 0.99 * th_prev || soc_p + 1 >= MMPC_SOC_MAX) {
-                    // the correction failed: back to x_k, the uncorrected direction restored, evaluated there again (state 3)
-                    apply_step(-a_soc, false);
-                    soc_dir(false);
-                    soc_st = 3; in_ls = 0;
-                    continue;
-                } else {
-                    soc_rows(false, false);
-                    apply_step(-a_soc, false);
-                    soc_p++; a_prev = a_soc; th_prev = th; soc_st = 1; in_ls = 0;
-                    continue;
-                }
-            } else if (!accepted && MMPC_SOC_MAX > 0 && lsi == 0 && lspass == 0 && io.soc && th >= th0 && th0 <= th_min) {
-                // first trial rejected without reducing the infeasibility, theta(x_k) <= theta_min: second-order correction
-                soc_dir(true);
-                soc_rows(false, false);
-                apply_step(-alpha, false);
-                alpha0 = alpha; a_prev = alpha; th_prev = th; soc_p = 0; soc_st = 1; in_ls = 0;
-                continue;
-            }
-            if (!accepted) {
-                double anext = alpha;
-                bool retry = false;
-                if (lsi < MMPC_MAX_LS - 1) { anext = 0.5 * alpha; lsi++; retry = true; }
-                else if (lspass == 0 && nfilt > 0) { nfilt = 0; lspass = 1; lsi = 0; anext = ap; retry = true; }   // filter reset heuristic
-                if (retry) { apply_step(anext - alpha, false); alpha = anext; continue; }
-            }
-            in_ls = 0;   // accepted (or every trial rejected: the last one is kept, as IPOPT without restoration would stall too)
-            mmpc_prox_update(ap, alpha, prox, nsmall);
-            MMPC_TS(12)
-        }
-        if (soc_st == 1) soc_rows(true, soc_p == 0);
-        if (soc_st == 0) {
-        // IPOPT's termination test (Waechter & Biegler 2006, eq. 5-6): stationarity over s_d (all multipliers), complementarity over
-        // s_c (the row multipliers alone)
-        double sd = (zsum + zeq_c) * inv_rows, sc = zsum * inv_nrows;
-        sd = (sd > 100.0 ? sd : 100.0) * 0.01;
-        sc = (sc > 100.0 ? sc : 100.0) * 0.01;
-        const double isd = mmpc_rcp(sd), isc = mmpc_rcp(sc);
-        E0 = mmpc_vmax(mmpc_vmax(err_d * isd, err_p), tzmax * isc);
-        if (!mmpc_finite(E0) || !mmpc_finite(th_c + cost_c + zsum + zeq_c)) {   // NaN or inf anywhere in the point or its data (the sums carry them)
-#ifdef MMPC_EMU_DEBUG
-            fprintf(stderr, "E0 nan it %d: err_d %g err_p %g tzmax %g tzmin %g zsum %g sumlog %g\n", it, err_d, err_p, tzmax, tzmin, zsum, sumlog);
-#endif
-            status = 2; break; }
-        if (E0 <= tol) { status = 0; break; }
-        if (it == P.max_iter) break;
-        if (CONT && io.budget > 0 && it - it_start >= io.budget && io.state) {
-            // ---- iteration budget of this launch used up: park the solve (the point has just been evaluated and is not
-            //      converged; a resumed launch re-evaluates it and continues with the barrier update below)
-            double *const st_xu = io.state, *const st_s = io.state + ST_S, *const st_lam = io.state + ST_LAM,
-                   *const st_filt = io.state + ST_FILT, *const st_scal = io.state + ST_SCAL, *const st_lane = io.state + ST_LANE;
-            LANES_BEGIN
-            auto &ls = MMPC_LS;
-            for (int i = lane; i < NPAIR; i += MMPC_WAVE) st_xu[i] = XU[i];
-            for (int i = lane; i < NS; i += MMPC_WAVE) st_s[i] = S[i];
-            for (int i = lane; i < NS * NX; i += MMPC_WAVE) st_lam[i] = LAM[i];
-            for (int i = lane; i < 2 * MMPC_FCAP; i += MMPC_WAVE) st_filt[i] = i < 2 * nfilt ? FILT[i] : 0.0;
-            double *q = st_lane + lane * NLREG;
-#pragma unroll
-            for (int p = 0; p < NPASS; p++) { q[p] = ls.lo_z[p]; q[NPASS + p] = ls.hi_z[p]; }
-#pragma unroll
-            for (int m = 0; m < MCR; m++) { q[2 * NPASS + m] = ls.ct[m]; q[2 * NPASS + MCS + m] = ls.cz[m]; }
-#pragma unroll
-            for (int i = 0; i < 4; i++) { q[2 * NPASS + 2 * MCS + i] = ls.st[i]; q[2 * NPASS + 2 * MCS + 4 + i] = ls.sz[i]; }
-            if (lane == 0) {
-                st_scal[0] = mu; st_scal[1] = th_max; st_scal[2] = th_min; st_scal[3] = prox;
-                st_scal[4] = (double)it; st_scal[5] = (double)nfilt; st_scal[6] = (double)filt_init; st_scal[7] = (double)nsmall; st_scal[8] = delta_last;
-            }
-            LANES_END
-            status = 3;   // MMPC_STATUS_SUSPENDED
-            break;
-        }
-        {
-            bool changed = false;
-            for (;;) {
-                const double compmu = mmpc_vmax(fabs(tzmax - mu), fabs(tzmin - mu));
-                const double Emu = mmpc_vmax(mmpc_vmax(err_d * isd, err_p), compmu * isc);
-                if (!(Emu <= 10.0 * mu && mu > tol / 10)) break;
-                mu = mmpc_vmax(tol / 10, mmpc_vmin(0.2 * mu, mu * sqrt(mu)));
-                changed = true;
-            }
-            if (changed) filt_init = 0;
-        }
-        phi0 = cost_c - mu * sumlog;   // barrier objective at the current point for the (possibly new) mu
-        th0 = th_c;
-        }   // soc_st == 0
-
-        MMPC_TS(2)
-        // ============================================================ Newton direction
-        int failed = 0;
-        double dw = 0.0;
-        if (soc_st != 3) {   // (after a failed correction only the row steps D2 are formed again: the direction is back from io.soc)
+        bool soc_enter = false;
 #pragma unroll 1
-        // (exact Lagrangian Hessian, + delta_w I by IPOPT's inertia correction where a pivot of the recursion is not positive - see mmpc_core.h)
         for (;;) {
-            constexpr bool exact = true, dyn_curv = true;
-            const double reg = prox + dw;
-            int ric_bad = 0;   // a pivot of this pass was not positive (every lane factorises the same matrix: uniform)
-            // ---- A1 (circle rows where RG lanes share a stage): w g g^T (+ exact curvature), gradient and s_k coupling of the
-            //      lane's rows: cp = (Hxx, Hxy, Hyy, qx, qy, h_ss, g_ss, vx, vy)
-            auto a1_rows = [&](auto TAG) {
-            constexpr bool socm = decltype(TAG)::value; (void)socm;
-            if (RG > 1 && M > 0) {
-                LANES_BEGIN
-                auto &ls = MMPC_LS;
-                MMPC_ROW_LANE
-                double cp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-                if (rlane) {
-                    const double px = XU[rk * NV], py = XU[rk * NV + 1], sk = S[rk];
-                    double ob[MCR * 3];
-#pragma unroll
-                    for (int r = 0; r < MCR; r++) {
-                        const double *o = obs_ptr(rk, rs + RG * r < M ? rs + RG * r : 0);
-                        ob[3 * r] = o[0]; ob[3 * r + 1] = o[1]; ob[3 * r + 2] = o[2];
-                    }
-#pragma unroll
-                    for (int r = 0; r < MCR; r++) {
-                        if (rs + RG * r < M) {
-                            const double ddx = px - ob[3 * r], ddy = py - ob[3 * r + 1], m2 = ddx * ddx + ddy * ddy, id = mmpc_rsqrt(m2), d = m2 * id;
-                            const double g0 = -ddx * id, g1 = -ddy * id, hv = (ob[3 * r + 2] + MMPC_BASE_R) - d - sk;
-                            const double t = ls.ct[r], z = ls.cz[r], it_ = mmpc_rcp(t), w = z * it_;
-                            double res = hv + t;
-                            if constexpr (socm) res = io.soc[O_AR + rk * NRS + rs + RG * r];   // corrected pass: (h + t)_soc
-                            const double zh = mu * it_ + w * res;
-                            cp[0] += w * g0 * g0; cp[1] += w * g1 * g0; cp[2] += w * g1 * g1;
-                            if (exact) { const double zi = z * id; cp[0] -= zi * (1 - g0 * g0); cp[1] += zi * g0 * g1; cp[2] -= zi * (1 - g1 * g1); }
-                            cp[3] += g0 * zh; cp[4] += g1 * zh;
-                            cp[5] += w; cp[6] -= zh; cp[7] += w * g0; cp[8] += w * g1;
-                        }
-                    }
-                    if (rs > 0) {
-                        double *cpo = HXX + rk * NXX + (rs - 1) * 9;
-#pragma unroll
-                        for (int q = 0; q < 9; q++) cpo[q] = cp[q];
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < 9; q++) ls.cp[q] = cp[q];
-                LANES_END
-            }
-            };
-            if (soc_st == 1) a1_rows(MmpcTag<true>{}); else a1_rows(MmpcTag<false>{});
-            // ---- A1 (stage lanes): stage Hessian incl. elimination of s_k
-            auto a1_stage = [&](auto TAG) {
-            constexpr bool socm = decltype(TAG)::value; (void)socm;
-            LANES_BEGIN
-            auto &ls = MMPC_LS;
-            if (lane < NS) {
-                const int k = lane, k1 = k < N ? k + 1 : k;
-                // every LDS word of this stage first (one round trip instead of one per block below)
-                double hxx[NXX], qx[NX], wd[NX], ob[RG > 1 ? (RG - 1) * 9 : (MC > 0 ? MC : 1) * 3];   // (ob: as in the evaluation)
-#pragma unroll
-                for (int j = 0; j < NX; j++) { wd[j] = CST[(k < N ? MMPC_C_WQ : MMPC_C_WP) + j]; qx[j] = RB[k * NV + j]; }
-                const double *cv = CV + k * MMPC_NCV;
-                const double l3 = LAM[k1 * NX + 3], l4 = LAM[k1 * NX + 4], cv3 = cv[3], cv4 = cv[4], cv9 = cv[9], cv10 = cv[10];
-                const double px = XU[k * NV], py = XU[k * NV + 1], sk = S[k], sks = S[slack_idx(k)];
-                if (RG > 1) {
-#pragma unroll
-                    for (int q = 0; q < (RG - 1) * 9; q++) ob[q] = M > 0 ? HXX[k * NXX + q] : 0.0;
-                } else {
-#pragma unroll
-                    for (int m = 0; m < M; m++) { const double *o = obs_ptr(k, m); ob[3 * m] = o[0]; ob[3 * m + 1] = o[1]; ob[3 * m + 2] = o[2]; }
-                }
-                double sn = 0.0, cs = 0.0, dr[3] = {0, 0, 0}, dz[3] = {0, 0, 0};
-                if (NSELF) {
-                    sn = TRG[k * 8]; cs = TRG[k * 8 + 1];
-#pragma unroll
-                    for (int a = 0; a < 3; a++) { dr[a] = TRG[k * 8 + 2 + a]; dz[a] = TRG[k * 8 + 5 + a]; }
-                }
-                mmpc_sched_fence();
-#pragma unroll
-                for (int e = 0; e < NXX; e++) hxx[e] = 0.0;
-#pragma unroll
-                for (int j = 0; j < NX; j++) hxx[j * (j + 1) / 2 + j] = wd[j] + reg;
-                double h02 = 0.0;
-                if (k < N && dyn_curv) {
-                    hxx[5] += l3 * cv4 - l4 * cv3;
-                    hxx[19] += dt * l3;
-                    hxx[18] -= dt * l4;
-                    h02 = -(-l3 * cv10 + l4 * cv9);
-                }
-                double hss = 2 * Sw, gss = 2 * Sw * sk, vx[6] = {0, 0, 0, 0, 0, 0};
-                if (RG > 1 && M > 0) {   // circle rows: own lane's sums first, then the other lanes' in lane order
-#pragma unroll
-                    for (int q = 0; q < 9; q++) {
-                        double c = ls.cp[q];
-#pragma unroll
-                        for (int g = 0; g < RG - 1; g++) c += ob[9 * g + q];
-                        if (q < 3) hxx[q] += c; else if (q < 5) qx[q - 3] += c; else if (q == 5) hss += c; else if (q == 6) gss += c; else vx[q - 7] += c;
-                    }
-                }
-#pragma unroll
-                for (int m = 0; m < (RG > 1 ? 0 : M); m++) {
-                    // row geometry is re-derived from x_k (cheaper than keeping it in registers)
-                    const double *o = ob + 3 * m;
-                    const double ddx = px - o[0], ddy = py - o[1], m2 = ddx * ddx + ddy * ddy, id = mmpc_rsqrt(m2), d = m2 * id;
-                    const double g0 = -ddx * id, g1 = -ddy * id, hv = (o[2] + MMPC_BASE_R) - d - sk;
-                    const double t = ls.ct[m], z = ls.cz[m], it_ = mmpc_rcp(t), w = z * it_;
-                    double res = hv + t;
-                    if constexpr (socm) res = io.soc[O_AR + k * NRS + m];   // corrected pass: (h + t)_soc
-                    const double zh = mu * it_ + w * res;
-                    hxx[0] += w * g0 * g0; hxx[1] += w * g1 * g0; hxx[2] += w * g1 * g1;
-                    if (exact) { const double zi = z * id; hxx[0] -= zi * (1 - g0 * g0); hxx[1] += zi * g0 * g1; hxx[2] -= zi * (1 - g1 * g1); }
-                    qx[0] += g0 * zh; qx[1] += g1 * zh;
-                    hss += w; gss -= zh; vx[0] += w * g0; vx[1] += w * g1;
-                }
-                if (NSELF) {
-#pragma unroll
-                    for (int i = 0; i < NSELF; i++) {
-                        double g6[6];
-                        const double hv = mmpc_self_row(i, px, py, cs, sn, dr, dz, g6) - sks;
-                        const double t = ls.st[i], z = ls.sz[i], it_ = mmpc_rcp(t), w = z * it_;
-                        double res = hv + t;
-                        if constexpr (socm) res = io.soc[O_AR + k * NRS + M + i];
-                        const double zh = mu * it_ + w * res;
-                        // (the terminal stage's self rows belong to s_{N-1}, quirk Q1: they do not enter this lane's s_k block)
-                        const double wk = k < N ? w : 0.0, zhk = k < N ? zh : 0.0;
-#pragma unroll
-                        for (int a = 0; a < 6; a++) {
-                            const double wa = w * g6[a];
-#pragma unroll
-                            for (int b = 0; b <= a; b++) hxx[mmpc_y(a) * (mmpc_y(a) + 1) / 2 + mmpc_y(b)] += wa * g6[b];
-                            qx[mmpc_y(a)] += g6[a] * zh;
-                            vx[a] += wk * g6[a];
-                        }
-                        hss += wk; gss -= zhk;
-                    }
-                }
-                // Q1: terminal self rows -> s_{N-1}.  a = v + A^T vN, b = B^T vN, gamma = g_s - vN.c.  Lane N-1 publishes
-                // (a, b, gamma, 1/h_ss); the dense rank-one blocks are applied by all lanes in the next phase, so this lane
-                // stores its blocks WITHOUT the elimination of s (weight 0 below; one store sequence for every lane)
-                const bool q1 = NSELF && k == N - 1;
-                if (q1) {
-                    const double hssN = SN[0], gssN = -(mu * SN[1] + SN[2]);
-                    hss += hssN; gss += gssN;
-                }
-                const double ih = mmpc_rcp(hss), ihs = q1 ? 0.0 : ih;
-                if (!NSELF && k == N - 1) {
-                    for (int c = 0; c < NU * NX; c++) HUXL[c] = 0.0;
-                    for (int c = 0; c < NUU; c++) HUUL[c] = 0.0;
-                }
-                {
-                    constexpr int ny = NSELF ? 6 : 2;
-#pragma unroll
-                    for (int a = 0; a < ny; a++) {
-#pragma unroll
-                        for (int b = 0; b <= a; b++) hxx[mmpc_y(a) * (mmpc_y(a) + 1) / 2 + mmpc_y(b)] -= vx[a] * vx[b] * ihs;
-                        qx[mmpc_y(a)] += vx[a] * gss * ihs;
-                    }
-                    if (k < N) {
-#pragma unroll
-                        for (int c = 0; c < NU; c++) QXU[k * NV + NX + c] = RB[k * NV + NX + c];
-                    }
-#pragma unroll
-                    for (int e = 0; e < NXX; e++) HXX[k * NXX + e] = hxx[e];
-#pragma unroll
-                    for (int j = 0; j < NX; j++) QXU[k * NV + j] = qx[j];
-                }
-                if (q1) {
-                    double vf[NX], a[NX], b[NU];
-#pragma unroll
-                    for (int j = 0; j < NX; j++) { vf[j] = 0.0; a[j] = 0.0; }
-#pragma unroll
-                    for (int q = 0; q < 6; q++) { vf[mmpc_y(q)] = SN[4 + q]; a[mmpc_y(q)] = vx[q]; }
-                    const double *cv = CV + k * MMPC_NCV;
-                    a[0] += vf[0]; a[1] += vf[1];
-                    a[2] += vf[2] + cv[3] * vf[3] + cv[4] * vf[4];
-                    a[3] += vf[3] + dt * vf[0] + cv[5] * vf[4];
-                    a[4] += vf[4] + dt * vf[1] + cv[6] * vf[3];
-                    a[5] += vf[5] + dt * vf[2] + cv[7] * vf[3] + cv[8] * vf[4];
-                    b[0] = cv[9] * vf[3] + cv[10] * vf[4];
-                    b[1] = dt * vf[5];
-                    if (KIND == 0) { a[6] += vf[6]; a[7] += vf[7]; a[8] += vf[8]; b[2] = dt * vf[6]; b[3] = dt * vf[7]; b[4] = dt * vf[8]; }
-                    double gam = gss;
-#pragma unroll
-                    for (int j = 0; j < NX; j++) gam -= vf[j] * CD[k * NX + j];
-#pragma unroll
-                    for (int j = 0; j < NX; j++) Q1V[j] = a[j];
-#pragma unroll
-                    for (int c = 0; c < NU; c++) Q1V[NX + c] = b[c];
-                    Q1V[NV] = gam * ih; Q1V[NV + 1] = ih;
-                }
-                ls.hss = hss; ls.gss = gss;
-#pragma unroll
-                for (int a = 0; a < 6; a++) ls.vx[a] = vx[a];
-                HUX02[k] = h02;
-#pragma unroll
-                for (int c = 0; c < NU; c++) HUUD[k * NU + c] = CST[MMPC_C_RW2 + c * NU + c] + reg;
-            }
-            LANES_END
-            };
-            if (soc_st == 1) a1_stage(MmpcTag<true>{}); else a1_stage(MmpcTag<false>{});
-            if (NSELF) {
-                // ---- dense rank-one blocks of stage N-1 (the elimination of s_{N-1} reaches x_N through the dynamics):
-                //      Hxx -= a a^T/h, Hux = -b a^T/h, Huu = -b b^T/h, q += (a; b) gamma/h
-                LANES_BEGIN
-                const double ih = Q1V[NV + 1], gih = Q1V[NV];
-                for (int e = lane; e < NXX + NU * NX + NUU + NV; e += MMPC_WAVE) {
-                    if (e < NXX) {
-                        int i = 0;
-                        while ((i + 1) * (i + 2) / 2 <= e) i++;
-                        const int j = e - i * (i + 1) / 2;
-                        HXX[(N - 1) * NXX + e] -= Q1V[i] * Q1V[j] * ih;
-                    } else if (e < NXX + NU * NX) {
-                        const int c = (e - NXX) / NX, j = (e - NXX) % NX;
-                        HUXL[c * NX + j] = -Q1V[NX + c] * Q1V[j] * ih;
-                    } else if (e < NXX + NU * NX + NUU) {
-                        const int q = e - NXX - NU * NX;
-                        int c = 0;
-                        while ((c + 1) * (c + 2) / 2 <= q) c++;
-                        const int d2 = q - c * (c + 1) / 2;
-                        HUUL[q] = -Q1V[NX + c] * Q1V[NX + d2] * ih;
-                    } else {
-                        const int j = e - NXX - NU * NX - NUU;
-                        QXU[(N - 1) * NV + j] += Q1V[j] * gih;
-                    }
-                }
-                LANES_END
-            }
-            MMPC_TS(3)
-            // ---- A1 (pair lanes): barrier terms of the box rows (diagonal entries, unique owners)
-            LANES_BEGIN
-            auto &ls = MMPC_LS;
-#pragma unroll
-            for (int p = 0; p < NPASS; p++) {
-                mmpc_sched_fence();
-                const int idx = lane + MMPC_WAVE * p;
-                if (idx < NPAIR) {
-                    const int k = idx / NV, v = idx % NV;
-                    const double lo = ls.b_lo[p], hi = ls.b_hi[p];
-                    const bool alo = lo > -1e299, ahi = hi < 1e299;
-                    // the diagonal Hessian entry this pair owns (state: HXX[k] diagonal, input: HUUD[k]); loads first
-                    double *hd = v < NX ? HXX + k * NXX + v * (v + 1) / 2 + v : HUUD + (k < N ? k : 0) * NU + v - NX;
-                    const double val = XU[idx], q0 = QXU[idx], h0 = *hd;
-                    mmpc_sched_fence();
-                    double wsum = 0.0, gsum = 0.0;
-                    if (alo) { const double it_ = mmpc_rcp(mmpc_box_t(val - lo)); wsum += ls.lo_z[p] * it_; gsum -= mu * it_; }
-                    if (ahi) { const double it_ = mmpc_rcp(mmpc_box_t(hi - val)); wsum += ls.hi_z[p] * it_; gsum += mu * it_; }
-                    if (alo || ahi) { QXU[idx] = q0 + gsum; *hd = h0 + wsum; }
-                }
-            }
-            LANES_END
-            MMPC_TS(4)
-            // ---- R0: terminal cost-to-go [P_N p_N; p_N^T .] = stage-N Hessian and gradient, in accumulator layout;
-            //      operands of stage N-1: rAB = homogeneous dynamics rows 4r+g, rM = stage matrix (accumulator input)
-            LANES_BEGIN
-            auto &ls = MMPC_LS;
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const unsigned o = ls.h_o[r];
-                ls.rP[r] = ((ls.h_m >> r) & 1u) ? lds[(o & 0xffffu) + N * (int)(o >> 16)] : 0.0;
-                ls.rM[r] = lds[(o & 0xffffu) + (N - 1) * (int)(o >> 16)] + lds[ls.h_l[r]];
-            }
-#pragma unroll
-            for (int r = 0; r < NKB; r++) { const unsigned o = ls.ab_o[r]; ls.rAB[r] = lds[(o & 0xffffu) + (N - 1) * (int)(o >> 16)]; }
-            LANES_END
-#pragma unroll RIC_UNROLL
-            for (int k = N - 1; k >= 0; k--) {
-                MMPC_TS(5)
-                if (ric_bad) break;   // (uniform: every lane factorises the same matrix) the pass is redone one rung down
-                // R1: T = [P p; p^T .] [A B c; 0 0 1]   (symmetric: its accumulator registers are the A operand; the affine
-                // part rides along as row / column NX, so the chain starts from a zero accumulator)
-                MMPC_MFMA0(rT, ls.rP[0], ls.rAB[0])
-                MMPC_MFMA(rT, ls.rP[1], ls.rAB[1])
-                if (NKB > 2) MMPC_MFMA(rT, ls.rP[NKB > 2 ? 2 : 0], ls.rAB[NKB > 2 ? 2 : 0])
-                // R2: M = [A B c; 0 0 1]^T T + stage matrix  ->  [F gx G^T; gx^T . gu^T; G gu Hh]
-                MMPC_MFMA(rM, ls.rAB[0], ls.rT[0])
-                MMPC_MFMA(rM, ls.rAB[1], ls.rT[1])
-                if (NKB > 2) MMPC_MFMA(rM, ls.rAB[NKB > 2 ? 2 : 0], ls.rT[NKB > 2 ? 2 : 0])
-                MMPC_TS(6)
-                // operands of the next stage travel while this one eliminates its inputs
-                LANES_BEGIN
-                auto &ls = MMPC_LS;
-                if (k > 0) {
-#pragma unroll
-                    for (int r = 0; r < NKB; r++) { const unsigned o = ls.ab_o[r]; ls.nab[r] = lds[(o & 0xffffu) + (k - 1) * (int)(o >> 16)]; }
-#pragma unroll
-                    for (int r = 0; r < 4; r++) { const unsigned o = ls.h_o[r]; ls.nhm[r] = lds[(o & 0xffffu) + (k - 1) * (int)(o >> 16)]; }
-                }
-                LANES_END_REG
-                // R3: the inputs are eliminated ON the tile (block L D L^T = Schur complement).  For input a with pivot row
-                // c = M[NX+1+a][.] and pivot d = c[NX+1+a] > 0,  M <- M - c c^T / d  is one rank-one MFMA whose only non-zero
-                // K-slot is supplied by the lane group that already holds the row in its accumulator (row index mod 4 = lane
-                // group = K-slot: no LDS exchange).  Two inputs whose rows sit in neighbouring lane groups of the same
-                // accumulator register go together (one MFMA with two K-slots: the serial chain accumulator -> pivot ->
-                // reciprocal -> MFMA is what a stage costs): M <- M - c0 c0^T / d0 - c1' c1'^T / d1 with c1' = c1 - (d01/d0) c0,
-                // the second group fetching its partner's row entry from lane ^ 16.  What is left in rows / columns (x, 1) after the
-                // last input is [P_k p_k; p_k^T .].  The normalised rows c / d are kept: u_a = -(c/d) . (dx, 1,
-                // u_b>a), from which the gains are formed for all stages at once after the pass.
-                constexpr bool PAIRS = F::PAIRS;                          // first input row even -> rows (2q, 2q+1) share a register
-                constexpr int NLEG = F::NLEG;
-#pragma unroll
-                for (int leg = 0; leg < NLEG; leg++) {
-                    LANES_BEGIN
-                    auto &ls = MMPC_LS;
-                    const int a0 = PAIRS ? 2 * leg : leg;
-                    const bool pair = PAIRS && a0 + 1 < NU;
-                    const int ta = NX + 1 + a0, ra = ta >> 2, ga = ta & 3, g = lane >> 4;
-                    const double c = ls.rM[ra];
-                    double w, cb = c;
-                    bool own;
-                    if (pair) {
-                        const double d00 = MMPC_LANE_GET(rM[ra], 16 * ga + ta), d01 = MMPC_LANE_GET(rM[ra], 16 * ga + ta + 1),
-                                     d11 = MMPC_LANE_GET(rM[ra], 16 * (ga + 1) + ta + 1);
-                        // the two pivots of the pair in sequence (same arithmetic as two rank-one steps: l = d01 / d00, second
-                        // pivot d1 = d11 - l d01, second row c1 - l c0), applied as the two K-slots of ONE MFMA
-                        const double i0 = mmpc_rcp3(d00), l = d01 * i0, d1 = fma(-l, d01, d11);
-                        if (!(d00 > 0.0 && d1 > 0.0)) ric_bad = 1;   // (NaN fails too) the pass stops at the next stage, redone one rung down
-                        const double i1 = mmpc_rcp3(d1), co = MMPC_LANE_XOR16(rM[ra]);
-                        const bool in1 = g == ga + 1;
-                        own = g == ga || in1;
-                        // (the exchanged value is used by EVERY lane, with a zero multiplier where it does not apply: written as
-                        //  in1 ? fma(-l, co, c) : c the compiler may sink the cross-lane operation under the lane-dependent branch,
-                        //  where it reads inactive lanes - seen with a four-input variant of this leg)
-                        cb = fma(in1 ? -l : 0.0, co, c);
-                        w = cb * (in1 ? i1 : i0);
-                    } else {
-                        const double d = MMPC_LANE_GET(rM[ra], 16 * ga + ta);
-                        if (!(d > 0.0)) ric_bad = 1;
-                        own = g == ga;
-                        w = c * mmpc_rcp3(d);
-                    }
-                    ls.opa = own ? -w : 0.0;
-                    ls.opb = own ? cb : 0.0;
-                    // (lanes that hold no entry of the row write to their dump slot - no branch; MMPC_GK_MASK: masked instead, see there)
-                    if (!(GK && MMPC_GK_MASK) || ls.kl_s[leg] != 0)
-                        *(double *)((char *)KBASE + (unsigned)(ls.kl_b[leg] + MMPC_MUL24(k, ls.kl_s[leg]))) = w;
-                    LANES_END_REG
-                    MMPC_MFMA(rM, ls.opa, ls.opb)
-                }
-                MMPC_TS(7)
-                LANES_BEGIN
-                auto &ls = MMPC_LS;
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    ls.rP[r] = ls.rM[r];
-                    const unsigned o = ls.p_o[r];   // (entries that are not stored go to a dump slot: no branch)
-                    lds[(o & 0xffffu) + k * (int)(o >> 16)] = ls.rM[r];
-                    ls.rM[r] = ls.nhm[r];
-                }
-#pragma unroll
-                for (int r = 0; r < NKB; r++) ls.rAB[r] = ls.nab[r];
-                LANES_END
-            }
-            if (ric_bad) failed = 1;
-            if (!failed) { if (dw > 0.0) delta_last = dw; break; }
-            dw = dw == 0.0 ? (delta_last == 0.0 ? MMPC_IC_D0 : mmpc_vmax(1e-20, MMPC_IC_DN * delta_last)) : MMPC_IC_UP * dw;
-            if (dw > 1e40) break;
-            failed = 0;
+#define MMPC_ITER_SOC 0
+#define MMPC_ITER_LEAVE { leave = true; break; }
+#include "mmpc_fast_iter.inc"
+#undef MMPC_ITER_SOC
         }
-        if (failed) {
-#ifdef MMPC_EMU_DEBUG
-            fprintf(stderr, "riccati failed twice it %d\n", it);
-#endif
-            status = 2; fatal = 1; }
-        if (!fatal) {
-        // ---- gains of all stages from the normalised pivot rows, by back-substitution over the inputs (the last eliminated
-        //      input depends on x only): K_a = -(w_a[x,1] + sum_{b>a} w_a[u_b] K_b), in place, one lane per (stage, column)
-        if (GK) MMPC_GFENCE();   // the legs' stores to the gain block are read by other lanes
-        LANES_BEGIN
-        {
-            // two (stage, column) items per lane at a time, the loads of both ahead of the arithmetic: the update is in place, so the
-            // compiler cannot move the loads of one item above the stores of the one before
-            constexpr int NITEM = N * (NX + 1), NTRIP = (NITEM + MMPC_WAVE - 1) / MMPC_WAVE;
-            // entry (stage, input, column) of [K_k | kf_k]; in the gain block one access with a selected offset (a select between two
-            // global accesses becomes a branch per access)
-            auto kref = [&](int kq, int a, int jq) -> double & {
-                if constexpr (GK) return gk(io.gscr, jq < NX ? GB::KK + (kq * NU + a) * NX + jq : GB::KF + kq * NU + a);
-                else return jq < NX ? KK[(kq * NU + a) * NX + jq] : KF[kq * NU + a];
-            };
-            // (gain block in global memory: the loads of half of the lane's items ahead of their arithmetic - two exposed round trips to L2
-            //  instead of one per pair of items)
-            constexpr int TSTEP = GK ? (NTRIP + 1) / 2 : 2;
-#pragma unroll
-            for (int t0 = 0; t0 < NTRIP; t0 += TSTEP) {
-                double kv[TSTEP][NU], cu[TSTEP][NPU > 0 ? NPU : 1];
-                int kk[TSTEP], jj[TSTEP];
-                bool ok[TSTEP];
-#pragma unroll
-                for (int u = 0; u < TSTEP; u++) {
-                    const int i = lane + MMPC_WAVE * (t0 + u);
-                    ok[u] = t0 + u < NTRIP && i < NITEM;
-                    const int ii = ok[u] ? i : 0;
-                    kk[u] = ii / (NX + 1); jj[u] = ii % (NX + 1);
-#pragma unroll
-                    for (int a = 0; a < NU; a++) kv[u][a] = kref(kk[u], a, jj[u]);
-#pragma unroll
-                    for (int q = 0; q < NPU; q++) cu[u][q] = gk(KU, kk[u] * NPU + q);
-                }
-#pragma unroll
-                for (int u = 0; u < TSTEP; u++) {
-#pragma unroll
-                    for (int a = NU - 1; a >= 0; a--) {
-                        double v = kv[u][a];
-#pragma unroll
-                        for (int b2 = a + 1; b2 < NU; b2++) v += cu[u][a * (2 * NU - a - 1) / 2 + (b2 - a - 1)] * kv[u][b2];
-                        kv[u][a] = -v;
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < TSTEP; u++) {
-                    if (ok[u]) {
-#pragma unroll
-                        for (int a = 0; a < NU; a++) kref(kk[u], a, jj[u]) = kv[u][a];
-                    }
-                }
-            }
+        if (leave || !soc_enter) break;
+        // ---- a second-order correction starts: the uncorrected direction and the residuals of the rejected trial go to io.soc,
+        //      the point moves back to x_k (state 1)
+        soc_dir(true);
+        soc_rows(false, false);
+        apply_step(-alpha, false);
+        alpha0 = alpha; a_prev = alpha; soc_p = 0; soc_st = 1; in_ls = 0;
+#pragma unroll 1
+        for (;;) {
+            if (soc_st == 0) break;   // the correction is over (accepted, or the line search is back on the uncorrected direction)
+#define MMPC_ITER_SOC 1
+#include "mmpc_fast_iter.inc"
+#undef MMPC_ITER_SOC
+#undef MMPC_ITER_LEAVE
         }
-        LANES_END
-        if (GK) MMPC_GFENCE();
-        MMPC_TS(8)
-        // ---- forward roll-out: lane i < NX carries dx_k[i] in a register; a stage broadcasts the NX values through scalar
-        //      registers (v_readlane), forms the input step of its row and the next dx - no LDS round trip on the chain.
-        //      The operands of a stage (gain row, coefficients) do not depend on the chain and are fetched one stage ahead;
-        //      dx and du are stored for the phases that follow, nothing in the loop reads them back.
-        {
-            double nkr[NX], nkf = 0.0, nc0 = 0.0, ncf[5];
-            LANES_BEGIN
-            auto &ls = MMPC_LS;
-            for (int j = lane; j < NV; j += MMPC_WAVE) DXU[j] = 0.0;
-            ls.fw[MMPC_FW_SLOT(0)] = 0.0;
-            {   // (lanes that own no row / no input write to their dump slot: no branch in the loop)
-                const int a = (int)MMPC_B(ls.f_x, 2) - 1;
-                ls.fw_a[0] = lane < NX ? L.DXU + NV + lane : L.DUMP + lane;
-                ls.fw_a[1] = (lane < NX && a >= 0 && lane != 4) ? L.DXU + NX + a : L.DUMP + lane;
-                ls.fw_a[2] = lane < NX ? NV : 0;
-                ls.fw_a[3] = lane < NX ? lane : 0;        // row of the dynamics this lane carries
-                ls.fw_a[4] = a < 0 ? 0 : a;               // the input that enters this row
-            }
-            LANES_END
-#ifndef MMPC_EMU
-            // Gains in global memory (GK): lane l < GRS carries element l of a stage's (K_k, kf_k).  A ring of four stage slots in
-            // LDS - over the stage-matrix extras HUXL .. HUUD, dead since the backward pass - is filled two stages ahead of the
-            // chain from registers that were loaded from the gain block three stages before that; the row lanes read their gain
-            // row from the ring one stage ahead, as they read it from the LDS copy of the short horizons.
-            constexpr int GRS = NU * NX + NU;
-            static_assert(!GK || 4 * GRS <= NU * NX + NUU + NS + NS * NU, "the gain ring must fit the stage-matrix extras");
-            static_assert(!GK || FWD_UNROLL >= N, "the gain ring's registers rotate statically: the roll-out must be fully unrolled");
-            double *const RING = lds + L.HUXL;
-            double gpre[3] = {0.0, 0.0, 0.0};
-            unsigned g_off = 0, g_st = 0;
-            int r_off = 0, r_st = 0;
-            auto gload = [&](int stage) -> double { return *(const double *)((const char *)io.gscr + (size_t)(g_off + (unsigned)stage * g_st)); };
-            if (GK) {
-                const int lane = mmpc_lane_id();
-                const bool isk = lane < NU * NX, isf = !isk && lane < GRS;
-                g_off = (unsigned)(isk ? GB::KK + lane : (isf ? GB::KF + lane - NU * NX : GB::DUMP + lane)) * 8u;
-                g_st = isk ? (unsigned)(NU * NX) * 8u : (isf ? (unsigned)NU * 8u : 0u);
-                r_off = lane < GRS ? L.HUXL + lane : L.DUMP + lane;
-                r_st = lane < GRS ? GRS : 0;
-                const double e0 = gload(0), e1 = N > 1 ? gload(1) : 0.0;
-#pragma unroll
-                for (int q = 0; q < 3; q++) if (q + 2 < N) gpre[q] = gload(q + 2);
-                lds[r_off] = e0; lds[r_off + r_st] = e1;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            }
-            {   // operands of stage 0
-                const int lane = mmpc_lane_id();
-                auto &ls = MMPC_LS;
-                const int i = lane < NX ? lane : 0, a = (int)MMPC_B(ls.f_x, 2) - 1, aa = a < 0 ? 0 : a;
-#pragma unroll
-                for (int j = 0; j < NX; j++) nkr[j] = GK ? RING[aa * NX + j] : KK[aa * NX + j];
-                nkf = GK ? RING[NU * NX + aa] : KF[aa]; nc0 = CD[i];
-#pragma unroll
-                for (int q = 0; q < 4; q++) ncf[q] = CV[MMPC_B(ls.f_v, q)];
-                ncf[4] = CV[MMPC_B(ls.f_x, 1)];
-            }
-#endif
-#pragma unroll FWD_UNROLL
-            for (int k = 0; k < N; k++) {
-                LANES_BEGIN
-                auto &ls = MMPC_LS;
-                const int i = ls.fw_a[3], aa = ls.fw_a[4];
-                const int fw_dx = ls.fw_a[0], fw_du = ls.fw_a[1], fw_st = ls.fw_a[2];
-                double kr[NX], cf[5], kf0, c0;
-#ifdef MMPC_EMU
-                {
-                    const double *cv = CV + k * MMPC_NCV;
-                    for (int j = 0; j < NX; j++) kr[j] = KK[(k * NU + aa) * NX + j];
-                    kf0 = KF[k * NU + aa]; c0 = CD[k * NX + i];
-                    for (int q = 0; q < 4; q++) cf[q] = cv[MMPC_B(ls.f_v, q)];
-                    cf[4] = cv[MMPC_B(ls.f_x, 1)];
-                }
-#else
-#pragma unroll
-                for (int j = 0; j < NX; j++) kr[j] = nkr[j];
-                kf0 = nkf; c0 = nc0;
-#pragma unroll
-                for (int q = 0; q < 5; q++) cf[q] = ncf[q];
-                if (k + 1 < N) {
-                    const double *cv = CV + (k + 1) * MMPC_NCV;
-#pragma unroll
-                    for (int j = 0; j < NX; j++) nkr[j] = GK ? RING[((k + 1) & 3) * GRS + aa * NX + j] : KK[((k + 1) * NU + aa) * NX + j];
-                    nkf = GK ? RING[((k + 1) & 3) * GRS + NU * NX + aa] : KF[(k + 1) * NU + aa]; nc0 = CD[(k + 1) * NX + i];
-#pragma unroll
-                    for (int q = 0; q < 4; q++) ncf[q] = cv[MMPC_B(ls.f_v, q)];
-                    ncf[4] = cv[MMPC_B(ls.f_x, 1)];
-                }
-                if (GK) {
-                    if (k + 2 < N) lds[r_off + ((k + 2) & 3) * r_st] = gpre[k % 3];
-                    if (k + 5 < N) gpre[k % 3] = gload(k + 5);
-                }
-#endif
-                double dx[NX];
-#pragma unroll
-                for (int j = 0; j < NX; j++) dx[j] = MMPC_LANE_GET(fw[MMPC_FW_SLOT(k)], j);
-                // du_a = kf_a + K_a dx in three partial sums; the terms of dx+ that do not need du meanwhile
-                double d0 = kf0, d1 = 0.0, d2 = 0.0;
-#pragma unroll
-                for (int j = 0; j < NX; j += 3) {
-                    d0 += kr[j] * dx[j];
-                    if (j + 1 < NX) d1 += kr[j + 1] * dx[j + 1];
-                    if (j + 2 < NX) d2 += kr[j + 2] * dx[j + 2];
-                }
-                double v = c0 + ls.fw[MMPC_FW_SLOT(k)];
-                double w = cf[0] * dx[2];
-                v += cf[1] * dx[3];
-                w += cf[2] * dx[4];
-                v += cf[3] * dx[5];
-                const double du = d0 + (d1 + d2);
-                v = (v + w) + cf[4] * du;
-                ls.fw[MMPC_FW_SLOT(k + 1)] = v;
-                // (lanes that own no row / no input write to their dump slot: no branch)
-                lds[fw_du + k * fw_st] = du;
-                lds[fw_dx + k * fw_st] = v;
-                LANES_END_REG
-            }
-            LANES_BEGIN
-            LANES_END
-        }
-        MMPC_TS(9)
-        // ---- D1: multiplier step and slack-variable step (stage lanes)
-        LANES_BEGIN
-        auto &ls = MMPC_LS;
-        if (lane < NS) {
-            const int k = lane;
-            // lam_k + dlam_k = -(P_k dx_k + p_k): every load ahead of the arithmetic, the stores at the end (a store inside the
-            // row loop makes the compiler wait for each load: it cannot tell DLAM from HXX)
-            double dx[NX], pk[NXX], y[NX];
-#pragma unroll
-            for (int j = 0; j < NX; j++) { dx[j] = DXU[k * NV + j]; y[j] = QXU[k * NV + j] + LAM[k * NX + j]; }
-#pragma unroll
-            for (int e = 0; e < NXX; e++) pk[e] = HXX[k * NXX + e];
-            mmpc_sched_fence();
-#pragma unroll
-            for (int i = 0; i < NX; i++) {
-#pragma unroll
-                for (int j = 0; j < NX; j++) y[i] += pk[i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i] * dx[j];
-            }
-#pragma unroll
-            for (int i = 0; i < NX; i++) DLAM[k * NX + i] = -y[i];
-            double vdx = 0.0;
-            constexpr int ny = NSELF ? 6 : 2;
-#pragma unroll
-            for (int a = 0; a < ny; a++) vdx += ls.vx[a] * dx[mmpc_y(a)];
-            if (k == N - 1 && NSELF) {
-#pragma unroll
-                for (int a = 0; a < 6; a++) vdx += SN[4 + a] * DXU[N * NV + mmpc_y(a)];
-            }
-            DS[k] = -(ls.gss - vdx) * mmpc_rcp(ls.hss);
-            if (k == N) { for (int c = 0; c < NU; c++) DXU[N * NV + NX + c] = 0.0; }
-        }
-        LANES_END
-        }   // !fatal
-        }   // soc_st != 3
-        if (fatal) break;
-        MMPC_TS(10)
-        // ---- D2: row steps, fraction-to-boundary, directional derivative
-        const double tau = mmpc_vmax(0.99, 1.0 - mu);
-        auto d2_rows = [&](auto TAG) {
-        constexpr bool socm = decltype(TAG)::value; (void)socm;
-        LANES_BEGIN
-        auto &ls = MMPC_LS;
-        // fraction to the boundary without divisions or branches: alpha = min(1, tau / max_i(-dt_i / t_i)) (1/t_i is at hand),
-        // likewise for the multipliers with 1/z_i
-        double rp = 0.0, rd = 0.0, dphi = 0.0;
-        if (RG > 1 && M > 0) {   // circle rows where RG lanes share a stage
-            MMPC_ROW_LANE
-            if (rlane) {
-                const double dx0 = DXU[rk * NV], dx1 = DXU[rk * NV + 1], dsk = DS[rk];
-                const double px = XU[rk * NV], py = XU[rk * NV + 1], sk = S[rk];
-                double ob[MCR * 3];
-#pragma unroll
-                for (int r = 0; r < MCR; r++) {
-                    const double *o = obs_ptr(rk, rs + RG * r < M ? rs + RG * r : 0);
-                    ob[3 * r] = o[0]; ob[3 * r + 1] = o[1]; ob[3 * r + 2] = o[2];
-                }
-#pragma unroll
-                for (int r = 0; r < MCR; r++) {
-                    if (rs + RG * r < M) {
-                        const double ddx = px - ob[3 * r], ddy = py - ob[3 * r + 1], m2 = ddx * ddx + ddy * ddy, id = mmpc_rsqrt(m2), d = m2 * id;
-                        const double hv = (ob[3 * r + 2] + MMPC_BASE_R) - d - sk;
-                        const double t = ls.ct[r], z = ls.cz[r];
-                        const double jd = -(ddx * dx0 + ddy * dx1) * id - dsk;
-                        double res = hv + t;
-                        if constexpr (socm) res = io.soc[O_AR + rk * NRS + rs + RG * r];
-                        const double dtv = -res - jd, it_ = mmpc_rcp(t), dzv = mu * it_ - z - z * it_ * dtv;
-                        ls.cdt[r] = dtv;
-                        rp = mmpc_vmax(rp, -dtv * it_);
-                        rd = mmpc_vmax(rd, -dzv * mmpc_rcp(z));
-                        dphi -= mu * dtv * it_;
-                    }
-                }
-            }
-        }
-        if (lane < NS) {
-            const int k = lane;
-            const double *dx = DXU + k * NV;
-            const double dsk = DS[k], dsks = DS[slack_idx(k)];
-            const double px = XU[k * NV], py = XU[k * NV + 1], sk = S[k];
-            double ob[(MC > 0 ? MC : 1) * 3];
-#pragma unroll
-            for (int m = 0; m < (RG > 1 ? 0 : M); m++) { const double *o = obs_ptr(k, m); ob[3 * m] = o[0]; ob[3 * m + 1] = o[1]; ob[3 * m + 2] = o[2]; }
-#pragma unroll
-            for (int m = 0; m < (RG > 1 ? 0 : M); m++) {
-                const double ddx = px - ob[3 * m], ddy = py - ob[3 * m + 1], m2 = ddx * ddx + ddy * ddy, id = mmpc_rsqrt(m2), d = m2 * id;
-                const double hv = (ob[3 * m + 2] + MMPC_BASE_R) - d - sk;
-                const double t = ls.ct[m], z = ls.cz[m];
-                const double jd = -(ddx * dx[0] + ddy * dx[1]) * id - dsk;
-                double res = hv + t;
-                if constexpr (socm) res = io.soc[O_AR + k * NRS + m];
-                const double dtv = -res - jd, it_ = mmpc_rcp(t), dzv = mu * it_ - z - z * it_ * dtv;
-                ls.cdt[m] = dtv;
-                rp = mmpc_vmax(rp, -dtv * it_);
-                rd = mmpc_vmax(rd, -dzv * mmpc_rcp(z));
-                dphi -= mu * dtv * it_;
-            }
-            double sn = 0.0, cs = 0.0, dr[3] = {0, 0, 0}, dz[3] = {0, 0, 0};
-            if (NSELF) {
-                sn = TRG[k * 8]; cs = TRG[k * 8 + 1];
-#pragma unroll
-                for (int a = 0; a < 3; a++) { dr[a] = TRG[k * 8 + 2 + a]; dz[a] = TRG[k * 8 + 5 + a]; }
-            }
-            const double sks = S[slack_idx(k)];
-#pragma unroll
-            for (int i = 0; i < NSELF; i++) {
-                double g6[6];
-                const double hv = mmpc_self_row(i, px, py, cs, sn, dr, dz, g6) - sks;
-                const double t = ls.st[i], z = ls.sz[i];
-                double jd = -dsks;
-#pragma unroll
-                for (int a = 0; a < 6; a++) jd += g6[a] * dx[mmpc_y(a)];
-                double res = hv + t;
-                if constexpr (socm) res = io.soc[O_AR + k * NRS + M + i];
-                const double dtv = -res - jd, it_ = mmpc_rcp(t), dzv = mu * it_ - z - z * it_ * dtv;
-                ls.sdt[i] = dtv;
-                rp = mmpc_vmax(rp, -dtv * it_);
-                rd = mmpc_vmax(rd, -dzv * mmpc_rcp(z));
-                dphi -= mu * dtv * it_;
-            }
-            dphi += 2 * Sw * S[k] * dsk;
-        }
-#pragma unroll
-        for (int p = 0; p < NPASS; p++) {
-            mmpc_sched_fence();
-            const int idx = lane + MMPC_WAVE * p;
-            if (idx < NPAIR) {
-                const int k = idx / NV, v = idx % NV;
-                const double lo = ls.b_lo[p], hi = ls.b_hi[p];
-                const bool alo = lo > -1e299, ahi = hi < 1e299;
-                const double val = XU[idx], dv = DXU[idx];
-                dphi += RB[idx] * dv;   // RB = plain cost gradient of this variable (kept by the evaluation)
-                if (alo) {
-                    const double t = mmpc_box_t(val - lo), z = ls.lo_z[p], dtv = dv, it_ = mmpc_rcp(t), dzv = mu * it_ - z - z * it_ * dtv;
-                    rp = mmpc_vmax(rp, -dtv * it_);
-                    rd = mmpc_vmax(rd, -dzv * mmpc_rcp(z));
-                    dphi -= mu * dtv * it_;
-                }
-                if (ahi) {
-                    const double t = mmpc_box_t(hi - val), z = ls.hi_z[p], dtv = -dv, it_ = mmpc_rcp(t), dzv = mu * it_ - z - z * it_ * dtv;
-                    rp = mmpc_vmax(rp, -dtv * it_);
-                    rd = mmpc_vmax(rd, -dzv * mmpc_rcp(z));
-                    dphi -= mu * dtv * it_;
-                }
-            }
-        }
-        MMPC_WR(0) = rp; MMPC_WR(1) = rd; MMPC_WR(2) = dphi;
-        LANES_END
-        };
-        if (soc_st == 1) d2_rows(MmpcTag<true>{}); else d2_rows(MmpcTag<false>{});
-        {
-            const double rp_ = MMPC_RED_MAX(0), rd_ = MMPC_RED_MAX(1), ap_n = rp_ > tau ? tau * mmpc_rcp(rp_) : 1.0;
-            if (soc_st == 1) {
-                // corrected direction: its primal step from x_k (the multipliers have taken their step; the acceptance test
-                // uses the length and the slope of the step it corrects)
-                a_soc = ap_n;
-                apply_step(a_soc, false);
-                soc_st = 2; in_ls = 1;
-                continue;
-            }
-            ap = ap_n; ad = rd_ > tau ? tau * mmpc_rcp(rd_) : 1.0; dphi = MMPC_RED_SUM(2);
-            if (soc_st == 3) {
-                // the correction failed: the row steps of the uncorrected direction are back in the registers, the line search
-                // goes on with its second trial
-                alpha = 0.5 * ap; lsi = 1; lspass = 0;
-                apply_step(alpha, false);
-                soc_st = 0; in_ls = 1;
-                continue;
-            }
-        }
-
-        MMPC_TS(11)
-        if (!filt_init) { nfilt = 0; th_max = 1e4 * mmpc_vmax(1.0, th0); th_min = 1e-4 * mmpc_vmax(1.0, th0); filt_init = 1; }
-        // ---- first trial of the line search: multipliers with alpha_d, primal variables / slacks with alpha = alpha_p
-        alpha = ap; lspass = 0; lsi = 0;
-        apply_step(alpha, true);
-        in_ls = 1;
-        it++;
+        if (leave) break;
     }
 
     MMPC_TS(13)

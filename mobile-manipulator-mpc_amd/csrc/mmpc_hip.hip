@@ -89,7 +89,9 @@ __global__ __launch_bounds__(MMPC_WAVE) void mmpc_solve_kernel_static(
 // rows, scenario 1 (three planes) as written, the plane-free shape (the terminal-xy 'approach' phase of scenario 0), and the
 // shape of BASELINE configs C3 / C4 for the cases the specialised kernel refuses (dense weights, terminal equality): 38 -> 32 ms
 // per 8192 against the run-time-sized kernel (no scalar spills: every LDS offset an immediate)
+#ifndef MMPC_STATIC_LIST   // (experiments build shorter lists: tools/build_variant.sh)
 #define MMPC_STATIC_LIST(X) X(0, 20, 3, 0, 2, 1) X(0, 20, 3, 0, 2, 0) X(0, 20, 3, 0, 3, 1) X(0, 20, 3, 0, 0, 0) X(0, 20, 5, 0, 0, 0)
+#endif
 
 // OPS = obstacle table per stage (config obs_per_stage): part of the LDS layout.  The LDS block is STATIC (its size is a
 // constant of the instantiation): with `extern __shared__` the base of the dynamic block is resolved after instruction

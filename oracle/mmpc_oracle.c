@@ -49,9 +49,9 @@
  * [18] proximal trigger on the fraction-to-boundary step (1) or on the accepted step (0) | [20] second-order correction only where
  * theta(x_k) <= [20] theta_min (0: always) */
 static double LAB[32] = {1, 1, 2, 0, 0, 0, 1, 4, 4, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 1};
-static long long LAB_NFACT = 0, LAB_NSOC = 0, LAB_NSOCOK = 0, LAB_NSOCFAIL = 0, LAB_DH[20] = {0};
+static long long LAB_NTRIAL = 0, LAB_NFACT = 0, LAB_NSOC = 0, LAB_NSOCOK = 0, LAB_NSOCFAIL = 0, LAB_DH[20] = {0};
 void mmpc_oracle_set_lab(int i, double v) { if (i >= 0 && i < 32) LAB[i] = v; }
-double mmpc_oracle_get_lab(int i) { return i >= 200 && i < 220 ? (double)LAB_DH[i - 200] : i == 100 ? (double)LAB_NFACT : i == 101 ? (double)LAB_NSOC : i == 102 ? (double)LAB_NSOCOK : i == 103 ? (double)LAB_NSOCFAIL : (i >= 0 && i < 32 ? LAB[i] : 0.0); }
+double mmpc_oracle_get_lab(int i) { return i >= 200 && i < 220 ? (double)LAB_DH[i - 200] : i == 104 ? (double)LAB_NTRIAL : i == 100 ? (double)LAB_NFACT : i == 101 ? (double)LAB_NSOC : i == 102 ? (double)LAB_NSOCOK : i == 103 ? (double)LAB_NSOCFAIL : (i >= 0 && i < 32 ? LAB[i] : 0.0); }
 
 typedef struct {
     int kind;            /* 0 whole-body (nx=9,nu=5), 1 base-only (nx=6,nu=2) */
@@ -440,12 +440,13 @@ static void merit_parts(work *w, double X[NSM][NXM], double U[NSM][NUM], const d
 }
 
 /* Cholesky of n x n (row-major, leading dim NUM); returns 0 if a pivot is not > 0 */
+static __thread double chol_dfail = 0.0;   /* the pivot a factorisation failed on */
 static int chol(double H[NUM][NUM], int n, double L[NUM][NUM]) {
     memset(L, 0, sizeof(double) * NUM * NUM);
     for (int j = 0; j < n; j++) {
         double d = H[j][j];
         for (int k = 0; k < j; k++) d -= L[j][k] * L[j][k];
-        if (!(d > 0.0) || !isfinite(d)) return 0;
+        if (!(d > 0.0) || !isfinite(d)) { chol_dfail = d; return 0; }
         L[j][j] = sqrt(d);
         for (int i = j + 1; i < n; i++) {
             double v = H[i][j];
@@ -920,11 +921,14 @@ int mmpc_oracle_solve(const oracle_cfg *cfg, const double *x_init, const double 
             if (!okf) {                                                                                                      \
                 const double d0 = LAB[6] > 0 ? LAB[6] : 1e-4, kfirst = LAB[7] > 0 ? LAB[7] : 100.0, kup = LAB[8] > 0 ? LAB[8] : 8.0, kdn = LAB[9] > 0 ? LAB[9] : 1.0 / 3.0; \
                 double dw = delta_last == 0.0 ? d0 : fmax(1e-20, kdn * delta_last);                                          \
+                if (LAB[21] > 0 && isfinite(chol_dfail)) dw = fmax(dw, LAB[21] * fabs(chol_dfail));                          \
                 while (!(okf = factor(w, mu, 2, prox + dw))) {                                                               \
-                    dw *= delta_last == 0.0 ? kfirst : kup;                                                                  \
+                    dw *= delta_last == 0.0 ? kfirst : kup;  __atomic_fetch_add(&LAB_DH[1], 1, __ATOMIC_RELAXED);           \
+                    if (LAB[21] > 0 && isfinite(chol_dfail)) dw = fmax(dw, LAB[21] * fabs(chol_dfail));                      \
                     if (dw > 1e40) break;                                                                                    \
                 }                                                                                                            \
                 if (!okf) { FAILSTMT; }                                                                                      \
+                __atomic_fetch_add(&LAB_DH[0], 1, __ATOMIC_RELAXED); if (delta_last == 0.0) __atomic_fetch_add(&LAB_DH[2], 1, __ATOMIC_RELAXED); \
                 delta_last = dw; delta_used = dw;                                                                            \
             }                                                                                                                \
         } else if (!factor(w, mu, 2, prox)) if ((rung = 1, cfg->terminal_xy_eq || w->nhs > 0 || !factor(w, mu, 1, prox))) { \
@@ -978,6 +982,7 @@ int mmpc_oracle_solve(const oracle_cfg *cfg, const double *x_init, const double 
             for (int ls = 0; ls < 20; ls++) {
                 TRIAL_POINT(alpha)
                 double phi, th;
+                __atomic_fetch_add(&LAB_NTRIAL, 1, __ATOMIC_RELAXED);
                 merit_parts(w, Xn, Un, sn, tn, mu, &phi, &th);
                 ACCEPT_TEST(th, phi, alpha, accepted)
                 if (accepted) break;

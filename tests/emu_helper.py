@@ -25,7 +25,8 @@ class MmpcParams(C.Structure):
 
 def build(asan=False):
     out = os.path.join(_HERE, "emu", "_build", "libmmpc_emu_asan.so" if asan else "libmmpc_emu.so")
-    newest = max(os.path.getmtime(f) for f in (_SRC, _CORE, _FAST, _TILE, _IK))
+    csrc = os.path.dirname(_FAST)
+    newest = max(os.path.getmtime(f) for f in [_SRC, _CORE, _FAST, _TILE, _IK] + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith('.inc')])
     if not os.path.exists(out) or os.path.getmtime(out) < newest:
         os.makedirs(os.path.dirname(out), exist_ok=True)
         flags = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer"] if asan else ["-O2"]
