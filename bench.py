@@ -26,6 +26,14 @@ SEED_BASE = 3                                     # weak scaling: rank r solves 
 
 
 
+def _dig(d, path):
+    """d[path[0]][path[1]]... or None where a key is missing (extras that did not run)"""
+    for k in path:
+        if not isinstance(d, dict) or k not in d:
+            return None
+        d = d[k]
+    return d if isinstance(d, (int, float)) else None
+
 def _synth():
     """the package's seeded workload generator (numpy only): mobile-manipulator-mpc_amd/synth.py"""
     import mmpc_loader
@@ -364,14 +372,32 @@ def main():
                          "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tf / FP64_PEAK_TFLOPS,
                          "traffic": traffic, "kernel_ms": k_ms, "mfma": mfma,
                          "flops_per_iter": riccati_flops_per_iter(N, nx, nu, M, 4),
-                         "hbm_achieved_GBs": by / (k_ms * 1e-3) / 1e9, "hbm_frac": by / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                         # HBM side: from the counters' bytes when there are any (traffic), else the algorithmic bytes
+                         "hbm_achieved_GBs": (traffic or by) / (k_ms * 1e-3) / 1e9, "hbm_frac": (traffic or by) / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "hbm_bytes_source": "PMC counters (profiles/%s_pmc_traffic.json)" % PROFILE_TAG if traffic else "algorithmic bytes (no counter file for this shape)",
+                         "algorithmic_bytes": by},
         }
         res.update(extras)
+        if world > 1 and "strong_scaling" in extras:
+            # BASELINE config C4 read literally (ONE batch of --batch instances sharded over the ranks) beside the weak-scaling
+            # headline: `value` is the weak figure (--batch instances PER GPU), `value_strong` the literal one
+            res["value_strong"] = extras["strong_scaling"]["value"]
+            res["config"]["workload"] += "; `value` = weak scaling (%d instances per GPU), `value_strong` = config C4 literally (%d instances in all)" % (args.batch, args.batch)
         if world > 1:
             res["gather_checked"] = R["gather_ok"]        # every rank found its own records, bit for bit, in the gathered table
         ev0, ev1 = evs[0]
         if world == 1 and not args.no_cpu and not args.no_extras:   # (--no-cpu = the profiler passes: they see the warm-up and timed launches only)
-            # Extras, outside the timed region.  (1) the same launches in plain batch order (mode 0) and WITH the history hint
+            # Extras, outside the timed region.
+            # (0) config C5 (N = 30, 8 moving obstacles, warm-started receding horizon) in short form: `python bench.py --config c5`
+            # prints the full line.  FIRST among the extras: its groups run on their own HIP streams, and streams are mapped to the
+            # runtime's hardware queues in the order they are created - after the streams of the other extras two groups shared a
+            # queue (their kernels then run one after the other) and the compact figure read 383 k where the stand-alone process
+            # reads 435 k (round 3)
+            try:
+                res["c5"] = run_c5(args, torch, mm, None, 0, 1, dev, local_dev, steps=2, warmup=4, cpu_instances=256, compact=True)
+            except Exception as e:
+                res["c5"] = {"error": repr(e)}
+            # (1) the same launches in plain batch order (mode 0) and WITH the history hint
             # (mode 1, the engine's default): workgroups start longest-first by the iteration counts of the handle's previous
             # solve - exact here because the batch is re-solved, correlated in a receding-horizon loop.
             def timed_mode(mode):
@@ -508,14 +534,27 @@ def main():
                     res["pipelined_budget"] = pipelined_extra()
                 except Exception as e:
                     res["pipelined_budget"] = {"error": repr(e)}
-            # (7) config C5 (N = 30, 8 moving obstacles, warm-started receding horizon) in short form: `python bench.py --config c5`
-            # prints the full line
-            try:
-                res["c5"] = run_c5(args, torch, mm, None, 0, 1, dev, local_dev, steps=2, warmup=4, cpu_instances=256, compact=True)
-            except Exception as e:
-                res["c5"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu:
             res["cpu_baseline"] = cpu_baseline(d, N, M, min(args.cpu_sample, Bl), out["X"])
+        # one word per extra and the figures the documents quote, flat, where a reader of the line's tail finds them
+        names = ("c5", "schedule_hint", "continuation", "generic_kernel", "c1_shape_generic_kernel", "two_streams", "host_pointer_api",
+                 "single_solve_latency_ms", "large_batch", "stream_of_batches", "pipelined_budget", "strong_scaling", "cpu_baseline")
+        res["extras_status"] = {k: ("error" if isinstance(res[k], dict) and "error" in res[k] else "ok") for k in names if k in res}
+        g = lambda *path: _dig(res, path)
+        res["extras_summary"] = {k: v for k, v in {
+            "generic_kernel_c4_solves_s": g("generic_kernel", "value"),
+            "c1_as_written_solves_s": g("c1_shape_generic_kernel", "rows_as_written", "value"),
+            "c1_as_written_converged_frac": g("c1_shape_generic_kernel", "rows_as_written", "converged_frac"),
+            "c5_lock_step_solves_s": g("c5", "value"),
+            "c5_best_groups_solves_s": g("c5", "groups_out_of_phase", "best", "value"),
+            "c5_converged_frac": g("c5", "converged_frac"),
+            "hinted_ms": g("schedule_hint", "hinted_ms"),
+            "batch_order_ms": g("schedule_hint", "batch_order_ms"),
+            "two_streams_solves_s": g("two_streams", "value"),
+            "stream_of_batches_plain_ms": g("stream_of_batches", "plain", "ms_per_batch"),
+            "single_solve_latency_ms": g("single_solve_latency_ms", "median"),
+            "cpu_port_solves_s": g("cpu_baseline", "value"),
+        }.items() if v is not None}
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
@@ -846,6 +885,50 @@ def run_c5(args, torch, mm, dist, rank, world, dev, local_dev, steps, warmup, cp
     if world > 1:
         res["per_rank"] = [{"rank": r, "converged": int(p[0]), "solves": int(p[1]), "max_iters": int(p[2]), "kernel_ms_per_pass": p[3]} for r, p in enumerate(allp)]
         res["gather_checked"] = gok
+        if not args.no_extras and B >= 96:
+            # collective extra: every rank's robots as G groups in lock step on their own streams, out of phase
+            # (DeviceFleet.run_groups), the u0 all-gather issued per group and tick on the group's stream - a tick's exchange then
+            # waits for the slowest robot of one group of one rank, not of the whole node.  Same per-robot numbers as lock step.
+            G = 3
+            sizes_equal = len({sharding.shard_bounds(Bg, world, r)[1] - sharding.shard_bounds(Bg, world, r)[0] for r in range(world)}) == 1
+            del ctrl, eng
+            fleet = mm.DeviceFleet(mm, x0, glob, obs0, vel, N=N, device=local_dev)
+            gb = {}
+            okg = [True]
+            def on_tick(g, glo, ghi, t, u0):
+                k = (g, t & 1)
+                if k not in gb:
+                    gb[k] = [torch.empty((ghi - glo, 5), **f64), torch.empty(((ghi - glo) * world, 5), **f64), None]
+                loc_, all_, w_ = gb[k]
+                if w_ is not None:
+                    w_.wait()
+                loc_.copy_(u0)
+                if sizes_equal:
+                    gb[k][2] = dist.all_gather_into_tensor(all_, loc_, async_op=True)
+                else:                                       # ragged shards: group sizes differ between ranks, padded blocking gather
+                    sharding.allgather_solutions(loc_, None, dist)
+                if t == T - 1 and sizes_equal:
+                    gb[k][2].wait(); gb[k][2] = None
+                    okg[0] = okg[0] and torch.equal(all_[rank * (ghi - glo):(rank + 1) * (ghi - glo)], loc_) and bool(torch.isfinite(all_).all())
+            def drain():
+                for v in gb.values():
+                    if v[2] is not None:
+                        v[2].wait(); v[2] = None
+            ref_ls = fleet.run_lockstep(T); torch.cuda.synchronize()
+            fleet.run_groups(T, groups=G, on_tick=on_tick if sizes_equal else None); drain(); torch.cuda.synchronize()
+            dist.barrier(); torch.cuda.synchronize(); g0 = time.perf_counter()
+            for _ in range(steps):
+                rg = fleet.run_groups(T, groups=G, on_tick=on_tick if sizes_equal else None)
+            drain(); torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+            tg = torch.tensor([time.perf_counter() - g0], **f64); dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+            flag = torch.tensor([1.0 if (okg[0] and bool(rg["all_converged"]) and torch.equal(rg["u0"], ref_ls["u0"])) else 0.0], **f64)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            res["groups_per_rank"] = {"groups": G, "value": Bg * T * steps / float(tg.item()), "unit": "solves/s", "ms_per_step": float(tg.item()) / steps * 1e3,
+                                      "gather": "u0 per group and tick, asynchronous, on the group's stream" if sizes_equal else "none (ragged shards)",
+                                      "checked": bool(flag.item() == 1.0),
+                                      "note": "every rank's robots in %d groups out of phase (own stream, handle, descending priority); per-robot results "
+                                              "bitwise those of lock step, every solve converged and every rank's rows found in the gathered tables when `checked`" % G}
+            del fleet
     elif not args.no_extras:
         # the same fleet driven asynchronously (mmpc_amd.fleet.DeviceFleet.run_async: iteration budget per launch, the robots that
         # converge move on, the suspended ones are continued on a side stream and rejoin later), against the same class's lock step

@@ -117,7 +117,8 @@ int mmpc_solve_batch_device(mmpc_handle h, int B, const double *d_x_init, const 
 /* List launch (specialised kernels; no reference counterpart): the same solve for the instances d_list[0 .. *d_count - 1] only -
  * row indices into the B-row arrays, every index at most once; list and count live in DEVICE memory (the count is read by the
  * kernel: a caller that builds the list on the device never has to synchronise), `capacity` (<= B) bounds the count and is the
- * size of the grid.  Rows that are not listed are neither read nor written.  Instances start in list order (put the ones that
+ * size of the grid.  An entry outside [0, B) is skipped (nothing can validate a device-side list on the host); a repeated entry is
+ * the caller's error (two workgroups would solve the same rows).  Rows that are not listed are neither read nor written.  Instances start in list order (put the ones that
  * are expected to take longest first); the handle's schedule hint is not used and not updated.  With an iteration budget set the
  * listed instances that need more are suspended as in mmpc_solve_batch_device and mmpc_resume_batch_device (same B) continues
  * exactly them.  What it is for: a receding-horizon loop over many robots in which the robots whose solve is finished advance

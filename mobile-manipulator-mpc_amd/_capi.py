@@ -273,6 +273,8 @@ class Engine:
             for t_ in (lst, cnt):
                 if t_.dtype != torch.int32 or not t_.is_cuda or not t_.is_contiguous() or t_.device != dev:
                     raise ValueError("rows = (list, count): contiguous int32 tensors on %s" % dev)
+            if cnt.numel() != 1 or lst.numel() < 1:
+                raise ValueError("rows = (list, count): a one-element count and a list of at least one entry")
             self._chk(lib().mmpc_solve_list_device(self._h, B, p(lst), p(cnt), int(min(lst.numel(), B)), p(x_init), p(traj_ref), p(u_ref), p(u_last),
                                                    p(x_guess), p(obs), p(out["X"]), p(out["U"]), p(out["s"]), p(out["status"]),
                                                    p(out["iters"]), p(out["cost"]), p(out["err"]), C.c_void_p(st)), "mmpc_solve_list_device")

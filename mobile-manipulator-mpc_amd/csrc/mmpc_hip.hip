@@ -119,6 +119,9 @@ __global__ __launch_bounds__(MMPC_WAVE, WPE) void mmpc_fast_kernel(
     for (int w = (int)blockIdx.x; w < limit; w += (int)gridDim.x) {
         // launch order: workgroup i solves instance order[i] (a permutation / a list; results do not depend on it)
         const int b = order ? order[w] : w;
+        // (a list launch takes its row indices from the caller's device memory, where nothing can have checked them: an index
+        //  outside the batch is skipped - it would address the inputs, the outputs and the handle's own save areas)
+        if ((unsigned)b >= (unsigned)B) { if (!CONT || !resume_count) break; continue; }
         const MmpcParams &P = *Pp;
         const int M = MC;
         const size_t so = (size_t)(P.obs_per_stage ? N + 1 : 1) * M * 3;
@@ -183,10 +186,10 @@ __global__ __launch_bounds__(256) void mmpc_collect_suspended(int B, const int *
 }
 
 // the same over a list of instances (list launches): only the listed ones can have been suspended by the launch before
-__global__ __launch_bounds__(256) void mmpc_collect_suspended_list(const int *__restrict__ in_list, const int *__restrict__ in_count,
+__global__ __launch_bounds__(256) void mmpc_collect_suspended_list(int B, const int *__restrict__ in_list, const int *__restrict__ in_count,
                                                                   const int *__restrict__ status, int *__restrict__ list, int *__restrict__ count) {
     const int w = blockIdx.x * 256 + threadIdx.x;
-    if (w < *in_count) { const int b = in_list[w]; if (status[b] == MMPC_STATUS_SUSPENDED) list[atomicAdd(count, 1)] = b; }
+    if (w < *in_count) { const int b = in_list[w]; if ((unsigned)b < (unsigned)B && status[b] == MMPC_STATUS_SUSPENDED) list[atomicAdd(count, 1)] = b; }
 }
 
 // A-priori difficulty of an instance, from its data alone: how close the reference path comes to (or how deep it cuts
@@ -604,7 +607,7 @@ static int launch(mmpc_handle h, int B, const double *x_init, const double *traj
     if (use_fast && h->budget > 0 && !resume) {
         // who is suspended: compacted list for mmpc_resume_batch_device
         HIPCHK(h, hipMemsetAsync(h->d_count, 0, 4, st));
-        if (ulist) hipLaunchKernelGGL(mmpc_collect_suspended_list, dim3((ucap + 255) / 256), dim3(256), 0, st, ulist, ucount, status, h->d_list, h->d_count);
+        if (ulist) hipLaunchKernelGGL(mmpc_collect_suspended_list, dim3((ucap + 255) / 256), dim3(256), 0, st, B, ulist, ucount, status, h->d_list, h->d_count);
         else hipLaunchKernelGGL(mmpc_collect_suspended, dim3((B + 255) / 256), dim3(256), 0, st, B, status, h->d_list, h->d_count);
         h->resume_B = B;
     }

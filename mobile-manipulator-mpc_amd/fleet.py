@@ -28,7 +28,11 @@ class DeviceFleet:
         self.dev = torch.device("cuda", device)
         B, M = self.B, self.M
         mk = lambda: mm.MPCWholeBody(mm.MobileManipulator(dt), [], [], N=N, max_batch=max(B, 1), device=device, n_obstacles=M, obs_per_stage=True)
-        self.ctrls = [mk() for _ in range(handles)]   # [0]: lock step (plain kernel); [1], [2]: the two alternating handles of run_async
+        # [0]: lock step (plain kernel); [1], [2]: the two alternating handles of run_async, created on its first call.  A handle owns
+        # max_batch rows of device state: staging, warm start, the second-order-correction scratch and - long horizons - the gain
+        # blocks (mmpc_create: about 0.5 MB per robot at N = 30, M = 8)
+        self._mk = mk
+        self.ctrls = [mk()]
         self.engs = [c._engine for c in self.ctrls]
         f64 = dict(dtype=torch.float64, device=self.dev)
         self.f64 = f64
@@ -74,8 +78,10 @@ class DeviceFleet:
             pass
         return res
 
-    def _lockstep_ticks(self, T, res):
-        """run_lockstep as a generator: one tick's work is queued on the current stream per next(); the result lands in `res`"""
+    def _lockstep_ticks(self, T, res, on_tick=None):
+        """run_lockstep as a generator: one tick's work is queued on the current stream per next(); the result lands in `res`.
+        on_tick(t, u0): called after tick t's solve is queued, on the stream it runs on, with the (B, 5) first inputs - where a
+        multi-rank run issues its all-gather of u0 (bench.py --config c5)"""
         torch = self.torch
         B, N = self.B, self.N
         eng = self.engs[0]
@@ -92,18 +98,23 @@ class DeviceFleet:
             ul = out["U"].clone()
             u0 = out["U"][:, 0]
             hist[:, t] = u0; its[:, t] = out["iters"]
+            if on_tick is not None:
+                on_tick(t, u0)
             x = self.plant(x, u0)
             tick += 1
             res.update(u0=hist, x=x, iters=its, all_converged=ok, rounds=T)
             yield t
 
     # ---- groups in lock step, out of phase
-    def run_groups(self, T, groups=2, priority=True):
+    def run_groups(self, T, groups=2, priority=True, on_tick=None):
         """The fleet as `groups` contiguous groups of robots, each in lock step on its own HIP stream and handle, the streams at
         descending priority: the workgroup dispatcher serves the first group's launch first and fills the slots its tail leaves
         empty - a tick lasts as long as its slowest robot, 200-450 iterations against a mean of 34 - with the other group's
         launch, so the groups run out of phase and one group's tail overlaps the other's bulk.  Robots do not interact: every
-        robot's numbers are those of run_lockstep (tests/test_gpu_parity.py).  Same reference protocol per robot."""
+        robot's numbers are those of run_lockstep (tests/test_gpu_parity.py).  Same reference protocol per robot.
+        on_tick(g, lo, hi, t, u0): called per group and tick on the group's stream (see _lockstep_ticks) - a multi-rank run gathers
+        the first inputs of group g's robots [lo, hi) there, so that a tick's exchange waits for the slowest robot of ONE group of
+        one rank, not of the whole node."""
         torch = self.torch
         G = int(groups)
         if not hasattr(self, "_groups") or len(self._groups) != G or getattr(self, "_groups_pr", True) != bool(priority):
@@ -127,7 +138,8 @@ class DeviceFleet:
         for g, (lo, hi, sub, st) in enumerate(self._groups):
             st.wait_event(ev0)
             with torch.cuda.stream(st):
-                gens.append(sub._lockstep_ticks(T, res[g]))
+                cb = None if on_tick is None else (lambda t, u0, g=g, lo=lo, hi=hi: on_tick(g, lo, hi, t, u0))
+                gens.append(sub._lockstep_ticks(T, res[g], cb))
         for t in range(T):
             for g, (lo, hi, sub, st) in enumerate(self._groups):
                 with torch.cuda.stream(st):
@@ -149,6 +161,8 @@ class DeviceFleet:
         B, N, M = self.B, self.N, self.M
         dev = self.dev
         main = torch.cuda.current_stream(dev)
+        while len(self.ctrls) < 3:
+            self.ctrls.append(self._mk()); self.engs.append(self.ctrls[-1]._engine)
         if not hasattr(self, "_sets"):
             self._sides = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
             self._sets = []
@@ -203,7 +217,10 @@ class DeviceFleet:
             S["list"].copy_(torch.argsort(score, descending=True, stable=True).to(torch.int32))
             S["count"].copy_(ready.sum().to(torch.int32).reshape(1))
             eng.solve_batch_device(S["x_in"], S["loc"], self.uref, S["ul_in"], S["obs"], out=S["out"], rows=(S["list"], S["count"]))
-            snap = S["out"]["status"].clone()                      # (before the continuation may rewrite it)
+            # (snapshots before the continuation on the side stream starts rewriting the rows of the suspended robots: advance() below
+            #  reads whole columns on the main stream)
+            snap = S["out"]["status"].clone()
+            snap_out = dict(U=S["out"]["U"].clone(), iters=S["out"]["iters"].clone())
             evm = torch.cuda.Event(); evm.record(main)
             side = self._sides[s]
             side.wait_event(evm)
@@ -213,7 +230,7 @@ class DeviceFleet:
             susp = ready & (snap == 3)
             failed = failed | (ready & (snap != 0) & (snap != 3)).any()
             nsusp = nsusp + susp.sum()
-            advance(conv, S["out"])
+            advance(conv, snap_out)
             inflight = inflight | susp
             S["susp"] = susp
             r += 1

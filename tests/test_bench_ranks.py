@@ -49,6 +49,7 @@ def test_two_rank_bench_line():
     assert d["config"]["iteration_budget"] == 0                                          # the same mode at every N: one launch per batch, plain kernel
     assert d["gather_checked"] is True                                                   # every rank found its records in the gathered table
     pb, ss = d["pipelined_budget"], d["strong_scaling"]                                  # collective extras: pipelined budget, C4 read literally
+    assert d["value_strong"] == ss["value"] and "value_strong" in d["config"]["workload"]  # the literal C4 figure at top level beside the weak one
     assert pb["iteration_budget"] == 64 and pb["converged_frac"] == 1.0 and pb["gather_checked"] is True and pb["value"] > 0
     assert ss["global_batch"] == 1024 and ss["batch_per_gpu"] == [512, 512] and ss["converged_frac"] == 1.0 and ss["gather_checked"] is True
     assert len(d["per_rank"]) == 2 and all(p["converged"] == 1024 for p in d["per_rank"]) and "no schedule hint from earlier solves" in d["config"]["workload"]
@@ -74,3 +75,7 @@ def test_two_rank_c5_receding_horizon():
     assert d["gather_checked"] is True and len(d["per_rank"]) == 2 and all(p_["converged"] == p_["solves"] == 512 * 3 for p_ in d["per_rank"])
     assert d["solver"]["converged_frac"] == 1.0 and abs(d["value"] - 2 * 512 * 3 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     assert "cpu_baseline" not in d
+    # collective extra: every rank's robots as three groups out of phase, u0 gathered per group and tick on the group's stream;
+    # per-robot results bitwise those of lock step, every rank's rows found in the gathered tables
+    gr = d["groups_per_rank"]
+    assert gr["groups"] == 3 and gr["checked"] is True and gr["value"] > 0 and "per group" in gr["gather"]

@@ -467,6 +467,25 @@ def test_list_launch_solves_exactly_the_listed_rows(mm):
     eng.solve_batch_device(xi, tr, ur, ul, ob, out=out, rows=(lst, cnt))
     torch.cuda.synchronize()
     assert all(bool((v == -7).all()) for v in out.values())
+    # entries outside the batch (a stale or garbage index in a device-side list) are skipped: with and without a budget the
+    # valid entries beside them get their results and every other row stays untouched
+    bad = torch.tensor([5, -1, B, 2 ** 30, 17, -(2 ** 31)], dtype=torch.int32, device=dev)
+    lst2 = torch.zeros(B, dtype=torch.int32, device=dev); lst2[:bad.numel()] = bad
+    cnt2 = torch.tensor([bad.numel()], dtype=torch.int32, device=dev)
+    for budget in (0, 12):
+        eng.set_iteration_budget(budget)
+        out = {k: torch.full_like(v, -7) for k, v in ref.items()}
+        eng.solve_batch_device(xi, tr, ur, ul, ob, out=out, rows=(lst2, cnt2))
+        if budget:
+            eng.resume_batch_device(xi, tr, ur, ul, ob, out)
+        torch.cuda.synchronize()
+        rest = torch.ones(B, dtype=torch.bool, device=dev); rest[[5, 17]] = False
+        for k in ("X", "U", "s", "status", "iters"):
+            assert torch.equal(out[k][[5, 17]], ref[k][[5, 17]]), (budget, k)
+            assert bool((out[k][rest] == -7).all()), (budget, k)
+    eng.set_iteration_budget(0)
+    with pytest.raises(ValueError, match="one-element count"):
+        eng.solve_batch_device(xi, tr, ur, ul, ob, out=out, rows=(lst, torch.zeros(2, dtype=torch.int32, device=dev)))
     gen = mm.MPCWholeBody(mm.MobileManipulator(0.1), [], [], N=12, max_batch=B, n_obstacles=2)     # no specialised kernel for this shape
     with pytest.raises(RuntimeError, match="list launches"):
         d2 = synth.make_batch(B, N=12, M=2)
