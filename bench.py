@@ -21,7 +21,7 @@ sys.path.insert(0, _ROOT)
 
 FP64_PEAK_TFLOPS = 78.6      # MI355X FP64 vector = FP64 matrix peak (spec), SURVEY §7
 HBM_PEAK_GBS = 8000.0
-PROFILE_TAG = "r03"                               # PMC summaries of this build (tools/collect_profiles.sh <tag>)
+PROFILE_TAG = "r04"
 SEED_BASE = 3                                     # weak scaling: rank r solves seed SEED_BASE + r of the C4 generator (no selection)
 
 

@@ -123,7 +123,7 @@ struct MmpcParams {
 // inside it; the box rows are linear, so their slack then stays equal to the distance to the bound
 #define MMPC_BOUND_PUSH 1e-2
 // proximal term for crawling iterations: after two consecutive steps with alpha < MMPC_PROX_LO the (x,u) Hessian gets
-// + prox I (MMPC_PROX0, x4 per further small step), divided by 4 after a step with alpha > 0.5 (oracle/ipm_numpy.py)
+// + prox I (MMPC_PROX0, x4 per further small step, at most MMPC_PROX_MAX), divided by 4 after a step with alpha > 0.5 (oracle/ipm_numpy.py)
 #define MMPC_PROX0 100.0
 // inertia correction (IPOPT: 1e-4, x100 the first time, x8 after, 1/3: the corrections this NLP needs are 1 ... 100)
 #define MMPC_IC_D0 1.0

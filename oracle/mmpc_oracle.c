@@ -1061,8 +1061,8 @@ int mmpc_oracle_solve(const oracle_cfg *cfg, const double *x_init, const double 
             const double a_px = LAB[18] >= 1.0 ? ap : alpha;
             nsmall = a_px < PXLO ? nsmall + 1 : 0;
             if (cfg->terminal_xy_eq || LAB[3] >= 1.0) prox = 0.0;   /* the forced correction E dx_N = e makes nu grow like prox */
-            else if (a_px < PXLO && (nsmall >= PXN || prox > 0.0)) { prox = prox * 4.0 > PX0 ? prox * 4.0 : PX0; if (prox > PROX_MAX) prox = PROX_MAX; }
-            else if (alpha > 0.5) prox = prox > PX0 * 1e-3 ? prox / 4.0 : 0.0;
+            else if (a_px < PXLO && (nsmall >= PXN || prox > 0.0)) { const double PXM = LAB[22] > 0 ? LAB[22] : PROX_MAX; prox = prox * 4.0 > PX0 ? prox * 4.0 : PX0; if (prox > PXM) prox = PXM; }
+            else if (alpha > (LAB[23] > 0 ? LAB[23] : 0.5)) prox = prox > PX0 * 1e-3 ? prox / (LAB[24] > 0 ? LAB[24] : 4.0) : 0.0;
         }
         /* ---- update */
         for (int j = 0; j < 2; j++) w->nu_eq[j] += alpha * (w->nu_new[j] - w->nu_eq[j]);
