@@ -595,7 +595,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
     constexpr int ST_S = NPAIR, ST_LAM = NPAIR + NS, ST_FILT = NPAIR + NS + NS * NX, ST_SCAL = ST_FILT + 2 * MMPC_FCAP,
                   ST_LANE = ST_SCAL + MMPC_NSCAL;
     int nsmall_r = 0;
-    double prox_r = 0.0, delta_r = 0.0;
+    double prox_r = 0.0, delta_r = 0.0, dprev_r = 0.0;
     if (CONT && io.resume) {
         // ---- continue a suspended solve: the state the uninterrupted loop would hold at this point
         const double *const st_xu = io.state, *const st_s = io.state + ST_S, *const st_lam = io.state + ST_LAM,
@@ -615,7 +615,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
         for (int i = 0; i < 4; i++) { ls.st[i] = q[2 * NPASS + 2 * MCS + i]; ls.sz[i] = q[2 * NPASS + 2 * MCS + 4 + i]; }
         LANES_END
         mu = st_scal[0]; th_max = st_scal[1]; th_min = st_scal[2]; prox_r = st_scal[3];
-        it = (int)st_scal[4]; nfilt = (int)st_scal[5]; filt_init = (int)st_scal[6]; nsmall_r = (int)st_scal[7]; delta_r = st_scal[8];
+        it = (int)st_scal[4]; nfilt = (int)st_scal[5]; filt_init = (int)st_scal[6]; nsmall_r = (int)st_scal[7]; delta_r = st_scal[8]; dprev_r = st_scal[9];
     }
     const int it_start = CONT ? it : 0;
     // results of the evaluation of the current point (iterate or line-search trial)
@@ -625,6 +625,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
     int in_ls = 0, lspass = 0, lsi = 0, nsmall = nsmall_r;
     double prox = prox_r;   // proximal term for crawling iterations (mmpc_prox_update)
     double delta_last = delta_r;   // last successful inertia correction
+    double delta_prev = dprev_r;   // the correction of the previous iteration's matrix (0: none)
     double alpha = 0.0, ap = 1.0, ad = 1.0, dphi = 0.0, phi0 = 0.0, th0 = 0.0;
 
     // ---- move to a trial point: the primal variables, the equality multipliers and the slacks of the nonlinear rows by

@@ -52,6 +52,8 @@ class Options:
                             # geometric sequence (delta0, x kappa_first while no correction has succeeded yet, x kappa_up after, the next
                             # iteration starts from kappa_dn times the last successful value) until every pivot of the recursion is positive
     kappa_first = 4.0; kappa_up = 4.0; kappa_dn = 1.0 / 3.0
+    ic_skip0 = 0.1          # an iteration whose predecessor needed a correction above this starts from the corrected matrix at once (IPOPT always
+                            # tries delta_w = 0 first: here that attempt failed in most iterations of a run of corrected ones - a wasted pass)
     soc_max = 2             # second-order corrections per iteration (IPOPT: max_soc = 4), tried when the first trial step is rejected
                             # without reducing the infeasibility and theta(x_k) <= theta_min (the regime of the switching condition)
     inertia_streak = 0      # >0 (experiment, off: it trades the 600-800-iteration cases for others that take 1300+): inertia correction (exact Hessian + delta I) instead of the Gauss-Newton fallback once the
@@ -216,7 +218,7 @@ def solve(prob: nlp.Problem, U0=None, X0=None, opt: Options = None, verbose=Fals
     RW2 = (p.R + p.R.T) + (p.W + p.W.T)
     status = 1
     nu_merit = 1.0
-    delta_last = 0.0
+    delta_last = 0.0; delta_used = 0.0; delta_prev_it = 0.0
     nu_eq = np.zeros(2)
     prox_cur, nsmall, nstreak = 0.0, 0, 0
     filt = None
@@ -379,9 +381,11 @@ def solve(prob: nlp.Problem, U0=None, X0=None, opt: Options = None, verbose=Fals
         #  nu then grow like prox)
         def newton():
             """factorisation of the Newton matrix: exact Hessian, inertia-corrected where a pivot fails (or the round-3 ladder)"""
-            nonlocal delta_last, prox_cur
+            nonlocal delta_last, prox_cur, delta_used
+            delta_used = 0.0
             prox = prox_cur if (opt.prox and not p.terminal_xy_equality) else 0.0
-            fac = factor(opt.exact_hessian, prox) if opt.exact_hessian else None
+            skip0 = opt.inertia and not p.terminal_xy_equality and opt.ic_skip0 > 0 and delta_prev_it > opt.ic_skip0
+            fac = factor(opt.exact_hessian, prox) if (opt.exact_hessian and not skip0) else None
             if fac is None and opt.exact_hessian and opt.inertia and not p.terminal_xy_equality:
                 delta = opt.delta0 if delta_last == 0.0 else max(opt.delta_min, delta_last * opt.kappa_dn)
                 while True:
@@ -390,7 +394,7 @@ def solve(prob: nlp.Problem, U0=None, X0=None, opt: Options = None, verbose=Fals
                         break
                     delta = delta * (opt.kappa_first if delta_last == 0.0 else opt.kappa_up)
                 if fac is not None:
-                    delta_last = delta
+                    delta_last = delta; delta_used = delta
                 return fac
             if fac is None and opt.exact_hessian and opt.mid_fallback and not p.terminal_xy_equality and \
                     (prob.hs is None or len(prob.hs) == 0):
@@ -460,6 +464,7 @@ def solve(prob: nlp.Problem, U0=None, X0=None, opt: Options = None, verbose=Fals
         if fac is None:
             status = 2
             break
+        delta_prev_it = delta_used
         dX, dU, ds, lam_new, nu_new, dt, dz, ap, ad = direction(fac)
         if getattr(opt, "dense_check", False):
             _dense_check(prob, rows, ev, X, U, s, t, z, lam, mu, c, AB, gX, gU, gs, rh, dX, dU, ds, lam_new, opt,

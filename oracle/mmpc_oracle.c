@@ -47,8 +47,9 @@
 /* [0] complementarity scaled by s_c (1) or s_d (0) | [1] inertia correction (1) or the round-3 Hessian ladder (0) | [2] second-order
  * corrections per iteration | [3] 1: no proximal term | [6..9] inertia correction: first delta, first growth, growth, decay |
  * [18] proximal trigger on the fraction-to-boundary step (1) or on the accepted step (0) | [20] second-order correction only where
- * theta(x_k) <= [20] theta_min (0: always) */
-static double LAB[32] = {1, 1, 2, 0, 0, 0, 1, 4, 4, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 1};
+ * theta(x_k) <= [20] theta_min (0: always) | [25] an iteration whose predecessor needed a correction above this starts from
+ * the corrected matrix at once (0: always try the uncorrected matrix first, as IPOPT does) */
+static double LAB[32] = {1, 1, 2, 0, 0, 0, 1, 4, 4, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 1, 0, 0, 0, 0, 0.1};
 static long long LAB_NTRIAL = 0, LAB_NFACT = 0, LAB_NSOC = 0, LAB_NSOCOK = 0, LAB_NSOCFAIL = 0, LAB_DH[20] = {0};
 void mmpc_oracle_set_lab(int i, double v) { if (i >= 0 && i < 32) LAB[i] = v; }
 double mmpc_oracle_get_lab(int i) { return i >= 200 && i < 220 ? (double)LAB_DH[i - 200] : i == 104 ? (double)LAB_NTRIAL : i == 100 ? (double)LAB_NFACT : i == 101 ? (double)LAB_NSOC : i == 102 ? (double)LAB_NSOCOK : i == 103 ? (double)LAB_NSOCFAIL : (i >= 0 && i < 32 ? LAB[i] : 0.0); }
@@ -821,7 +822,7 @@ int mmpc_oracle_solve(const oracle_cfg *cfg, const double *x_init, const double 
     for (int k = 0; k <= N; k++) for (int r = 0; r < w->nrow; r++) if (w->act[k][r]) {
         double v = -w->h[k][r]; w->t[k][r] = v > 1e-2 ? v : 1e-2; w->z[k][r] = mu / w->t[k][r]; nrows_act++; }
     int status = 1, it = 0, nf = 0, nsmall = 0;
-    double prox = 0.0, delta_last = 0.0; int soc_off = 0; work *sv = 0;
+    double prox = 0.0, delta_last = 0.0, delta_prev_it = 0.0; int soc_off = 0; work *sv = 0;
     double th_max = 0, th_min = 0, E0 = 0;
     fent filt[FCAP];
     int filt_init = 0, nfilt = 0;
@@ -917,7 +918,7 @@ int mmpc_oracle_solve(const oracle_cfg *cfg, const double *x_init, const double 
              * of a geometric sequence for which every pivot of the recursion is positive.  Not with the terminal-xy        \
              * equality: the multipliers of the regularised system grow like delta_w there (the full correction             \
              * E dx_N = e is forced whatever the damping) and feed back into lam^T d2f - Gauss-Newton as in round 3 */     \
-            int okf = factor(w, mu, 2, prox);                                                                                \
+            int okf = (LAB[25] > 0 && delta_prev_it > LAB[25]) ? 0 : factor(w, mu, 2, prox);                                 \
             if (!okf) {                                                                                                      \
                 const double d0 = LAB[6] > 0 ? LAB[6] : 1e-4, kfirst = LAB[7] > 0 ? LAB[7] : 100.0, kup = LAB[8] > 0 ? LAB[8] : 8.0, kdn = LAB[9] > 0 ? LAB[9] : 1.0 / 3.0; \
                 double dw = delta_last == 0.0 ? d0 : fmax(1e-20, kdn * delta_last);                                          \
@@ -943,6 +944,7 @@ int mmpc_oracle_solve(const oracle_cfg *cfg, const double *x_init, const double 
         int nfail = 0;
         NEWTON_SOLVE(nfail = 1)
         if (nfail) { status = 2; break; }
+        delta_prev_it = delta_used;
         double ap = 1, ad = 1, dphi = 0;
         direction(w, mu, &ap, &ad, &dphi);
         /* ---- filter line search */

@@ -189,7 +189,8 @@ def test_c1_demo_scenario_with_halfspaces(mm):
         assert oi["status"][0] == 0
         assert np.abs(u0i - oi["U"][0, 0]).max() < TOL and np.abs(loose.x_guess - oi["X"][0]).max() < TOL
         if case == 0:
-            assert np.abs(u0 - u0i).max() < 1e-5                                          # extra rows inactive: same optimum (two solves, each to KKT 1e-8)
+            assert np.abs(u0 - u0i).max() < 5e-5      # extra rows inactive: same optimum (two solves of two NLPs, each to KKT 1e-8: the weakly
+                                                       # determined inputs move by up to 2e-5 within that tolerance)
         else:
             assert u0[0] < -1.99 and u0i[0] > -0.2                                        # the two NLPs differ under the ridge
             q8 = mm.controllers._q8
