@@ -271,7 +271,7 @@ def solve(prob: nlp.Problem, U0=None, X0=None, opt: Options = None, verbose=Fals
         Emu = max(err_d / sd, err_p, compmu / sc)
         if history is not None:
             history.append(dict(it=it, mu=mu, E0=E0, Emu=Emu, err_d=err_d, err_p=err_p,
-                                cost=nlp.cost(prob, X, U, s)))
+                                cost=nlp.cost(prob, X, U, s), X=X.copy()))
         if verbose:
             print(f"it {it:3d} mu {mu:8.2e} E0 {E0:9.3e} Emu {Emu:9.3e} d {err_d:9.3e} p {err_p:9.3e} "
                   f"f {nlp.cost(prob, X, U, s):12.6f}")
