@@ -864,6 +864,7 @@ def run_c5(args, torch, mm, dist, rank, world, dev, local_dev, steps, warmup, cp
     else:
         allp = [conv_loc.tolist()]
         gok = None
+    c5_tr = _c5_traffic() if (world == 1 and B == 8192) else None
     res = {"metric": "MPC solves/sec, whole-body N=30 batch=%d, %d warm-started receding-horizon ticks, 8 moving obstacles" % (args.batch, T),
            "value": Bg * T * steps / el, "unit": "solves/s", "n_gpus": world, "steps": steps, "warmup": warmup,
            "ms_per_step": el / steps * 1e3, "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None,
@@ -872,8 +873,14 @@ def run_c5(args, torch, mm, dist, rank, world, dev, local_dev, steps, warmup, cp
                                   "launch order of a tick is hinted by the iteration counts of the tick before)" % (B, Bg, T),
                       "batch_per_gpu": B, "parallelism": "robots sharded x%d%s" % (world, " + all-gather(u0) per tick" if world > 1 else "")},
            "roofline": {"bound": "mfma", "kernel": "mmpc_fast_kernel<0,30,8>", "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": ach / FP64_PEAK_TFLOPS, "traffic": _c5_traffic() if (world == 1 and B == 8192) else None, "kernel_ms_per_tick": k_ms, "flops_per_iter": fl_iter,
-                        "hbm_achieved_GBs": by * B * T / (sum(k_ms) * 1e-3) / 1e9, "hbm_frac": by * B * T / (sum(k_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                        "frac": ach / FP64_PEAK_TFLOPS, "traffic": c5_tr, "kernel_ms_per_tick": k_ms, "flops_per_iter": fl_iter,
+                        # HBM side from the counters' bytes per launch (= per tick) when there are any: the gain block of the long
+                        # horizons is written twice per iteration through L2, 47x the algorithmic bytes
+                        "algorithmic_bytes_per_tick": by * B,
+                        "traffic_over_algorithmic": (c5_tr / (by * B)) if c5_tr else None,
+                        "hbm_achieved_GBs": (c5_tr or by * B) * T / (sum(k_ms) * 1e-3) / 1e9,
+                        "hbm_frac": (c5_tr or by * B) * T / (sum(k_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "hbm_bytes_source": "PMC counters (profiles/%s_c5_pmc_traffic.json)" % PROFILE_TAG if c5_tr else "algorithmic bytes"},
            "solver": {"mean_iters_per_tick": [float(a) for a, _, _ in its], "converged_frac": sum(p[0] for p in allp) / max(sum(p[1] for p in allp), 1.0),
                       "max_iters_per_tick": [int(c) for _, _, c in its],
                       "lds_bytes_per_problem": eng.lds_bytes, "problems_per_cu": eng.problems_per_cu},

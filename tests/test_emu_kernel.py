@@ -211,3 +211,21 @@ def test_emu_custom_weights_and_limits(fast):
     d["x_init"] = np.clip(d["x_init"], par.xlim[0], par.xlim[1])
     r, e = _cmp(par, d, d["obs"], np.zeros((B, 20, 5)), fast=fast)
     assert (np.abs(e["U"][:, :, 0]) > 1.0 - 1e-6).any()      # the merged box min(ulim, u_last + dulim) = 1.0 binds
+
+
+@pytest.mark.parametrize("fast", [False, True])
+def test_second_order_correction_on_the_round3_tail(fast):
+    """Five C5 solves (N = 30, 8 moving obstacles, warm start per mpc_wholebody_qref.py:301-310) recorded on the GPU in round 3 -
+    the two that stopped at the reference's iteration cap and three other stragglers of that run (tests/golden/c5_tail_cases.npz:
+    inputs, and the iteration counts of the round-3 solver on the C oracle: 2966, 2132, 32, 33, 56): near-degenerate minima beside
+    an active circle row, where a step the linearised row allows violates it to second order.  With the second-order correction (and the inertia correction) they take 27-46 iterations on the C oracle, and the
+    host builds of both kernels - the specialised one runs its corrected passes in the second copy of its loop, with the
+    gains in the global block of the long horizons - follow it iteration for iteration."""
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "c5_tail_cases.npz"))
+    par = nlp.WholeBodyParams(N=30)
+    assert (z["round3_iters"][:2] > 2000).all()
+    o = coracle.solve_batch(par, z["x"], z["loc"], np.zeros_like(z["ul"]), z["ul"], z["obs"], max_iter=2000)
+    assert (o["status"] == 0).all() and o["iters"].max() <= 60, o["iters"]
+    e = emu_helper.solve_batch(par, z["x"], z["loc"], np.zeros_like(z["ul"]), z["ul"], z["obs"], fast=fast, max_iter=2000)
+    assert (e["status"] == 0).all() and np.array_equal(e["iters"], o["iters"]), (e["iters"], o["iters"])
+    assert np.abs(e["X"] - o["X"]).max() < TOL and np.abs(e["U"] - o["U"]).max() < 1e-5
