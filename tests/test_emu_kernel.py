@@ -150,7 +150,14 @@ def test_emu_under_asan():
             "assert (e['status']==0).all()\n"
             "d=synth.make_batch(2,N=15,M=3,kind='base')\n"
             "e=emu_helper.solve_batch(nlp.BaseParams(N=15),d['x_init'],d['traj_ref'],d['u_ref'],np.zeros((2,15,2)),d['obs'],asan=True)\n"
-            "assert (e['status']==0).all(); print('ASAN-OK')\n") % (emu_helper._HERE + "/..", emu_helper._HERE)
+            "assert (e['status']==0).all()\n"
+            # the second-order correction's passes (its scratch is an exact-size heap block here, global memory on the device): two of the
+            # round-3 tail cases on both kernels, N = 30 with the gains in their global block
+            "import os; z=np.load(os.path.join(%r,'golden','c5_tail_cases.npz')); p30=nlp.WholeBodyParams(N=30)\n"
+            "for f in (False, True):\n"
+            "    e=emu_helper.solve_batch(p30,z['x'][:2],z['loc'][:2],np.zeros((2,30,5)),z['ul'][:2],z['obs'][:2],asan=True,fast=f,max_iter=2000)\n"
+            "    assert (e['status']==0).all() and e['iters'].max()<=60\n"
+            "print('ASAN-OK')\n") % (emu_helper._HERE + "/..", emu_helper._HERE, emu_helper._HERE)
     libasan = subprocess.check_output(["gcc", "-print-file-name=libasan.so"]).decode().strip()
     env = dict(os.environ, LD_PRELOAD=libasan, ASAN_OPTIONS="detect_leaks=0")
     p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
