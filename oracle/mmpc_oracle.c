@@ -50,9 +50,9 @@
  * theta(x_k) <= [20] theta_min (0: always) | [25] an iteration whose predecessor needed a correction above this starts from
  * the corrected matrix at once (0: always try the uncorrected matrix first, as IPOPT does) */
 static double LAB[32] = {1, 1, 2, 0, 0, 0, 1, 4, 4, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 1, 0, 0, 0, 0, 0.1};
-static long long LAB_NTRIAL = 0, LAB_NFACT = 0, LAB_NSOC = 0, LAB_NSOCOK = 0, LAB_NSOCFAIL = 0, LAB_DH[20] = {0};
+static long long LAB_NTRIAL = 0, LAB_NFACT = 0, LAB_NSOC = 0, LAB_NSOCOK = 0, LAB_NSOCFAIL = 0;
 void mmpc_oracle_set_lab(int i, double v) { if (i >= 0 && i < 32) LAB[i] = v; }
-double mmpc_oracle_get_lab(int i) { return i >= 200 && i < 220 ? (double)LAB_DH[i - 200] : i == 104 ? (double)LAB_NTRIAL : i == 100 ? (double)LAB_NFACT : i == 101 ? (double)LAB_NSOC : i == 102 ? (double)LAB_NSOCOK : i == 103 ? (double)LAB_NSOCFAIL : (i >= 0 && i < 32 ? LAB[i] : 0.0); }
+double mmpc_oracle_get_lab(int i) { return i == 104 ? (double)LAB_NTRIAL : i == 100 ? (double)LAB_NFACT : i == 101 ? (double)LAB_NSOC : i == 102 ? (double)LAB_NSOCOK : i == 103 ? (double)LAB_NSOCFAIL : (i >= 0 && i < 32 ? LAB[i] : 0.0); }
 
 typedef struct {
     int kind;            /* 0 whole-body (nx=9,nu=5), 1 base-only (nx=6,nu=2) */
@@ -441,13 +441,12 @@ static void merit_parts(work *w, double X[NSM][NXM], double U[NSM][NUM], const d
 }
 
 /* Cholesky of n x n (row-major, leading dim NUM); returns 0 if a pivot is not > 0 */
-static __thread double chol_dfail = 0.0;   /* the pivot a factorisation failed on */
 static int chol(double H[NUM][NUM], int n, double L[NUM][NUM]) {
     memset(L, 0, sizeof(double) * NUM * NUM);
     for (int j = 0; j < n; j++) {
         double d = H[j][j];
         for (int k = 0; k < j; k++) d -= L[j][k] * L[j][k];
-        if (!(d > 0.0) || !isfinite(d)) { chol_dfail = d; return 0; }
+        if (!(d > 0.0) || !isfinite(d)) return 0;
         L[j][j] = sqrt(d);
         for (int i = j + 1; i < n; i++) {
             double v = H[i][j];
@@ -816,13 +815,13 @@ int mmpc_oracle_solve(const oracle_cfg *cfg, const double *x_init, const double 
             w->X[k][j] = bound_push(w->X[k][j], w->act[k][SL_XLO(w, j)] ? w->bnd[k][SL_XLO(w, j)] : -INFINITY,
                                     w->act[k][SL_XHI(w, j)] ? w->bnd[k][SL_XHI(w, j)] : INFINITY);
     }
-    double mu = LAB[10] > 0 ? LAB[10] : cfg->mu_init;
+    double mu = cfg->mu_init;
     eval_rows(w, w->X, w->U, w->s, w->h, 0);
     int nrows_act = 0;
     for (int k = 0; k <= N; k++) for (int r = 0; r < w->nrow; r++) if (w->act[k][r]) {
         double v = -w->h[k][r]; w->t[k][r] = v > 1e-2 ? v : 1e-2; w->z[k][r] = mu / w->t[k][r]; nrows_act++; }
     int status = 1, it = 0, nf = 0, nsmall = 0;
-    double prox = 0.0, delta_last = 0.0, delta_prev_it = 0.0; int soc_off = 0; work *sv = 0;
+    double prox = 0.0, delta_last = 0.0, delta_prev_it = 0.0; work *sv = 0;
     double th_max = 0, th_min = 0, E0 = 0;
     fent filt[FCAP];
     int filt_init = 0, nfilt = 0;
@@ -922,14 +921,11 @@ int mmpc_oracle_solve(const oracle_cfg *cfg, const double *x_init, const double 
             if (!okf) {                                                                                                      \
                 const double d0 = LAB[6] > 0 ? LAB[6] : 1e-4, kfirst = LAB[7] > 0 ? LAB[7] : 100.0, kup = LAB[8] > 0 ? LAB[8] : 8.0, kdn = LAB[9] > 0 ? LAB[9] : 1.0 / 3.0; \
                 double dw = delta_last == 0.0 ? d0 : fmax(1e-20, kdn * delta_last);                                          \
-                if (LAB[21] > 0 && isfinite(chol_dfail)) dw = fmax(dw, LAB[21] * fabs(chol_dfail));                          \
                 while (!(okf = factor(w, mu, 2, prox + dw))) {                                                               \
-                    dw *= delta_last == 0.0 ? kfirst : kup;  __atomic_fetch_add(&LAB_DH[1], 1, __ATOMIC_RELAXED);           \
-                    if (LAB[21] > 0 && isfinite(chol_dfail)) dw = fmax(dw, LAB[21] * fabs(chol_dfail));                      \
+                    dw *= delta_last == 0.0 ? kfirst : kup;                                                                  \
                     if (dw > 1e40) break;                                                                                    \
                 }                                                                                                            \
                 if (!okf) { FAILSTMT; }                                                                                      \
-                __atomic_fetch_add(&LAB_DH[0], 1, __ATOMIC_RELAXED); if (delta_last == 0.0) __atomic_fetch_add(&LAB_DH[2], 1, __ATOMIC_RELAXED); \
                 delta_last = dw; delta_used = dw;                                                                            \
             }                                                                                                                \
         } else if (!factor(w, mu, 2, prox)) if ((rung = 1, cfg->terminal_xy_eq || w->nhs > 0 || !factor(w, mu, 1, prox))) { \
@@ -951,9 +947,8 @@ int mmpc_oracle_solve(const oracle_cfg *cfg, const double *x_init, const double 
         double phi0, th0;
         merit_parts(w, w->X, w->U, w->s, w->t, mu, &phi0, &th0);
         if (!filt_init) { nfilt = 0; th_max = 1e4 * fmax(1.0, th0); th_min = 1e-4 * fmax(1.0, th0); filt_init = 1; }
-        double alpha = ap; int accepted = 0, soc_used = 0, null_step = 0, z_done = 0;
-        const int soc_max = soc_off ? 0 : (int)LAB[2];
-        soc_off = 0;
+        double alpha = ap; int accepted = 0, soc_used = 0, z_done = 0;
+        const int soc_max = (int)LAB[2];
 #define TRIAL_POINT(A)                                                                                                      \
         for (int k = 0; k <= N; k++) {                                                                                       \
             for (int j = 0; j < nx; j++) Xn[k][j] = w->X[k][j] + (A) * w->dX[k][j];                                          \
@@ -979,7 +974,7 @@ int mmpc_oracle_solve(const oracle_cfg *cfg, const double *x_init, const double 
                 }                                                                                                            \
             }                                                                                                                \
         }
-        for (int lspass = 0; lspass < 2 && !accepted && !null_step; lspass++) {
+        for (int lspass = 0; lspass < 2 && !accepted; lspass++) {
             alpha = ap;
             for (int ls = 0; ls < 20; ls++) {
                 TRIAL_POINT(alpha)
@@ -1043,7 +1038,6 @@ int mmpc_oracle_solve(const oracle_cfg *cfg, const double *x_init, const double 
                     memcpy(w->c, c0s, sizeof(c0s)); memcpy(w->h, h0s, sizeof(h0s));
                     if (soc_ok) { accepted = 1; break; }
                     __atomic_fetch_add(&LAB_NSOCFAIL, 1, __ATOMIC_RELAXED);
-                    if (LAB[19] >= 1.0) { null_step = 1; soc_off = 1; break; }
                     /* the correction failed: the line search goes on along the uncorrected direction */
                     memcpy(w->dX, sv->dX, sizeof(w->dX)); memcpy(w->dU, sv->dU, sizeof(w->dU)); memcpy(w->ds, sv->ds, sizeof(w->ds));
                     memcpy(w->lamn, sv->lamn, sizeof(w->lamn)); memcpy(w->dt_, sv->dt_, sizeof(w->dt_));
@@ -1051,20 +1045,19 @@ int mmpc_oracle_solve(const oracle_cfg *cfg, const double *x_init, const double 
                 }
                 if (ls < 19) alpha *= 0.5;
             }
-            if (accepted || null_step || nfilt == 0) break;
+            if (accepted || nfilt == 0) break;
             nfilt = 0; /* filter reset heuristic: the filter blocked every trial step */
         }
         nf += !accepted;
-        if (null_step) alpha = 0.0;
-        if (getenv("MMPC_ORACLE_DEBUG")) fprintf(stderr, "it %d mu %.2e E0 %.3e err_d %.3e err_p %.3e comp %.3e alpha %.3e ap %.3e ad %.3e acc %d prox %.1e dphi %.3e rung %d dw %.1e th %.2e soc %d | k %d r %d t %.2e dt %.2e z %.2e\n", it, mu, E0, err_d, err_p, comp0, alpha, ap, ad, accepted, prox, dphi, rung, delta_used, th0, null_step ? -1 : soc_used, w->dbg_k, w->dbg_r, w->dbg_t, w->dbg_dt, w->dbg_z);
+        if (getenv("MMPC_ORACLE_DEBUG")) fprintf(stderr, "it %d mu %.2e E0 %.3e err_d %.3e err_p %.3e comp %.3e alpha %.3e ap %.3e ad %.3e acc %d prox %.1e dphi %.3e rung %d dw %.1e th %.2e soc %d | k %d r %d t %.2e dt %.2e z %.2e\n", it, mu, E0, err_d, err_p, comp0, alpha, ap, ad, accepted, prox, dphi, rung, delta_used, th0, soc_used, w->dbg_k, w->dbg_r, w->dbg_t, w->dbg_dt, w->dbg_z);
         /* proximal term for crawling iterations (oracle/ipm_numpy.py: Options.prox*) */
-        if (!null_step) {
+        {
             const double PX0 = LAB[15] > 0 ? LAB[15] : PROX0, PXLO = LAB[17] > 0 ? LAB[17] : PROX_LO; const int PXN = LAB[16] > 0 ? (int)LAB[16] : 2;
             const double a_px = LAB[18] >= 1.0 ? ap : alpha;
             nsmall = a_px < PXLO ? nsmall + 1 : 0;
             if (cfg->terminal_xy_eq || LAB[3] >= 1.0) prox = 0.0;   /* the forced correction E dx_N = e makes nu grow like prox */
-            else if (a_px < PXLO && (nsmall >= PXN || prox > 0.0)) { const double PXM = LAB[22] > 0 ? LAB[22] : PROX_MAX; prox = prox * 4.0 > PX0 ? prox * 4.0 : PX0; if (prox > PXM) prox = PXM; }
-            else if (alpha > (LAB[23] > 0 ? LAB[23] : 0.5)) prox = prox > PX0 * 1e-3 ? prox / (LAB[24] > 0 ? LAB[24] : 4.0) : 0.0;
+            else if (a_px < PXLO && (nsmall >= PXN || prox > 0.0)) { prox = prox * 4.0 > PX0 ? prox * 4.0 : PX0; if (prox > PROX_MAX) prox = PROX_MAX; }
+            else if (alpha > 0.5) prox = prox > PX0 * 1e-3 ? prox / 4.0 : 0.0;
         }
         /* ---- update */
         for (int j = 0; j < 2; j++) w->nu_eq[j] += alpha * (w->nu_new[j] - w->nu_eq[j]);
