@@ -18,7 +18,9 @@
  * The reference hands that NLP to CasADi 3.6.4 -> IPOPT -> MUMPS (requirements.txt:9), which
  * is not in this image; the solver below is the build's own interior-point method - the same
  * algorithm as oracle/ipm_numpy.py and the HIP kernels, written independently of the latter as
- * straightforward dense scalar code.
+ * straightforward dense scalar code.  Since round 4 it follows IPOPT (Waechter & Biegler 2006) in its termination test
+ * (eq. 5-6: complementarity over s_c), its inertia correction (Algorithm IC) and its second-order correction (section 2.4);
+ * constants and the three deviations are listed in DESIGN.md section 3.
  *
  * PARITY STATUS: model functions pinned by tests/golden (reference robot_models + sympy DH);
  * solve() output of the reference is UNPINNED (no executable IPOPT here, no reference tests);
@@ -1078,7 +1080,7 @@ int mmpc_oracle_solve(const oracle_cfg *cfg, const double *x_init, const double 
     }
     if (iters_out) *iters_out = it;
     if (cost_out) *cost_out = cost_fn(w, w->X, w->U, w->s);
-    if (err_out) *err_out = E0;
+    if (err_out) *err_out = LAB[26] >= 1.0 ? mu : E0;   /* ([26]: experiments read the barrier parameter reached) */
     (void)nf;
     free(w); free(sv);
     return status;
