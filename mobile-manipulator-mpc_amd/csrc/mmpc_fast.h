@@ -107,6 +107,24 @@ MMPC_HD constexpr int mmpc_y(int a) { return a < 3 ? a : a + 3; }
 // distance of that size can round to zero: floor it at a couple of ulps.
 MMPC_DEV double mmpc_box_t(double d) { return mmpc_vmax(d, 1e-15); }
 
+#ifndef MMPC_SAFEGUARD_LAZY
+#define MMPC_SAFEGUARD_LAZY 1   // multiplier safeguard of the first trial: range check per row, exact clamp only if some row needs it (see apply_step; A/B switch)
+#endif
+#ifndef MMPC_TRGS
+#define MMPC_TRGS 9      // stride of the per-stage trig cache (8 words used): with 8 the stage lanes' words sit 16 dwords apart - two LDS banks for 21 lanes
+#endif
+#ifndef MMPC_LEG_LEAN
+#define MMPC_LEG_LEAN 1   // input elimination legs: pivot test and gain store behind the rank-one product, arithmetic lane-group masks (A/B switch)
+#endif
+#ifndef MMPC_D2_ONE_RCP
+#define MMPC_D2_ONE_RCP 1   // row steps D2: one reciprocal per row (see mmpc_fast_d2.inc; A/B switch)
+#endif
+#ifndef MMPC_FWD_DPP
+#define MMPC_FWD_DPP 1   // forward roll-out: dx_k by v_mov_b64_dpp row_newbcast instead of v_readlane pairs (A/B switch)
+#endif
+#ifndef MMPC_PADMAP
+#define MMPC_PADMAP 1    // padded pair map (see MmpcFastDims::PADMAP); 0: the plain map everywhere (A/B switch)
+#endif
 #ifndef MMPC_SLIM_NMIN
 #define MMPC_SLIM_NMIN 21  // horizons from here on: "slim" LDS layout (see mmpc_fast_layout) and circle rows spread over lanes
 #endif
@@ -116,7 +134,15 @@ struct MmpcFastDims {
     static constexpr int NX = D::NX, NU = D::NU, NV = D::NV, NXX = D::NXX, NUU = D::NUU, NSELF = D::NSELF;
     static constexpr int NS = N + 1;
     static constexpr int NPAIR = NS * NV;
-    static constexpr int NPASS = (NPAIR + MMPC_WAVE - 1) / MMPC_WAVE;
+    // Pair lanes: which (stage, variable) pair lane l works on in pass p.  Plain map: pair l + 64 p (k = idx / NV, v = idx % NV - a
+    // division by 14 and the addresses derived from it, ~25 instructions per pass in each of the four pair-lane phases of an
+    // iteration).  Padded map (where it needs no extra pass): a 16-lane row of the wave owns one stage per pass, row 4 p + (l >> 4),
+    // column l & 15 < NV is the variable; the pairs of the terminal stage (states only) sit in column NV of the first NX rows.  Every
+    // address is then base(l) + p * stride(l), both formed once per phase.
+    static constexpr bool PADMAP = MMPC_PADMAP && NV < 16 && NX <= N && (N * 16 + MMPC_WAVE - 1) / MMPC_WAVE <= (NPAIR + MMPC_WAVE - 1) / MMPC_WAVE;
+    // stride of the per-stage trig cache (8 words used; the long horizons have no LDS to spare for the padding)
+    static constexpr int TRGS = N >= MMPC_SLIM_NMIN ? 8 : MMPC_TRGS;
+    static constexpr int NPASS = PADMAP ? (N * 16 + MMPC_WAVE - 1) / MMPC_WAVE : (NPAIR + MMPC_WAVE - 1) / MMPC_WAVE;
     // Riccati recursion on 16x16 MFMA tiles in homogeneous form: tile index t < NX is state t, t = NX the constant 1 (its
     // row and column carry the gradient), NX < t <= NV input t-NX-1.  K-blocks (4 rows each) that cover the (x, 1) rows /
     // the input rows, accumulator registers that hold the input rows NX+1..NV of the stage matrix
@@ -184,7 +210,7 @@ MMPC_HD constexpr MmpcFastLayout mmpc_fast_layout(int M, int obs_per_stage) {
     MMPC_CARVE(XU, F::NS * F::NV) MMPC_CARVE(S, F::NS) MMPC_CARVE(LAM, F::NS * F::NX)
     MMPC_CARVE(XUREF, SLIM ? 0 : F::NS * F::NV) MMPC_CARVE(ULAST, SLIM ? 0 : F::NS * F::NU)
     MMPC_CARVE(OBS, obs_per_stage ? (SLIM ? 0 : F::NS * M * 3) : M * 3)
-    MMPC_CARVE(CST, MMPC_C_SIZE) MMPC_CARVE(CV, F::NS * MMPC_NCV) MMPC_CARVE(CD, F::NS * F::NX) MMPC_CARVE(TRG, F::NS * 8)
+    MMPC_CARVE(CST, MMPC_C_SIZE) MMPC_CARVE(CV, F::NS * MMPC_NCV) MMPC_CARVE(CD, F::NS * F::NX) MMPC_CARVE(TRG, F::NS * F::TRGS)
     MMPC_CARVE(HXX, F::NS * F::NXX) MMPC_CARVE(QXU, F::NS * F::NV) MMPC_CARVE(HUXL, F::NU * F::NX)
     MMPC_CARVE(HUUL, F::NUU) MMPC_CARVE(HUX02, F::NS) MMPC_CARVE(HUUD, F::NS * F::NU) MMPC_CARVE(SN, 16)
     MMPC_CARVE(KK, GK ? 0 : N * F::NU * F::NX) MMPC_CARVE(KF, GK ? 0 : N * F::NU) MMPC_CARVE(DXU, F::NS * F::NV) MMPC_CARVE(DS, F::NS)
@@ -235,6 +261,7 @@ struct MmpcLaneState {
                                                      // offset at stage 0 and per-stage stride (gain row / kf / coupling; a dump slot otherwise)
     MmpcAcc rP, rT, rM;                              // cost-to-go [P p; p^T .], its product T with the dynamics, stage matrix M
     double rAB[F::NKB], opa, opb;                    // MFMA operands
+    double mg[4], pv0, pv1;                          // elimination legs: 0 / 1 masks of the four lane groups; the pivots of the leg under way
     double nab[F::NKB], nhm[4];                      // next stage's dynamics rows and stage-matrix entries (loaded one stage ahead)
     // forward roll-out, row `lane` of [A B] (base.py:19-26): dx+[i] = dx[i] + sum_{j=2..5} C_j dx[j] + C_u du_a + c[i];
     // f_v: coefficient ids (into CV[k]) of C_2..C_5, f_x: id of C_u << 8 | (a + 1) << 16 (a: the input of this row, -1 none)
@@ -292,6 +319,18 @@ static inline double mmpc_emu_red(double (*wr)[9], int i, int op) {
 #define MMPC_RED_MAX(i) mmpc_emu_red(wr_all, i, 1)
 #define MMPC_RED_MIN(i) mmpc_emu_red(wr_all, i, 2)
 #endif
+
+// pair lanes (MmpcFastDims::PADMAP): per phase, the lane's base index and per-pass stride; per pass, the pair's index into XU / DXU / RB /
+// QXU (`idx`), whether the slot holds a pair (`pok`), its stage and variable (`k`, `v`)
+#define MMPC_PAIR_SETUP                                                                                                         \
+    const int pg_ = lane >> 4, pc_ = lane & 15; const bool pt_ = F::PADMAP && pc_ == NV;                                         \
+    const int pb_ = F::PADMAP ? (pt_ ? N * NV + pg_ : pg_ * NV + pc_) : lane, ps_ = F::PADMAP ? (pt_ ? 4 : 4 * NV) : MMPC_WAVE;   \
+    (void)pg_; (void)pc_; (void)pt_;
+#define MMPC_PAIR(p)                                                                                                            \
+    const int idx = pb_ + (p) * ps_;                                                                                            \
+    const bool pok = F::PADMAP ? (pt_ ? 4 * (p) + pg_ < NX : (pc_ < NV && 4 * (p) + pg_ < N)) : idx < NPAIR;
+#define MMPC_PAIR_KV(p)                                                                                                         \
+    const int k = F::PADMAP ? (pt_ ? N : 4 * (p) + pg_) : idx / NV, v = F::PADMAP ? (pt_ ? 4 * (p) + pg_ : pc_) : idx % NV;
 
 // compile-time switch handed to the generic lambdas of the assembly / row-step phases (corrected pass of the second-order correction or not)
 template <bool B> struct MmpcTag { static constexpr bool value = B; };
@@ -529,13 +568,14 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
     // ------------------------------------------------------------------ slack / multiplier init
     LANES_BEGIN
     auto &ls = MMPC_LS;
+    MMPC_PAIR_SETUP
 #pragma unroll
     for (int p = 0; p < NPASS; p++) {
         mmpc_sched_fence();
-        const int idx = lane + MMPC_WAVE * p;
+        MMPC_PAIR(p)
         ls.lo_z[p] = 0.0; ls.hi_z[p] = 0.0; ls.b_lo[p] = -1e300; ls.b_hi[p] = 1e300;
-        if (idx < NPAIR) {
-            const int k = idx / NV, v = idx % NV;
+        if (pok) {
+            MMPC_PAIR_KV(p)
             double lo, hi; bool alo, ahi;
             pair_bounds(k, v, lo, hi, alo, ahi);
             const double val = XU[idx];
@@ -632,6 +672,18 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
     //      d_alpha times the direction (signed: a rejected trial is moved back by the difference); with `first` also the
     //      row multipliers by alpha_d (they do not depend on alpha; evaluated with the slacks of the point the step starts at)
     auto apply_step = [&](double d_alpha, bool first) {
+        // Multiplier safeguard of the first trial (mmpc_z_safeguard: z clamped to [mu / (kappa t), kappa mu / t], kappa = 1e10), lazily:
+        // the clamp needs 1 / t_new per row and changes nothing unless t z has left [mu / kappa, kappa mu] - which no solve of the
+        // bench batches ever does.  The rows only track the range of t z (a multiply, a min, a max); if any row of the wave comes
+        // within a factor 2 of either end, a second phase clamps every row exactly, from the same (z, t, mu) - the result is the one
+        // of the eager clamp in every case.
+        double pz_lo = 1e300, pz_hi = 0.0;
+        auto zsafe = [&](double zn, double tn) -> double {
+            if (!MMPC_SAFEGUARD_LAZY) return mmpc_z_safeguard_fast(zn, tn, mu);
+            const double pz = zn * tn;
+            pz_lo = mmpc_vmin(pz_lo, pz); pz_hi = mmpc_vmax(pz_hi, pz);
+            return zn;
+        };
         LANES_BEGIN
         auto &ls = MMPC_LS;
         {
@@ -641,7 +693,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                 for (int r = 0; r < MCR; r++) {
                     if (RG == 1 || rs + RG * r < M) {
                         const double t = ls.ct[r], z = ls.cz[r], dtv = ls.cdt[r], tn = t + d_alpha * dtv;
-                        if (first) { const double it_ = mmpc_rcp(t); ls.cz[r] = mmpc_z_safeguard_fast(z + ad * (mu * it_ - z - z * it_ * dtv), tn, mu); }
+                        if (first) { const double it_ = mmpc_rcp(t); ls.cz[r] = zsafe(z + ad * (mu * it_ - z - z * it_ * dtv), tn); }
                         ls.ct[r] = tn;
                     }
                 }
@@ -651,30 +703,57 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
 #pragma unroll
             for (int i = 0; i < NSELF; i++) {
                 const double t = ls.st[i], z = ls.sz[i], dtv = ls.sdt[i], tn = t + d_alpha * dtv;
-                if (first) { const double it_ = mmpc_rcp(t); ls.sz[i] = mmpc_z_safeguard_fast(z + ad * (mu * it_ - z - z * it_ * dtv), tn, mu); }
+                if (first) { const double it_ = mmpc_rcp(t); ls.sz[i] = zsafe(z + ad * (mu * it_ - z - z * it_ * dtv), tn); }
                 ls.st[i] = tn;
             }
         }
         // (same phase: every lane touches only its own registers and its own words of XU / LAM / S)
+        MMPC_PAIR_SETUP
 #pragma unroll
         for (int p = 0; p < NPASS; p++) {
             mmpc_sched_fence();
-            const int idx = lane + MMPC_WAVE * p;
-            if (idx < NPAIR) {
-                const double val = XU[idx], dv = DXU[idx];
+            MMPC_PAIR(p)
+            if (pok) {
+                const double val = XU[idx], dv = DXU[idx], vn = val + d_alpha * dv;
                 if (first) {
                     const double lo = ls.b_lo[p], hi = ls.b_hi[p];
                     const bool alo = lo > -1e299, ahi = hi < 1e299;
-                    const double vn = val + d_alpha * dv;
-                    if (alo) { const double z = ls.lo_z[p], it_ = mmpc_rcp(mmpc_box_t(val - lo)); ls.lo_z[p] = mmpc_z_safeguard_fast(z + ad * (mu * it_ - z - z * it_ * dv), mmpc_box_t(vn - lo), mu); }
-                    if (ahi) { const double z = ls.hi_z[p], it_ = mmpc_rcp(mmpc_box_t(hi - val)); ls.hi_z[p] = mmpc_z_safeguard_fast(z + ad * (mu * it_ - z + z * it_ * dv), mmpc_box_t(hi - vn), mu); }
+                    if (alo) { const double z = ls.lo_z[p], it_ = mmpc_rcp(mmpc_box_t(val - lo)); ls.lo_z[p] = zsafe(z + ad * (mu * it_ - z - z * it_ * dv), mmpc_box_t(vn - lo)); }
+                    if (ahi) { const double z = ls.hi_z[p], it_ = mmpc_rcp(mmpc_box_t(hi - val)); ls.hi_z[p] = zsafe(z + ad * (mu * it_ - z + z * it_ * dv), mmpc_box_t(hi - vn)); }
                 }
-                if (idx >= NX) XU[idx] = val + d_alpha * dv;   // x_0 is data
+                if (idx >= NX) XU[idx] = vn;   // x_0 is data
             }
         }
         for (int i = lane; i < NS * NX; i += MMPC_WAVE) if (i >= NX) LAM[i] += d_alpha * DLAM[i];
         for (int i = lane; i < NS; i += MMPC_WAVE) S[i] += d_alpha * DS[i];
         LANES_END
+        if (MMPC_SAFEGUARD_LAZY && first && MMPC_WAVE_ANY(!(pz_lo >= 2.0 * mu * (1.0 / MMPC_KAPPA_SIGMA) && pz_hi <= 0.5 * MMPC_KAPPA_SIGMA * mu))) {
+            // (rare) the exact clamp of every row, at the slacks of the trial point
+            LANES_BEGIN
+            auto &ls = MMPC_LS;
+            {
+                MMPC_ROW_LANE
+                if (rlane) {
+#pragma unroll
+                    for (int r = 0; r < MCR; r++) if (RG == 1 || rs + RG * r < M) ls.cz[r] = mmpc_z_safeguard_fast(ls.cz[r], ls.ct[r], mu);
+                }
+            }
+            if (lane < NS) {
+#pragma unroll
+                for (int i = 0; i < NSELF; i++) ls.sz[i] = mmpc_z_safeguard_fast(ls.sz[i], ls.st[i], mu);
+            }
+            MMPC_PAIR_SETUP
+#pragma unroll
+            for (int p = 0; p < NPASS; p++) {
+                MMPC_PAIR(p)
+                if (pok) {
+                    const double lo = ls.b_lo[p], hi = ls.b_hi[p], vn = XU[idx];
+                    if (lo > -1e299) ls.lo_z[p] = mmpc_z_safeguard_fast(ls.lo_z[p], mmpc_box_t(vn - lo), mu);
+                    if (hi < 1e299) ls.hi_z[p] = mmpc_z_safeguard_fast(ls.hi_z[p], mmpc_box_t(hi - vn), mu);
+                }
+            }
+            LANES_END
+        }
     };
 
     // ---- second-order correction (Waechter & Biegler 2006, section 2.4; algorithm and deviations: mmpc_core.h).  This kernel moves to
@@ -738,10 +817,10 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
         }
         if (NSELF && lane < NS) {
             const int k = lane;
-            const double sn = TRG[k * 8], cs = TRG[k * 8 + 1], sks = S[slack_idx(k)];
+            const double sn = TRG[k * F::TRGS], cs = TRG[k * F::TRGS + 1], sks = S[slack_idx(k)];
             double dr[3], dz[3], swr = 0.0;
 #pragma unroll
-            for (int a = 0; a < 3; a++) { dr[a] = TRG[k * 8 + 2 + a]; dz[a] = TRG[k * 8 + 5 + a]; }
+            for (int a = 0; a < 3; a++) { dr[a] = TRG[k * F::TRGS + 2 + a]; dz[a] = TRG[k * F::TRGS + 5 + a]; }
 #pragma unroll
             for (int i = 0; i < NSELF; i++) {
                 const double rr = mmpc_self_row(i, XU[k * NV], XU[k * NV + 1], cs, sn, dr, dz, nullptr) - sks + ls.st[i];

@@ -10,7 +10,9 @@
 // is read across lanes and rewritten in the same phase is double-buffered by the parity of the stage)
 #define MMPC_LANE_GET(field, j) (ls_all[j].field)
 #define MMPC_LANE_XOR16(field) (ls_all[lane ^ 16].field)
+#define MMPC_LANE_LOWER16(field) (ls_all[lane & ~16].field)
 #define MMPC_FW_SLOTS 2
+#define MMPC_WAVE_ANY(x) (x)     // (a flag declared outside the lane loop has been or-ed / min-ed over the lanes by the loop itself)
 #define MMPC_FW_SLOT(k) ((k) & 1)
 #define LANES_END_REG }
 #else
@@ -18,7 +20,9 @@
 #define MMPC_WR(i) wr_one[i]
 #define MMPC_LANE_GET(field, j) mmpc_readlane_f64(ls_one.field, j)
 #define MMPC_LANE_XOR16(field) mmpc_xor16_f64(ls_one.field, lane)
+#define MMPC_LANE_LOWER16(field) mmpc_lower16_f64(ls_one.field)
 #define MMPC_FW_SLOTS 1
+#define MMPC_WAVE_ANY(x) (__builtin_amdgcn_ballot_w64(x) != 0ull)   // true in every lane if the flag is set in any
 #define MMPC_FW_SLOT(k) 0
 #define LANES_END_REG }      // end of a phase whose results travel in registers only: no LDS ordering to enforce
 #endif
@@ -104,6 +108,22 @@ MMPC_DEV double mmpc_xor16_f64(double v, int lane) {
     const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
     const bool odd = (lane >> 4) & 1;
     return __hiloint2double(odd ? b[0] : b[1], odd ? a[0] : a[1]);
+}
+// value of lane J of the caller's own row of 16 lanes, in every lane of that row: ONE v_mov_b64_dpp row_newbcast (the only DPP
+// control the double-precision pipe takes) instead of two v_readlane_b32 into a scalar pair and the scalar-operand hazards after them
+template <int J>
+MMPC_DEV double mmpc_rowbcast_f64(double v) { return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + J, 0xf, 0xf, true); }
+template <int J0, int NJ>
+MMPC_DEV void mmpc_rowbcast_all(double x, double *out) {
+    if constexpr (J0 < NJ) { out[J0] = mmpc_rowbcast_f64<J0>(x); mmpc_rowbcast_all<J0 + 1, NJ>(x, out); }
+}
+// value of the EVEN row of 16 lanes of the caller's pair of rows (lane & ~16): what the odd rows get is their lower neighbour's
+// word, the even rows keep their own (v_permlane16_swap_b32 x 2 without the select of mmpc_xor16_f64)
+MMPC_DEV double mmpc_lower16_f64(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double(b[0], a[0]);
 }
 // Wave-wide reductions as a butterfly over the steps 1, 2, 4, 8, 16, 32 without the LDS crossbar (ds_bpermute: 57 cycles per
 // step, tools/lat_probe.hip): the partner's value comes through DPP inside a row of 16 lanes (quad permutes for 1 and 2;
