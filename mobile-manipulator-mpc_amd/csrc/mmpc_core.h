@@ -27,6 +27,7 @@
 #define MMPC_HD inline
 #define MMPC_CONST static const
 #define LANES_BEGIN for (int lane = emu.first; lane != emu.end; lane += emu.step) {
+#define LANES_BEGIN_NL LANES_BEGIN
 #define LANES_END }
 struct MmpcEmu { int first, end, step; };
 #define MMPC_EMU_ARG , MmpcEmu emu
@@ -38,6 +39,8 @@ struct MmpcEmu { int first, end, step; };
 // lane-derived address out of the solver's loops and the hoisted values alone exceed the register file.
 __device__ __forceinline__ int mmpc_lane_id() { int l = (int)threadIdx.x; asm volatile("" : "+v"(l)); return l; }
 #define LANES_BEGIN { const int lane = mmpc_lane_id();
+// a phase whose device code does not use the lane id (register-only blocks inside the stage loops: the opaque copy is one v_mov each)
+#define LANES_BEGIN_NL {
 // End of a phase.  A workgroup is ONE wavefront, and the LDS unit executes the LDS instructions of a wavefront in issue
 // order: what one lane wrote in a phase is visible to every lane's reads of the next phase without waiting for the
 // writes to retire.  So no s_barrier and no s_waitcnt here - only a fence that keeps the COMPILER from moving memory

@@ -28,9 +28,17 @@ __device__ unsigned long long mmpc_stamp_acc[16];
 #define MMPC_T0() unsigned long long t_prev_ = __builtin_readcyclecounter(), t_now_, t_acc_[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define MMPC_TS(i) { t_now_ = __builtin_readcyclecounter(); t_acc_[i] += t_now_ - t_prev_; t_prev_ = t_now_; }
 #define MMPC_TEND() { if (threadIdx.x == 0) for (int i_ = 0; i_ < 14; i_++) atomicAdd(&mmpc_stamp_acc[i_], t_acc_[i_]); }
+// stamps inside the stage loop of the backward pass (three per stage: reading the counter waits for the scalar cache and drains the
+// LDS queue, ~5 k cycles per iteration in all); -DMMPC_STAMP_COARSE leaves them out - the pass is then one segment, booked under stamp 8
+#ifdef MMPC_STAMP_COARSE
+#define MMPC_TSF(i)
+#else
+#define MMPC_TSF(i) MMPC_TS(i)
+#endif
 #else
 #define MMPC_T0()
 #define MMPC_TS(i)
+#define MMPC_TSF(i)
 #define MMPC_TEND()
 #endif
 // A wave's stores to global memory (the gain block of long horizons) followed by loads of the same words from other lanes of the
@@ -110,8 +118,19 @@ MMPC_DEV double mmpc_box_t(double d) { return mmpc_vmax(d, 1e-15); }
 #ifndef MMPC_SAFEGUARD_LAZY
 #define MMPC_SAFEGUARD_LAZY 1   // multiplier safeguard of the first trial: range check per row, exact clamp only if some row needs it (see apply_step; A/B switch)
 #endif
+// scheduler fences of this file by site: bit i of MMPC_FENCE_MASK keeps fence i (0 init, 1 trial move pairs, 2 E1 stage loads, 3 / 4 E1 pair
+// pass / loads, 5 / 6 A1 pair pass / loads, 7 leg before the product, 8 D1 loads, 9 A1 stage loads, 10 D2 pairs).  A lone wave issues a
+// dependent instruction every ~8 cycles and an independent one every ~4: fences that keep the unrolled bodies of a lane-parallel loop
+// apart (rounds 1-3: fewer live registers) cost more in issue bubbles than the register moves they save.
+#ifndef MMPC_FENCE_MASK
+#define MMPC_FENCE_MASK 0x000
+#endif
+#define MMPC_SFENCE(i) { if ((MMPC_FENCE_MASK >> (i)) & 1) mmpc_sched_fence(); }
 #ifndef MMPC_TRGS
 #define MMPC_TRGS 9      // stride of the per-stage trig cache (8 words used): with 8 the stage lanes' words sit 16 dwords apart - two LDS banks for 21 lanes
+#endif
+#ifndef MMPC_LEG_DET
+#define MMPC_LEG_DET 1    // pair legs: the second pivot's reciprocal from the 2 x 2 determinant, beside the first's (A/B switch)
 #endif
 #ifndef MMPC_LEG_LEAN
 #define MMPC_LEG_LEAN 1   // input elimination legs: pivot test and gain store behind the rank-one product, arithmetic lane-group masks (A/B switch)
@@ -571,7 +590,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
     MMPC_PAIR_SETUP
 #pragma unroll
     for (int p = 0; p < NPASS; p++) {
-        mmpc_sched_fence();
+        MMPC_SFENCE(0)
         MMPC_PAIR(p)
         ls.lo_z[p] = 0.0; ls.hi_z[p] = 0.0; ls.b_lo[p] = -1e300; ls.b_hi[p] = 1e300;
         if (pok) {
@@ -711,7 +730,7 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
         MMPC_PAIR_SETUP
 #pragma unroll
         for (int p = 0; p < NPASS; p++) {
-            mmpc_sched_fence();
+            MMPC_SFENCE(1)
             MMPC_PAIR(p)
             if (pok) {
                 const double val = XU[idx], dv = DXU[idx], vn = val + d_alpha * dv;

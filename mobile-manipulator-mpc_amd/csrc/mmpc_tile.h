@@ -32,18 +32,49 @@
 MMPC_DEV double mmpc_rcp(double x) { return 1.0 / x; }
 MMPC_DEV double mmpc_rsqrt(double x) { return 1.0 / sqrt(x); }
 MMPC_DEV double mmpc_rcp3(double x) { return 1.0 / x; }
+MMPC_DEV double mmpc_rcp_piv(double x) { return 1.0 / x; }
+#define MMPC_OPAQUE(x)
 MMPC_DEV double mmpc_powf(double x, float e) { return (double)exp2f(e * log2f((float)x)); }
 MMPC_DEV void mmpc_sched_fence() {}
 #else
 // v_rcp_f64 / v_rsq_f64 (seeds good to 2^-24, tools/rcp_probe.hip) + one cubic step: 1.1e-16 / 1.4e-16 worst relative error in three
 // / five dependent operations; the IEEE division / sqrt sequences are ~3x longer
+// (MMPC_RCP_NEWTON 1: one Newton step instead of the cubic one - a dependent operation less per call, relative error e^2 resp. 3/8 e^2
+//  <= 3.6e-15; A/B switch, default off: the slacks' reciprocals enter the multipliers' update)
+#ifndef MMPC_RCP_NEWTON
+#define MMPC_RCP_NEWTON 0
+#endif
 MMPC_DEV double mmpc_rcp(double x) {
     const double r = __builtin_amdgcn_rcp(x), e = fma(-x, r, 1.0);
+#if MMPC_RCP_NEWTON
+    return fma(e, r, r);
+#else
     return fma(fma(e, e, e), r, r);                    // r (1 + e + e^2), e = 1 - x r
+#endif
 }
 MMPC_DEV double mmpc_rcp3(double x) { return mmpc_rcp(x); }
+// reciprocal of a pivot of the elimination legs, where every dependent operation is on the critical path of a Riccati stage: the seed
+// and ONE Newton step, r (2 - x r): relative error e^2 <= 2^-48 (3.6e-15) in two dependent fma instead of three (MMPC_PIV_NEWTON 0: the
+// cubic step of mmpc_rcp).  The factorisation it feeds is backward stable in the usual sense either way: the pivots' own rounding
+// through twenty stages of rank-one updates is of that order.
+#ifndef MMPC_PIV_NEWTON
+#define MMPC_PIV_NEWTON 1
+#endif
+MMPC_DEV double mmpc_rcp_piv(double x) {
+#if MMPC_PIV_NEWTON
+    const double r = __builtin_amdgcn_rcp(x), e = fma(-x, r, 1.0);
+    return fma(e, r, r);
+#else
+    return mmpc_rcp(x);
+#endif
+}
+// keeps the compiler from re-deriving a value (e.g. forming w and then -w where -w is wanted first)
+#define MMPC_OPAQUE(x) asm volatile("" : "+v"(x))
 MMPC_DEV double mmpc_rsqrt(double x) {
     const double y = __builtin_amdgcn_rsq(x), e = fma(-(x * y), y, 1.0);
+#if MMPC_RCP_NEWTON
+    return fma(y * 0.5, e, y);
+#endif
     return fma(y * e, fma(0.375, e, 0.5), y);          // y (1 + e/2 + 3 e^2/8), e = 1 - x y^2
 }
 // x^e in single precision (only used by the filter's switching rule, a heuristic threshold)

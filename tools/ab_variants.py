@@ -38,13 +38,23 @@ a, ita, _, _ = run(1024, same=0)
 b, itb, cs, conv = run(8192, order=0)
 c, _, _, _ = run(8192, order=2)
 e, _, _, _ = run(8192, order=1)
-print("%%-8s  1024 x inst 0: %%7.3f ms (%%d it, %%.2f us/it)   8192: batch order %%7.3f  key %%7.3f  exact %%7.3f ms   iters mean %%.3f max %%d conv %%.4f  sum X %%.9f" %% (
-    os.environ.get("MMPC_AB_TAG", "?"), a, ita[0], a * 1e3 / ita[0], b, c, e, itb.mean(), itb.max(), conv, cs), flush=True)
+print("%%s %%.4f %%d %%.4f %%.4f %%.4f %%.3f %%d %%.4f %%.9f" %% (os.environ.get("MMPC_AB_TAG", "?"), a, ita[0], b, c, e, itb.mean(), itb.max(), conv, cs), flush=True)
 ''' % ROOT
 
-for tag in sys.argv[1:]:
-    lib = os.path.join(ROOT, "mobile-manipulator-mpc_amd", "csrc", "libmmpc.so" if tag == "ship" else "libmmpc_%s.so" % tag)
-    env = dict(os.environ, MMPC_LIB=lib, MMPC_AB_TAG=tag)
-    r = subprocess.run([sys.executable, "-c", WORKER], env=env, capture_output=True, text=True, timeout=600)
-    sys.stdout.write(r.stdout if r.returncode == 0 else "%s FAILED\n%s\n" % (tag, r.stderr[-2000:]))
-    sys.stdout.flush()
+ROUNDS = int(os.environ.get("MMPC_AB_ROUNDS", 3))
+tags = sys.argv[1:]
+res = {t: [] for t in tags}
+for r in range(ROUNDS):          # the variants interleaved, the best of the rounds per figure (run-to-run clock / power state: 1-2 %)
+    for tag in tags:
+        lib = os.path.join(ROOT, "mobile-manipulator-mpc_amd", "csrc", "libmmpc.so" if tag == "ship" else "libmmpc_%s.so" % tag)
+        env = dict(os.environ, MMPC_LIB=lib, MMPC_AB_TAG=tag)
+        p = subprocess.run([sys.executable, "-c", WORKER], env=env, capture_output=True, text=True, timeout=600)
+        if p.returncode != 0:
+            print("%s FAILED\n%s" % (tag, p.stderr[-2000:]), flush=True); continue
+        res[tag].append(p.stdout.split())
+for tag in tags:
+    v = res[tag]
+    if not v: continue
+    m = lambda i: min(float(x[i]) for x in v)
+    print("%-8s  1024 x inst 0: %7.3f ms (%s it, %.2f us/it)   8192: batch order %7.3f  key %7.3f  exact %7.3f ms   iters mean %s max %s conv %s  sum X %s" % (
+        tag, m(1), v[0][2], m(1) * 1e3 / int(v[0][2]), m(3), m(4), m(5), v[0][6], v[0][7], v[0][8], v[0][9]), flush=True)
