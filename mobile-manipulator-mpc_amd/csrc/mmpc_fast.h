@@ -132,9 +132,6 @@ MMPC_DEV double mmpc_box_t(double d) { return mmpc_vmax(d, 1e-15); }
 #ifndef MMPC_LEG_DET
 #define MMPC_LEG_DET 1    // pair legs: the second pivot's reciprocal from the 2 x 2 determinant, beside the first's (A/B switch)
 #endif
-#ifndef MMPC_LEG_LEAN
-#define MMPC_LEG_LEAN 1   // input elimination legs: pivot test and gain store behind the rank-one product, arithmetic lane-group masks (A/B switch)
-#endif
 #ifndef MMPC_D2_ONE_RCP
 #define MMPC_D2_ONE_RCP 1   // row steps D2: one reciprocal per row (see mmpc_fast_d2.inc; A/B switch)
 #endif
@@ -146,6 +143,12 @@ MMPC_DEV double mmpc_box_t(double d) { return mmpc_vmax(d, 1e-15); }
 #endif
 #ifndef MMPC_SLIM_NMIN
 #define MMPC_SLIM_NMIN 21  // horizons from here on: "slim" LDS layout (see mmpc_fast_layout) and circle rows spread over lanes
+#endif
+#ifndef MMPC_RG_NMIN
+#define MMPC_RG_NMIN MMPC_SLIM_NMIN   // horizons from here on spread the circle rows of a stage over RG lanes (A/B switch)
+#endif
+#ifndef MMPC_RG_MAX
+#define MMPC_RG_MAX 3
 #endif
 template <int KIND, int N>
 struct MmpcFastDims {
@@ -176,7 +179,7 @@ struct MmpcFastDims {
     // lanes travel through the first words of the stage's own - at that point dead - Hessian block.)  Short horizons keep the rows
     // in the stage lane, where their arithmetic fills the latency of the trigonometry around it (measured: -0.9 % at N = 20
     // when split, +11 % at N = 30, +2.6 % for the base kind).
-    static constexpr int RG = ((N >= MMPC_SLIM_NMIN || KIND == 1) && 2 * NS <= MMPC_WAVE) ? (MMPC_WAVE / NS < 3 ? MMPC_WAVE / NS : 3) : 1;
+    static constexpr int RG = ((N >= MMPC_RG_NMIN || KIND == 1) && 2 * NS <= MMPC_WAVE) ? (MMPC_WAVE / NS < MMPC_RG_MAX ? MMPC_WAVE / NS : MMPC_RG_MAX) : 1;
     static_assert(NV + 1 <= 16, "stage matrix over (x, 1, u) must fit one 16x16 tile");
 };
 

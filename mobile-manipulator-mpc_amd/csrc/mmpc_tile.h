@@ -33,7 +33,6 @@ MMPC_DEV double mmpc_rcp(double x) { return 1.0 / x; }
 MMPC_DEV double mmpc_rsqrt(double x) { return 1.0 / sqrt(x); }
 MMPC_DEV double mmpc_rcp3(double x) { return 1.0 / x; }
 MMPC_DEV double mmpc_rcp_piv(double x) { return 1.0 / x; }
-#define MMPC_OPAQUE(x)
 MMPC_DEV double mmpc_powf(double x, float e) { return (double)exp2f(e * log2f((float)x)); }
 MMPC_DEV void mmpc_sched_fence() {}
 #else
@@ -68,8 +67,6 @@ MMPC_DEV double mmpc_rcp_piv(double x) {
     return mmpc_rcp(x);
 #endif
 }
-// keeps the compiler from re-deriving a value (e.g. forming w and then -w where -w is wanted first)
-#define MMPC_OPAQUE(x) asm volatile("" : "+v"(x))
 MMPC_DEV double mmpc_rsqrt(double x) {
     const double y = __builtin_amdgcn_rsq(x), e = fma(-(x * y), y, 1.0);
 #if MMPC_RCP_NEWTON

@@ -18,8 +18,8 @@ def find(s, after=0):
         if i >= after and s in l: return i + 1
     raise KeyError(s)
 b = [('E1 stage', find('MMPC_TS(0)')), ('E1 pair', find('MMPC_TS(1)')), ('filter', find('if (in_ls) {')), ('conv', find('#if MMPC_ITER_SOC\n') if False else find("if (soc_st == 1) soc_rows(true")),
-     ('A1 stage', find('MMPC_TS(2)')), ('A1 pair', find('MMPC_TS(3)')), ('R0', find('MMPC_TS(4)')), ('R1R2', find('MMPC_TS(5)')), ('handover', find('MMPC_TS(6)')),
-     ('R3 legs', find('// R3: the inputs are eliminated')), ('Pstore', find('MMPC_TS(7)')), ('gains', find('if (ric_bad) failed = 1;')), ('forward', find('MMPC_TS(8)')),
+     ('A1 stage', find('MMPC_TS(2)')), ('A1 pair', find('MMPC_TS(3)')), ('R0', find('MMPC_TS(4)')), ('R1R2', find('MMPC_TSF(5)')), ('handover', find('MMPC_TSF(6)')),
+     ('R3 legs', find('// R3: the inputs are eliminated')), ('Pstore', find('MMPC_TSF(7)')), ('gains', find('if (ric_bad) failed = 1;')), ('forward', find('MMPC_TS(8)')),
      ('D1', find('MMPC_TS(9)')), ('D2', find('MMPC_TS(10)')), ('trial', find('MMPC_TS(11)')), ('end', len(src) + 1)]
 def phase(f, l, cur):
     if f == 'mmpc_fast_iter.inc':
