@@ -235,7 +235,9 @@ MMPC_HD constexpr MmpcFastLayout mmpc_fast_layout(int M, int obs_per_stage) {
     MMPC_CARVE(CST, MMPC_C_SIZE) MMPC_CARVE(CV, F::NS * MMPC_NCV) MMPC_CARVE(CD, F::NS * F::NX) MMPC_CARVE(TRG, F::NS * F::TRGS)
     MMPC_CARVE(HXX, F::NS * F::NXX) MMPC_CARVE(QXU, F::NS * F::NV) MMPC_CARVE(HUXL, F::NU * F::NX)
     MMPC_CARVE(HUUL, F::NUU) MMPC_CARVE(HUX02, F::NS) MMPC_CARVE(HUUD, F::NS * F::NU) MMPC_CARVE(SN, 16)
-    MMPC_CARVE(KK, GK ? 0 : N * F::NU * F::NX) MMPC_CARVE(KF, GK ? 0 : N * F::NU) MMPC_CARVE(DXU, F::NS * F::NV) MMPC_CARVE(DS, F::NS)
+    // (gains in LDS: one array [stage][input][NX + 1], the feed-forward kf as column NX of the gain row - the back-substitution and the
+    //  roll-out then address a row of NX + 1 words; in the gain block of the long horizons K and kf stay apart, see MmpcGainBlock)
+    MMPC_CARVE(KK, GK ? 0 : N * F::NU * (F::NX + 1)) MMPC_CARVE(KF, 0) MMPC_CARVE(DXU, F::NS * F::NV) MMPC_CARVE(DS, F::NS)
     MMPC_CARVE(DLAM, F::NS * F::NX) MMPC_CARVE(RB, F::NS * F::NV) MMPC_CARVE(RDS, F::NS) MMPC_CARVE(Q1V, F::NV + 2) MMPC_CARVE(FILT, 2 * MMPC_FCAP)
     // scratch of the backward pass lives, where it fits, in arrays that are dead while it runs: the couplings between the
     // inputs of a stage in the search direction (written by the forward roll-out afterwards), the dump slots in the
@@ -288,6 +290,8 @@ struct MmpcLaneState {
     // forward roll-out, row `lane` of [A B] (base.py:19-26): dx+[i] = dx[i] + sum_{j=2..5} C_j dx[j] + C_u du_a + c[i];
     // f_v: coefficient ids (into CV[k]) of C_2..C_5, f_x: id of C_u << 8 | (a + 1) << 16 (a: the input of this row, -1 none)
     unsigned f_v, f_x;
+    unsigned q1d[2];                                 // items of the stage-(N-1) rank-one blocks (quirk Q1) this lane forms: Q1V index | Q1V index << 5 |
+                                                     // accumulate << 10 | gradient item << 11 | LDS word offset of the target << 12
     double fw[MMPC_FW_SLOTS];                        // dx_k[lane] during the roll-out (exchanged by v_readlane, not LDS)
     int fw_a[5];                                     // where the lane stores dx_{k+1}[lane] and du_k[a]: LDS offsets at k = 0 and their stage stride
                                                      // (set once per roll-out: the lane id is opaque to the compiler in every phase)
@@ -400,7 +404,9 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
     typedef MmpcGainBlock<KIND, N> GB;
     constexpr bool GK = GB::ON;
     double *const KBASE = GK ? io.gscr : lds;     // what the store offsets of the elimination legs (kl_b) are relative to
-    double *const KK = GK ? io.gscr + GB::KK : lds + L.KK, *const KF = GK ? io.gscr + GB::KF : lds + L.KF, *const KU = GK ? io.gscr + GB::KU : lds + L.KU;
+    double *const KK = GK ? io.gscr + GB::KK : lds + L.KK, *const KF = GK ? io.gscr + GB::KF : lds + L.KK + NX, *const KU = GK ? io.gscr + GB::KU : lds + L.KU;
+    // stride of a gain row / of its feed-forward entry between inputs (LDS: rows of NX + 1 words with kf as the last one - KF points at it)
+    constexpr int KS = GK ? NX : NX + 1, KFS = GK ? 1 : NX + 1;
     constexpr int O_KK = GK ? GB::KK : 0, O_KF = GK ? GB::KF : 0, O_KU = GK ? GB::KU : 0, O_KDUMP = GK ? GB::DUMP : 0;
     // element `idx` of an array of the gain block: uniform base + 32-bit byte offset (the scalar-base form of the global
     // load / store: one address register per access instead of a 64-bit pair built per lane)
@@ -528,8 +534,9 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
             for (int a = a0; a < NU && a <= a0 + (F::PAIRS ? 1 : 0); a++) {
                 const int ta = NX + 1 + a;
                 if (g == (ta & 3)) {
-                    if (j < NX) { off = (unsigned)((GK ? O_KK : L.KK) + a * NX + j); stride = NU * NX; }
-                    else if (j == NX) { off = (unsigned)((GK ? O_KF : L.KF) + a); stride = NU; }
+                    if (!GK && j <= NX) { off = (unsigned)(L.KK + a * KS + j); stride = NU * KS; }
+                    else if (j < NX) { off = (unsigned)(O_KK + a * NX + j); stride = NU * NX; }
+                    else if (j == NX) { off = (unsigned)(O_KF + a); stride = NU; }
                     else if (j > ta && j <= NV) { const int b2 = j - NX - 1; off = (unsigned)((GK ? O_KU : L.KU) + a * (2 * NU - a - 1) / 2 + (b2 - a - 1)); stride = NPU; }
                 }
             }
@@ -549,6 +556,32 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
                 fx = (cu << 8) | ((unsigned)(a + 1) << 16);
             }
             ls.f_v = fv; ls.f_x = fx;
+            // items e = lane + 64 t of the dense blocks the elimination of s_{N-1} adds to stage N-1 (see the backward pass):
+            // Hxx -= a a^T / h (packed lower triangle), Hux = -b a^T / h, Huu = -b b^T / h, q += (a; b) gamma / h with (a; b) = Q1V[0 .. NV),
+            // gamma / h = Q1V[NV]; slots without an item multiply two zeros of the constant block into the lane's dump slot
+            static_assert(NXX + NU * NX + NUU + NV <= 2 * MMPC_WAVE && NV + 2 <= 32, "stage-(N-1) block items: two per lane");
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                const int e = lane + MMPC_WAVE * t;
+                unsigned ia = 0, ib = 0, acc = 0, grad = 0, dst = (unsigned)(L.DUMP + lane);
+                if (e < NXX) {
+                    int i = 0;
+                    while ((i + 1) * (i + 2) / 2 <= e) i++;
+                    ia = (unsigned)i; ib = (unsigned)(e - i * (i + 1) / 2); acc = 1; dst = (unsigned)(L.HXX + (N - 1) * NXX + e);
+                } else if (e < NXX + NU * NX) {
+                    const int c = (e - NXX) / NX, j = (e - NXX) % NX;
+                    ia = (unsigned)(NX + c); ib = (unsigned)j; dst = (unsigned)(L.HUXL + c * NX + j);
+                } else if (e < NXX + NU * NX + NUU) {
+                    const int q = e - NXX - NU * NX;
+                    int c = 0;
+                    while ((c + 1) * (c + 2) / 2 <= q) c++;
+                    ia = (unsigned)(NX + c); ib = (unsigned)(NX + q - c * (c + 1) / 2); dst = (unsigned)(L.HUUL + q);
+                } else if (e < NXX + NU * NX + NUU + NV) {
+                    const int j = e - NXX - NU * NX - NUU;
+                    ia = (unsigned)j; ib = (unsigned)NV; acc = 1; grad = 1; dst = (unsigned)(L.QXU + (N - 1) * NV + j);
+                }   // (else no item: -(Q1V[0]^2) / h into the lane's dump slot)
+                ls.q1d[t] = ia | (ib << 5) | (acc << 10) | (grad << 11) | (dst << 12);
+            }
         }
     }
     LANES_END
