@@ -361,12 +361,15 @@ static inline double mmpc_emu_red(double (*wr)[9], int i, int op) {
 // compile-time switch handed to the generic lambdas of the assembly / row-step phases (corrected pass of the second-order correction or not)
 template <bool B> struct MmpcTag { static constexpr bool value = B; };
 
-// product-of-mantissas accumulator for sum(log t)
+// product accumulator for sum(log t): the slacks themselves are multiplied and ONE logarithm is taken per lane and phase.  A lane
+// multiplies at most ten box slacks (>= 1e-15 by mmpc_box_t) or nine row slacks between init() and value(): the product stays a normal
+// number down to slacks of 1e-30, and scaling by powers of two being exact it has the mantissa the product of the mantissas had
+// (rounds 1-3 split every factor with frexp: four instructions per row instead of one).  `ex` carries the exponent handed over
+// between the two evaluation phases of the long horizons.
 struct MmpcLogAcc {
     double mant; int ex;
     MMPC_DEV void init() { mant = 1.0; ex = 0; }
-    // (a lane multiplies at most a few dozen mantissas in [0.5, 1) between init() and value(): no underflow, no renormalisation)
-    MMPC_DEV void mul(double t) { int e; mant *= frexp(t, &e); ex += e; }
+    MMPC_DEV void mul(double t) { mant *= t; }
     MMPC_DEV double value() const { int e = ex; const double l = mmpc_log_mant(mant, &e); return l + (double)e * 0.69314718055994530942; }
 };
 
