@@ -303,6 +303,10 @@ MMPC_DEV double mmpc_op_add(double a, double b) { return a + b; }
 MMPC_WAVE_RED(mmpc_wave_sum, mmpc_op_add)
 MMPC_WAVE_RED(mmpc_wave_max, mmpc_vmax)
 MMPC_WAVE_RED(mmpc_wave_min, mmpc_vmin)
+MMPC_WAVE_RED4(mmpc_wave_sum4, mmpc_op_add)
+MMPC_WAVE_RED4(mmpc_wave_max4, mmpc_vmax)
+#define MMPC_RED4_SUM(i0, i1, i2, i3, out) mmpc_wave_sum4(wr_one[i0], wr_one[i1], wr_one[i2], wr_one[i3], out)
+#define MMPC_RED4_MAX(i0, i1, i2, i3, out) mmpc_wave_max4(wr_one[i0], wr_one[i1], wr_one[i2], wr_one[i3], out)
 #else
 MMPC_DEV double mmpc_wave_sum(double v) {
 #pragma unroll
@@ -323,6 +327,10 @@ MMPC_DEV double mmpc_wave_min(double v) {
 #define MMPC_RED_SUM(i) mmpc_wave_sum(wr_one[i])
 #define MMPC_RED_MAX(i) mmpc_wave_max(wr_one[i])
 #define MMPC_RED_MIN(i) mmpc_wave_min(wr_one[i])
+#if !MMPC_RED_DPP
+#define MMPC_RED4_SUM(i0, i1, i2, i3, out) { (out)[0] = MMPC_RED_SUM(i0); (out)[1] = MMPC_RED_SUM(i1); (out)[2] = MMPC_RED_SUM(i2); (out)[3] = MMPC_RED_SUM(i3); }
+#define MMPC_RED4_MAX(i0, i1, i2, i3, out) { (out)[0] = MMPC_RED_MAX(i0); (out)[1] = MMPC_RED_MAX(i1); (out)[2] = MMPC_RED_MAX(i2); (out)[3] = MMPC_RED_MAX(i3); }
+#endif
 #else
 // host emulation: butterfly in the same pairing order as the device shuffles, so that the
 // floating-point sums are bit-identical on every "lane"
@@ -344,6 +352,28 @@ static inline double mmpc_emu_red(double (*wr)[9], int i, int op) {
 #define MMPC_RED_SUM(i) mmpc_emu_red(wr_all, i, 0)
 #define MMPC_RED_MAX(i) mmpc_emu_red(wr_all, i, 1)
 #define MMPC_RED_MIN(i) mmpc_emu_red(wr_all, i, 2)
+// the four-at-a-time reductions of the device (MMPC_WAVE_RED4): lane l with l + 32, the result with its neighbour 16 lanes on, then the
+// in-row butterfly of mmpc_emu_red over 16 lanes
+static inline double mmpc_emu_red4(double (*wr)[9], int i, int op) {
+    if (!MMPC_RED_DPP) return mmpc_emu_red(wr, i, op);
+    double v[16], w[16];
+    for (int l = 0; l < 16; l++) {
+        const double a0 = wr[l][i], a1 = wr[l + 16][i], a2 = wr[l + 32][i], a3 = wr[l + 48][i];
+        const double s0 = op == 0 ? a0 + a2 : (a0 > a2 ? a0 : a2), s1 = op == 0 ? a1 + a3 : (a1 > a3 ? a1 : a3);
+        v[l] = op == 0 ? s0 + s1 : (s0 > s1 ? s0 : s1);
+    }
+    for (int q = 0; q < 4; q++) {
+        const int o = 1 << q;
+        for (int l = 0; l < 16; l++) {
+            const int p = o == 4 ? ((l & ~7) | (7 - (l & 7))) : (o == 8 ? (15 - l) : (l ^ o));
+            w[l] = op == 0 ? v[l] + v[p] : (v[l] > v[p] ? v[l] : v[p]);
+        }
+        for (int l = 0; l < 16; l++) v[l] = w[l];
+    }
+    return v[0];
+}
+#define MMPC_RED4_SUM(i0, i1, i2, i3, out) { (out)[0] = mmpc_emu_red4(wr_all, i0, 0); (out)[1] = mmpc_emu_red4(wr_all, i1, 0); (out)[2] = mmpc_emu_red4(wr_all, i2, 0); (out)[3] = mmpc_emu_red4(wr_all, i3, 0); }
+#define MMPC_RED4_MAX(i0, i1, i2, i3, out) { (out)[0] = mmpc_emu_red4(wr_all, i0, 1); (out)[1] = mmpc_emu_red4(wr_all, i1, 1); (out)[2] = mmpc_emu_red4(wr_all, i2, 1); (out)[3] = mmpc_emu_red4(wr_all, i3, 1); }
 #endif
 
 // pair lanes (MmpcFastDims::PADMAP): per phase, the lane's base index and per-pass stride; per pass, the pair's index into XU / DXU / RB /

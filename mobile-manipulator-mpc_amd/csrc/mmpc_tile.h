@@ -186,6 +186,32 @@ MMPC_DEV double NAME(double v) {                                                
     v = OP(v, mmpc_xor16_f64(v, mmpc_lane_id()));                                                             \
     v = OP(v, mmpc_xor32_f64(v));                                                                             \
     return v; }
+// FOUR reductions of one kind at once.  v_permlane32_swap / v_permlane16_swap exchange halves / rows BETWEEN two registers, so a
+// pair of partials (a, b) needs no copies and no selects: after the swap one register holds (a's lower half, b's lower half), the other
+// (a's upper half, b's upper half), and ONE combine leaves a reduced over the two halves in lanes 0-31 and b in lanes 32-63; the same
+// over the rows of 16 leaves a, c, b, d - each reduced over its four rows - in rows 0, 1, 2, 3; one in-row butterfly then reduces
+// all four, and v_readlane hands each result to the whole wave through a scalar pair.  29 vector instructions instead of 4 x 30.
+// Pairing order (the host emulation mirrors it, mmpc_emu_red4): lane l with l + 32, then with l + 16, then the in-row steps 1, 2,
+// half-row mirror, row mirror of the single reductions.
+#define MMPC_WAVE_RED4(NAME, OP)                                                                              \
+MMPC_DEV void NAME(double a, double b, double c, double d, double *out) {                                      \
+    auto swp32 = [](double &x, double &y) {                                                                    \
+        const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(x), __double2loint(y), false, false); \
+        const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(x), __double2hiint(y), false, false); \
+        x = __hiloint2double(hi[0], lo[0]); y = __hiloint2double(hi[1], lo[1]); };                           \
+    auto swp16 = [](double &x, double &y) {                                                                    \
+        const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(x), __double2loint(y), false, false); \
+        const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(x), __double2hiint(y), false, false); \
+        x = __hiloint2double(hi[0], lo[0]); y = __hiloint2double(hi[1], lo[1]); };                           \
+    swp32(a, b); double u = OP(a, b);                                                                          \
+    swp32(c, d); double w = OP(c, d);                                                                          \
+    swp16(u, w); double v = OP(u, w);                                                                          \
+    v = OP(v, mmpc_dpp_f64<0xB1>(v));                                                                          \
+    v = OP(v, mmpc_dpp_f64<0x4E>(v));                                                                          \
+    v = OP(v, mmpc_dpp_f64<0x141>(v));                                                                         \
+    v = OP(v, mmpc_dpp_f64<0x140>(v));                                                                         \
+    out[0] = mmpc_readlane_f64(v, 0); out[2] = mmpc_readlane_f64(v, 16);                                      \
+    out[1] = mmpc_readlane_f64(v, 32); out[3] = mmpc_readlane_f64(v, 48); }
 #endif
 #endif
 
