@@ -815,7 +815,13 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
         for (int i = lane; i < NS * NX; i += MMPC_WAVE) if (i >= NX) LAM[i] += d_alpha * DLAM[i];
         for (int i = lane; i < NS; i += MMPC_WAVE) S[i] += d_alpha * DS[i];
         LANES_END
-        if (MMPC_SAFEGUARD_LAZY && first && MMPC_WAVE_ANY(!(pz_lo >= 2.0 * mu * (1.0 / MMPC_KAPPA_SIGMA) && pz_hi <= 0.5 * MMPC_KAPPA_SIGMA * mu))) {
+        // (-DMMPC_SAFEGUARD_FORCE: the exact clamp after every first trial - the tests' way into the branch no solve takes by itself)
+#ifdef MMPC_SAFEGUARD_FORCE
+        constexpr bool zforce = true;
+#else
+        constexpr bool zforce = false;
+#endif
+        if (MMPC_SAFEGUARD_LAZY && first && MMPC_WAVE_ANY(zforce || !(pz_lo >= 2.0 * mu * (1.0 / MMPC_KAPPA_SIGMA) && pz_hi <= 0.5 * MMPC_KAPPA_SIGMA * mu))) {
             // (rare) the exact clamp of every row, at the slacks of the trial point
             LANES_BEGIN
             auto &ls = MMPC_LS;

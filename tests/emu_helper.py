@@ -23,14 +23,16 @@ class MmpcParams(C.Structure):
                 ("L", C.c_int), ("hs", (C.c_double * 6) * 8), ("u_guess", C.c_void_p), ("as_written", C.c_int)]
 
 
-def build(asan=False):
-    out = os.path.join(_HERE, "emu", "_build", "libmmpc_emu_asan.so" if asan else "libmmpc_emu.so")
+def build(asan=False, defs=()):
+    """defs: extra -D switches of the kernel source (A/B switches such as MMPC_PADMAP=0): a library of its own per set"""
+    tag = ("_" + "_".join(d.replace("=", "") for d in defs)) if defs else ""
+    out = os.path.join(_HERE, "emu", "_build", ("libmmpc_emu_asan%s.so" if asan else "libmmpc_emu%s.so") % tag)
     csrc = os.path.dirname(_FAST)
     newest = max(os.path.getmtime(f) for f in [_SRC, _CORE, _FAST, _TILE, _IK] + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith('.inc')])
     if not os.path.exists(out) or os.path.getmtime(out) < newest:
         os.makedirs(os.path.dirname(out), exist_ok=True)
         flags = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer"] if asan else ["-O2"]
-        subprocess.check_call(["g++", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", *flags, "-o", out, _SRC])
+        subprocess.check_call(["g++", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", *flags, *["-D" + d for d in defs], "-o", out, _SRC])
     return out
 
 
@@ -67,8 +69,8 @@ def _p(a):
     return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
 
 
-def solve_batch(par, x_init, traj_ref, u_ref, u_last, obs, x_guess=None, reverse=False, asan=False, fast=False, u_guess=None, **kw):
-    lib = C.CDLL(build(asan))
+def solve_batch(par, x_init, traj_ref, u_ref, u_last, obs, x_guess=None, reverse=False, asan=False, fast=False, u_guess=None, defs=(), **kw):
+    lib = C.CDLL(build(asan, defs))
     assert lib.mmpc_emu_params_size() == C.sizeof(MmpcParams)
     x_init = np.ascontiguousarray(x_init, float); traj_ref = np.ascontiguousarray(traj_ref, float)
     u_ref = np.ascontiguousarray(u_ref, float); u_last = np.ascontiguousarray(u_last, float)
