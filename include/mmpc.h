@@ -62,6 +62,8 @@ typedef struct mmpc_config {
     double ulim[2][5]; /* [lo|hi][nu] */
     double xlim[2][9]; /* [lo|hi][nx]; psi entry +-INFINITY (mpc_base.py:16 stores 5 columns) */
     double dulim[2][5];
+                       /* a limit of magnitude >= 1e19 (in particular +-INFINITY) is no row: IPOPT's nlp_lower/upper_bound_inf,
+                          which the reference leaves at their defaults */
     int L;             /* half-space ("manipulation") obstacles, 0..8: len(obstacle_manipulation_list)
                           (mpc_wholebody_qref.py:10,39; demo_wholebody_qref.py:21-33); whole-body kind only */
     double halfspace[8][6]; /* per obstacle: point (3), outward normal (3).  One row per (stage, arm sample point):

@@ -327,6 +327,10 @@ MMPC_DEV void mmpc_prox_update(double ap, double alpha, double &prox, int &nsmal
     else if (alpha > 0.5) prox = prox > MMPC_PROX0 * 1e-3 ? 0.25 * prox : 0.0;
 }
 MMPC_DEV bool mmpc_finite(double v) { return fabs(v) < 1.0e300; }
+// a simple bound counts as absent from 1e19 on, as in IPOPT (nlp_lower_bound_inf / nlp_upper_bound_inf = -+1e19; the reference
+// leaves them at their defaults): a "large number for infinity" does not become a row - and the slack of such a row would be the one
+// factor that can overflow the product form of the barrier's log sum (MmpcLogAcc)
+MMPC_DEV bool mmpc_bound_active(double b) { return fabs(b) < 1.0e19; }
 
 // ---- light-weight sincos (both kernels; the generic one used the library routine until round 3) ------------
 // sin/cos: Cody-Waite reduction by pi/2 (three-part constant, exact for |x| < ~1e6 rad: heading and
@@ -635,7 +639,7 @@ MMPC_DEV void mmpc_solve_one(const MmpcParams &P, const MmpcIO io, double *lds M
             const int q = r - SL_XLO;
             b = q < NX ? WTS[MMPC_W_XLIM + q] : WTS[MMPC_W_XLIM + 9 + q - NX];
         }
-        return mmpc_finite(b);
+        return mmpc_bound_active(b);
     };
     auto obs_ptr = [&](int k, int m) -> const double * {
         return OBS + ((OPS ? k * M : 0) + m) * 3;

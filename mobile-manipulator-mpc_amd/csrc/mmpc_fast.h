@@ -626,14 +626,14 @@ MMPC_DEV void mmpc_solve_fast(const MmpcParams &P, const MmpcIO io, double *lds 
         if (v < NX) {
             lo = CST[MMPC_C_XLIM + v]; hi = CST[MMPC_C_XLIM + 9 + v];
             const bool ex = k >= 1;
-            alo = ex && mmpc_finite(lo); ahi = ex && mmpc_finite(hi);
+            alo = ex && mmpc_bound_active(lo); ahi = ex && mmpc_bound_active(hi);
         } else {
             const int a = v - NX;
             const double ul = ulast_at(k, a);
             lo = mmpc_vmax(CST[MMPC_C_ULIM + a], ul + CST[MMPC_C_DULIM + a]);
             hi = mmpc_vmin(CST[MMPC_C_ULIM + 5 + a], ul + CST[MMPC_C_DULIM + 5 + a]);
             const bool ex = k < N;
-            alo = ex && mmpc_finite(lo); ahi = ex && mmpc_finite(hi);
+            alo = ex && mmpc_bound_active(lo); ahi = ex && mmpc_bound_active(hi);
         }
     };
     // cost weight (diagonal, already doubled) of variable v at stage k;  second = W2 weight (inputs)
